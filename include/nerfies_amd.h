@@ -1,0 +1,213 @@
+/* nerfies_amd.h -- C-ABI of the MI355X-native nerfies hot path.
+ *
+ * The reference (google/nerfies) is pure Python on JAX and has NO FFI / plugin
+ * boundary: the seam this library replaces is the Python call
+ *   NerfModel.apply            nerfies/models.py:289-375
+ * together with its two callers
+ *   training.train_step        nerfies/training.py:138-271
+ *   evaluation.render_image    nerfies/evaluation.py:28-101
+ * Each entry point below cites the reference function it stands in for.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host.
+ *   - the caller owns every buffer, including the workspace; the library never
+ *     allocates, frees or synchronises per call (hipGraph-capture safe).
+ *   - all work is enqueued on the caller's hipStream_t (passed as void*).
+ *   - every entry returns 0 on success or a negative NRF_E_* code; nothing
+ *     throws or aborts.  nrf_last_error() returns a static message.
+ *   - fp32 everywhere (the reference computes in fp32); ids are int32.
+ */
+#ifndef NERFIES_AMD_H_
+#define NERFIES_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRF_VERSION 100 /* 0.1.0 */
+
+enum {
+  NRF_OK = 0,
+  NRF_E_NULL = -1,        /* null pointer */
+  NRF_E_SHAPE = -2,       /* bad size / shape */
+  NRF_E_UNSUPPORTED = -3, /* configuration outside what the kernels cover */
+  NRF_E_HIP = -4,         /* HIP runtime error (see nrf_last_error) */
+  NRF_E_WORKSPACE = -5,   /* workspace too small */
+  NRF_E_STATE = -6        /* call order (backward without a stashed forward) */
+};
+
+enum { NRF_ACT_RELU = 0, NRF_ACT_SOFTPLUS = 1 };
+
+/* Every NerfModel attribute that reaches the hot path (models.py:75-119), as
+ * POD.  Defaults are those of configs.ModelConfig (configs.py:35-105). */
+typedef struct nrf_model_desc {
+  int32_t num_coarse_samples;      /* models.py:75  */
+  int32_t num_fine_samples;        /* models.py:76  (0 = coarse only) */
+  int32_t use_viewdirs;            /* models.py:77  */
+  float near_plane;                /* models.py:78  */
+  float far_plane;                 /* models.py:79  */
+  int32_t nerf_trunk_depth;        /* 8   */
+  int32_t nerf_trunk_width;        /* 256 */
+  int32_t nerf_rgb_branch_depth;   /* 1   */
+  int32_t nerf_rgb_branch_width;   /* 128 */
+  int32_t nerf_skip_layer;         /* nerf_skips = (4,)  -> 4; -1 = none */
+  int32_t use_stratified_sampling; /* models.py:88; eval.py:239 forces 0 */
+  int32_t num_nerf_point_freqs;    /* models.py:89  */
+  int32_t num_nerf_viewdir_freqs;  /* models.py:90  */
+  int32_t sigma_activation;        /* NRF_ACT_*  (defaults.gin:66 softplus) */
+  int32_t use_white_background;
+  int32_t use_linear_disparity;
+  int32_t use_sample_at_infinity;
+  /* metadata / conditions (models.py:186-228) */
+  int32_t use_appearance_metadata;
+  int32_t num_appearance_embeddings; /* max(appearance_ids)+1, models.py:121 */
+  int32_t num_appearance_features;
+  int32_t use_camera_metadata;
+  int32_t num_camera_embeddings;
+  int32_t num_camera_features;
+  int32_t use_alpha_condition; /* also gates appearance->rgb (models.py:206) */
+  int32_t use_rgb_condition;   /* accepted, unused -- as in the reference */
+  int32_t use_trunk_condition; /* never forwarded by construct_nerf */
+  /* warp field (warping.py:202-389, SE3Field) */
+  int32_t use_warp;
+  int32_t num_warp_freqs;
+  int32_t num_warp_embeddings;
+  int32_t num_warp_features;
+} nrf_model_desc;
+
+typedef struct nrf_handle_s* nrf_handle;
+
+/* One leaf of the parameter tree inside the single flat fp32 buffer.  `name`
+ * is the flax path below params['model'], e.g.
+ * "nerf_mlps_coarse/MLP_0/hidden_4/kernel" -- kernels are [in,out] row-major
+ * exactly as flax nn.Dense stores them. */
+typedef struct nrf_tensor_info {
+  char name[96];
+  int64_t offset; /* in floats from the start of the flat buffer */
+  int32_t rows;   /* in  (embedding: num_embeddings) ; bias: 1 */
+  int32_t cols;   /* out (embedding: features) */
+} nrf_tensor_info;
+
+/* rays_dict of NerfModel.__call__ (models.py:300-329). */
+typedef struct nrf_rays {
+  int32_t num_rays;
+  const float* origins;          /* (B,3) */
+  const float* directions;       /* (B,3) */
+  const float* viewdirs;         /* (B,3) or NULL -> directions (models.py:326-329) */
+  const int32_t* warp_ids;       /* (B,) metadata['warp'] or NULL */
+  const int32_t* appearance_ids; /* (B,) or NULL */
+  const int32_t* camera_ids;     /* (B,) or NULL */
+} nrf_rays;
+
+/* warp_extra + the per-step scalars of training.ScalarParams (training.py:35-43). */
+typedef struct nrf_step_scalars {
+  float warp_alpha; /* warp_extra['alpha'] */
+  float time_alpha; /* accepted, unused (no preset selects the time encoder) */
+} nrf_step_scalars;
+
+/* Stand-in for the flax RNG streams 'coarse' / 'fine' (models.py:333,355).
+ * Either explicit uniforms (parity runs) or an on-device Philox4x32-10 keyed by
+ * (seed, offset) (throughput runs).  Ignored when use_stratified_sampling=0. */
+typedef struct nrf_rand {
+  const float* t_rand; /* (B,N_c) in [0,1) or NULL */
+  const float* u;      /* (B,N_f) in [0,1) or NULL */
+  uint64_t seed;
+  uint64_t offset;
+} nrf_rand;
+
+/* One level of the NerfModel output dict (models.py:278-287). Any pointer may
+ * be NULL to skip that output. */
+typedef struct nrf_level_out {
+  float* rgb;       /* (B,3) */
+  float* depth;     /* (B,)  */
+  float* med_depth; /* (B,)  */
+  float* acc;       /* (B,)  */
+  float* weights;   /* (B,S) */
+  float* z_vals;    /* (B,S)  (extra: the sample depths of this level) */
+} nrf_level_out;
+
+typedef struct nrf_outputs {
+  nrf_level_out coarse;
+  nrf_level_out fine;
+} nrf_outputs;
+
+/* flags for nrf_forward / nrf_workspace_bytes */
+#define NRF_FLAG_TRAIN 1u /* keep the activation stash nrf_backward needs */
+
+int nrf_version(void);
+const char* nrf_last_error(void);
+
+/* models.construct_nerf (models.py:378-489) minus parameter init: validates the
+ * configuration and fixes the parameter layout. */
+int nrf_create(const nrf_model_desc* desc, nrf_handle* out);
+int nrf_destroy(nrf_handle h);
+
+int nrf_param_count(nrf_handle h, int64_t* n_floats);
+/* out may be NULL to query *n only. */
+int nrf_param_layout(nrf_handle h, nrf_tensor_info* out, int32_t* n);
+
+int nrf_workspace_bytes(nrf_handle h, int32_t num_rays, uint32_t flags, size_t* bytes);
+
+/* NerfModel.apply (models.py:289-375): sampling, [warp,] posenc, NeRF MLPs,
+ * compositing, hierarchical resampling, fine pass. */
+int nrf_forward(nrf_handle h, const float* params, const nrf_rays* rays,
+                const nrf_step_scalars* scalars, const nrf_rand* rnd,
+                const nrf_outputs* out, uint32_t flags, void* workspace,
+                size_t workspace_bytes, void* stream);
+
+/* Reverse pass of the nrf_forward(NRF_FLAG_TRAIN) call that last used this
+ * workspace: the VJP jax.value_and_grad builds at training.py:264-265.
+ * d_rgb_coarse / d_rgb_fine are dL/d(out[level]['rgb']) (B,3); either may be
+ * NULL.  grad_params (flat, same layout as params) is OVERWRITTEN. */
+int nrf_backward(nrf_handle h, const float* params, const nrf_rays* rays,
+                 const float* d_rgb_coarse, const float* d_rgb_fine,
+                 float* grad_params, void* workspace, size_t workspace_bytes,
+                 void* stream);
+
+/* training.train_step up to (excluding) pmean + Adam (training.py:168-265):
+ * forward, loss = MSE_coarse + MSE_fine (training.py:172,261), backward.
+ * target_rgb (B,3).  stats[8] (device): {mse_coarse, mse_fine, psnr_coarse,
+ * psnr_fine, loss_total, 0,0,0}.  grad_params is OVERWRITTEN. */
+int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* rays,
+                             const float* target_rgb, const nrf_step_scalars* scalars,
+                             const nrf_rand* rnd, float* grad_params, float* stats,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
+/* flax.optim.Adam.apply_gradient (training.py:268-269; flax 0.3.4 optim/adam.py):
+ * g = grad*grad_scale (grad_scale = 1/world_size folds lax.pmean, training.py:266),
+ * m,v updated in place, step = number of updates already applied. */
+int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n,
+                  float lr, float beta1, float beta2, float eps, int64_t step,
+                  float grad_scale, void* stream);
+
+/* ---- individual operators (same device code the fused path runs), exposed so
+ * parity tests can check each reference function in isolation. ---- */
+
+/* model_utils.sample_along_rays (model_utils.py:36-73) -> z_vals (B,N). */
+int nrf_sample_along_rays(const float* origins, const float* directions, int32_t num_rays,
+                          int32_t num_samples, float near_plane, float far_plane,
+                          int32_t stratified, int32_t linear_disparity,
+                          const float* t_rand, uint64_t seed, uint64_t offset,
+                          float* z_vals, void* stream);
+
+/* model_utils.volumetric_rendering (+ compute_depth_map) (model_utils.py:76-136,
+ * 218-263).  rgb_sigma is (B,S,4) = (r,g,b,sigma) post-activation. */
+int nrf_volumetric_rendering(const float* rgb_sigma, const float* z_vals, const float* directions,
+                             int32_t num_rays, int32_t num_samples, int32_t white_background,
+                             int32_t sample_at_infinity, const nrf_level_out* out, void* stream);
+
+/* model_utils.sample_pdf (model_utils.py:139-215) applied as models.py:353-357:
+ * bins = midpoints of z_coarse, weights = weights_coarse[:,1:-1]; returns the
+ * sorted union (B, N_c+N_f). */
+int nrf_sample_pdf(const float* z_coarse, const float* weights_coarse, int32_t num_rays,
+                   int32_t num_coarse, int32_t num_fine, int32_t stratified, const float* u,
+                   uint64_t seed, uint64_t offset, float* z_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFIES_AMD_H_ */

@@ -1,0 +1,558 @@
+// Fused NeRF-MLP chain for gfx950: posenc -> 8x256 trunk (skip at 4) ->
+// alpha head / bottleneck -> rgb branch, forward and data-gradient passes.
+//
+// Replaces (reference, /root/reference/nerfies):
+//   modules.SinusoidalEncoder   modules.py:172-228  (fused into the tile prologue)
+//   modules.MLP / NerfMLP       modules.py:26-62, 65-169
+//   nn.sigmoid / sigma_activation  models.py:276-277
+//
+// Design (one workgroup = 4 waves = one 128-row tile, persistent over tiles):
+//   * activations of the tile live in LDS, feature-major  act[k][128 rows]
+//     (XOR-swizzled 16-byte granules so the MFMA epilogue's ds_write_b128 and
+//     the A-operand ds_read_b128 are both bank-conflict free at pitch 128);
+//   * every layer is  acc[128 x 64 per wave] += A(LDS) x B(weights), with
+//     v_mfma_f32_32x32x2_f32 (exact fp32 == an fmaf chain).  Rows are
+//     interleaved so that MFMA row-block rb holds tile rows p = 4*i + rb: one
+//     ds_read_b128 then feeds the A operand of all four row blocks;
+//   * weights are pre-packed per layer in B-fragment order, so each lane
+//     streams its B operands with one coalesced global_load_dwordx4 per 16
+//     MFMAs straight from L2 -- no LDS traffic for weights;
+//   * the training stash is written straight from the accumulator registers in
+//     "fragment-native" order (coalesced 1 KiB per wave store); the dgrad pass
+//     and the wgrad GEMM read it back in the same order.
+#include "nrf_internal.h"
+
+namespace nrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// Stash stores go through a wave-uniform buffer descriptor: the per-register offset rides in the
+// scalar offset, so one voffset VGPR (lane*16) serves every store (no per-store 64-bit address).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ void buf_store4(const float4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  u32x4 d;
+  d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
+}
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// LDS address (in floats) of granule (k, i): 4 consecutive tile rows 4i..4i+3 of feature k.
+__device__ __forceinline__ int act_addr(int k, int i) { return k * TILE_ROWS + 4 * (i ^ (k & 7)); }
+
+// acc[rb][cb] += A[128 x K] * B[K x 64(32)] for this wave.
+//   lds_in : feature-major tile, pitch 128 floats; SWZ selects the swizzled act layout.
+//   wp     : this wave's packed weights, [it][lane] float4.
+//   NCB=2  : it covers 4 k  (float4 = {ks0 cb0, ks0 cb1, ks1 cb0, ks1 cb1}), nit = K/4
+//   NCB=1  : it covers 8 k  (float4 = ks0..ks3),                               nit = K/8
+template <int NCB, bool SWZ>
+__device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[4][NCB], const float* lds_in, int nit,
+                                            const float4* __restrict__ wp, int lane) {
+  const int i = lane & 31, kk = lane >> 5;
+  constexpr int KS = (NCB == 2) ? 2 : 4;   // k-steps (of 2 k) per iteration
+  auto lda = [&](int it, int s) -> float4 {
+    const int k = it * (2 * KS) + 2 * s + kk;
+    const int a = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
+    return *reinterpret_cast<const float4*>(lds_in + a);
+  };
+  float4 b_n = wp[lane];
+  float4 a_n[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) a_n[s] = lda(0, s);
+  for (int it = 0; it < nit; ++it) {
+    const float4 b = b_n;
+    float4 a[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a[s] = a_n[s];
+    const int itn = (it + 1 < nit) ? it + 1 : it;
+    b_n = wp[itn * 64 + lane];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a_n[s] = lda(itn, s);
+    const float bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float av[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
+#pragma unroll
+      for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          acc[rb][cb] = mfma32(av[rb], bv[(NCB == 2) ? (2 * s + cb) : s], acc[rb][cb]);
+        }
+      }
+    }
+  }
+}
+
+template <int NCB>
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4][NCB]) {
+#pragma unroll
+  for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+}
+
+// row-in-block index of accumulator register `reg` for lane half h (C/D layout of 32x32 MFMA)
+__device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// Epilogue-side form of act_addr(n, c_row(reg, h)): the swizzle only touches the low 3 bits of the
+// granule index, so 4 per-lane offsets (one per reg&3) plus an immediate cover all 16 registers.
+struct EpiAddr {
+  int sw[4];
+  __device__ __forceinline__ EpiAddr(int lane) {
+    const int jx = lane & 7, h = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sw[q] = 4 * ((q + 4 * h) ^ jx);
+  }
+  __device__ __forceinline__ int operator()(int n, int reg) const { return n * TILE_ROWS + sw[reg & 3] + 32 * (reg >> 2); }
+};
+
+__device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
+
+// ---------------------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------------------
+// sign bits of one float4 (4 row blocks of one accumulator register) -> 4-bit nibble
+__device__ __forceinline__ uint32_t sign_nibble(const float4& v) {
+  return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
+}
+
+// bits_wave: this (layer, tile, wave)'s mask words, [lane][2*NCB] dwords; dword = cb*2 + reg/8,
+// nibble = reg%8, bit = row block.
+template <int NCB, bool RELU, bool STASH>
+__device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[4][NCB], const float* __restrict__ bias,
+                                             int ncol0, float* act, __amdgpu_buffer_rsrc_t stash, int stash_soff,
+                                             uint32_t* bits_wave, int lane) {
+  const int j = lane & 31;
+  const EpiAddr ea(lane);
+  __syncthreads();   // every wave has finished reading the previous activations
+  uint32_t mb[2 * NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int n = ncol0 + 32 * cb + j;
+    const float bv = bias[n];
+    mb[2 * cb] = mb[2 * cb + 1] = 0u;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      float4 v;
+      v.x = acc[0][cb][reg] + bv; v.y = acc[1][cb][reg] + bv;
+      v.z = acc[2][cb][reg] + bv; v.w = acc[3][cb][reg] + bv;
+      if (RELU) {
+        if (STASH) mb[2 * cb + (reg >> 3)] |= sign_nibble(v) << (4 * (reg & 7));
+        v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w);
+      }
+      *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
+      if (STASH) buf_store4(v, stash, lane * 16, stash_soff + (cb * 16 + reg) * 1024);
+    }
+  }
+  if (STASH && RELU) {
+#pragma unroll
+    for (int q = 0; q < 2 * NCB; ++q) bits_wave[lane * (2 * NCB) + q] = mb[q];
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float sigma_activation(float x, int kind) {
+  if (kind == 1) {  // softplus, computed as jax.nn.softplus = logaddexp(x, 0)
+    return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+  }
+  return relu(x);
+}
+
+template <bool STASH>
+__global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                 // [256][128] swizzled
+  float* pe = smem + ACT_FLOATS;     // [PK][128]; reused as scratch after the skip layer
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int p = tid & 127;
+  const int half = wave >> 1;
+  const float* __restrict__ prm = A.params;
+  const int PK = A.PK;
+
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    // ---- prologue: sample point + SinusoidalEncoder (modules.py:213-228) ----
+    {
+      int r = tile * TILE_ROWS + p;
+      r = r < A.rows ? r : A.rows - 1;
+      float x[3];
+      if (A.points) {
+        x[0] = A.points[3 * r]; x[1] = A.points[3 * r + 1]; x[2] = A.points[3 * r + 2];
+      } else {
+        const int ray = r / A.S;
+        const float z = A.zvals[r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)   // origins + z_vals * directions  (model_utils.py:72-73)
+          x[c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
+      }
+      float* stp = STASH ? A.st_pe + (size_t)tile * PK * TILE_ROWS + p : nullptr;
+      auto put = [&](int k, float v) {
+        pe[k * TILE_ROWS + p] = v;
+        if (STASH) stp[k * TILE_ROWS] = v;
+      };
+      if (half == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) put(c, x[c]);
+      } else {
+        for (int k = A.P; k < PK; ++k) put(k, 0.f);
+      }
+      const float half_pi = 1.57079632679489661923f;   // fp32(pi/2), modules.py:222
+      for (int f = half; f < A.F; f += 2) {
+        const float fr = (float)(1 << f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float a = __fmul_rn(x[c], fr);
+          put(3 + (2 * f) * 3 + c, sinf(a));
+          put(3 + (2 * f + 1) * 3 + c, sinf(__fadd_rn(a, half_pi)));
+        }
+      }
+    }
+    __syncthreads();
+
+    f32x16 acc[4][2];
+    const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
+    const size_t st_h_layer = (size_t)A.ntiles * FRAG_TILE_256;       // floats
+    const int wv_soff = wave * 2 * 16 * 1024;                          // bytes: this wave's slice of a tile
+
+    // ---- trunk: 8 x Dense(256)+ReLU, skip concat [h, posenc] at layer 4 (modules.py:41-50) ----
+#pragma unroll 1
+    for (int l = 0; l < TRUNK_DEPTH; ++l) {
+      zero_acc<2>(acc);
+      if (l == 0) {
+        mfma_k_loop<2, false>(acc, pe, PK / 4, wpk4 + (A.pk.fwd_L[0] / 4) + wave * (PK / 4) * 64, lane);
+      } else {
+        mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane);
+        if (l == SKIP_LAYER)
+          mfma_k_loop<2, false>(acc, pe, PK / 4, wpk4 + (A.pk.fwd_L4b / 4) + wave * (PK / 4) * 64, lane);
+      }
+      fwd_epilogue<2, true, STASH>(
+          acc, prm + A.po.trunk_b[l], wave * 64, act,
+          make_rsrc(STASH ? A.st_h + l * st_h_layer + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff,
+          STASH ? A.bits_trunk + (((size_t)l * A.ntiles + tile) * 4 + wave) * 256 : nullptr, lane);
+    }
+
+    // ---- alpha head: Dense(256->1) on the trunk output (modules.py:152-157) ----
+    float sigma_raw = 0.f;
+    {
+      const float* __restrict__ wa = prm + A.po.alpha_k;
+      float s = 0.f;
+      const int k0 = half * 128;
+      const int g = p >> 2, e = p & 3;
+      for (int k = k0; k < k0 + 128; ++k) s = fmaf(act[k * TILE_ROWS + 4 * (g ^ (k & 7)) + e], wa[k], s);
+      pe[half * TILE_ROWS + p] = s;   // scratch (posenc no longer needed for this tile)
+      __syncthreads();
+      if (half == 0) sigma_raw = pe[p] + pe[TILE_ROWS + p] + prm[A.po.alpha_b];
+    }
+
+    // ---- bottleneck: Dense(256), no activation (modules.py:149-150) ----
+    zero_acc<2>(acc);
+    mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_bn / 4) + wave * 64 * 64, lane);
+    fwd_epilogue<2, false, STASH>(
+        acc, prm + A.po.bn_b, wave * 64, act,
+        make_rsrc(STASH ? A.st_bn + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff, nullptr, lane);
+
+    // ---- rgb branch hidden: Dense(256+R -> 128)+ReLU; the R per-ray condition columns are
+    //      folded into condterm[ray][n] (= cond . W[256:] + bias) by ray_prep ----
+    {
+      f32x16 acc1[4][1];
+      zero_acc<1>(acc1);
+      mfma_k_loop<1, true>(acc1, act, 32, wpk4 + (A.pk.fwd_rgbh / 4) + wave * 32 * 64, lane);
+      const int n = wave * 32 + j;
+      const __amdgpu_buffer_rsrc_t st = make_rsrc(STASH ? A.st_rgbh + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4);
+      const EpiAddr ea(lane);
+      __syncthreads();
+      uint32_t mb[2] = {0u, 0u};
+      // rows visited by this lane increase with (reg, rb): walk the ray boundaries instead of dividing
+      int ray = (tile * TILE_ROWS) / A.S;
+      int nextb = (ray + 1) * A.S - tile * TILE_ROWS;   // first tile row of the next ray
+      float ct = A.condterm[(size_t)min(ray, A.B - 1) * RGB_W + n];
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = c_row(reg, h);
+        float v[4];
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const int pr = 4 * i + rb;
+          while (pr >= nextb) { ++ray; nextb += A.S; ct = A.condterm[(size_t)min(ray, A.B - 1) * RGB_W + n]; }
+          v[rb] = acc1[rb][0][reg] + ct;
+        }
+        float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
+        if (STASH) mb[reg >> 3] |= sign_nibble(v4) << (4 * (reg & 7));
+        v4.x = relu(v4.x); v4.y = relu(v4.y); v4.z = relu(v4.z); v4.w = relu(v4.w);
+        *reinterpret_cast<float4*>(act + ea(n, reg)) = v4;
+        if (STASH) buf_store4(v4, st, lane * 16, (wave * 16 + reg) * 1024);
+      }
+      if (STASH) {
+        uint32_t* bw = A.bits_rgbh + ((size_t)tile * 4 + wave) * 128;
+        bw[lane * 2] = mb[0]; bw[lane * 2 + 1] = mb[1];
+      }
+      __syncthreads();
+    }
+
+    // ---- rgb logits Dense(128->3), sigmoid; sigma activation (models.py:276-277) ----
+    {
+      const float* __restrict__ wl = prm + A.po.logit_k;   // [128][3]
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      const int k0 = half * 64;
+      const int g = p >> 2, e = p & 3;
+      for (int k = k0; k < k0 + 64; ++k) {
+        const float a = act[k * TILE_ROWS + 4 * (g ^ (k & 7)) + e];
+        s0 = fmaf(a, wl[3 * k], s0); s1 = fmaf(a, wl[3 * k + 1], s1); s2 = fmaf(a, wl[3 * k + 2], s2);
+      }
+      if (half == 1) { pe[p] = s0; pe[TILE_ROWS + p] = s1; pe[2 * TILE_ROWS + p] = s2; }
+      __syncthreads();
+      if (half == 0) {
+        s0 += pe[p] + prm[A.po.logit_b]; s1 += pe[TILE_ROWS + p] + prm[A.po.logit_b + 1];
+        s2 += pe[2 * TILE_ROWS + p] + prm[A.po.logit_b + 2];
+        float4 o;
+        o.x = 1.f / (1.f + expf(-s0)); o.y = 1.f / (1.f + expf(-s1)); o.z = 1.f / (1.f + expf(-s2));
+        o.w = sigma_activation(sigma_raw, A.sigma_act);
+        A.out4[(size_t)tile * TILE_ROWS + p] = o;
+      }
+      __syncthreads();   // scratch (aliases pe) is free again for the next tile's prologue
+    }
+  }
+}
+
+void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)(ACT_FLOATS + a.PK * TILE_ROWS) * sizeof(float);
+  if (stash) {
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nerf_mlp_fwd_kernel<true>, dim3(grid), dim3(256), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nerf_mlp_fwd_kernel<false>, dim3(grid), dim3(256), lds, stream, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward (data gradients; bias gradients accumulated per workgroup)
+// ---------------------------------------------------------------------------------------------
+// small_part layout (floats): db_trunk[8][256] | db_bn[256] | db_rgbh[128] | db_logit[3] | db_alpha
+constexpr int SP_DB_TRUNK = 0, SP_DB_BN = 2048, SP_DB_RGBH = 2304, SP_DB_LOGIT = 2432, SP_DB_ALPHA = 2435;
+
+__device__ __forceinline__ float4 mask4(const float4& v, uint32_t nib) {
+  return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
+}
+
+__global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* act = smem;                 // [256][128] swizzled: current dpre tile
+  float* dr = smem + ACT_FLOATS;     // [4][128]: d raw rgb (3) and d raw sigma of the tile rows
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const float* __restrict__ prm = A.params;
+  const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
+
+  // per-lane bias-gradient accumulators, carried across this workgroup's tiles
+  float db_trunk[TRUNK_DEPTH][2];
+#pragma unroll
+  for (int l = 0; l < TRUNK_DEPTH; ++l) db_trunk[l][0] = db_trunk[l][1] = 0.f;
+  float db_bn[2] = {0.f, 0.f};
+  float db_rgbh = 0.f;
+  float dsum[4] = {0.f, 0.f, 0.f, 0.f};   // threads < 128: column sums of d_raw (logit / alpha bias grads)
+
+  const size_t layer_fl = (size_t)A.ntiles * FRAG_TILE_256;   // floats per trunk layer
+  const int wv = wave * 2 * 16 * 1024;                          // bytes: this wave's slice of a tile
+  const EpiAddr ea(lane);
+
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    if (tid < TILE_ROWS) {
+      const float4 d = A.d_raw4[(size_t)tile * TILE_ROWS + tid];
+      dr[tid] = d.x; dr[TILE_ROWS + tid] = d.y; dr[2 * TILE_ROWS + tid] = d.z; dr[3 * TILE_ROWS + tid] = d.w;
+      dsum[0] += d.x; dsum[1] += d.y; dsum[2] += d.z; dsum[3] += d.w;
+    }
+    __syncthreads();
+
+    // ---- rgb logit^T (3 -> 128) on the VALU, ReLU mask of the rgb hidden layer ----
+    {
+      const int n = wave * 32 + j;
+      const float w0 = prm[A.po.logit_k + 3 * n], w1 = prm[A.po.logit_k + 3 * n + 1], w2 = prm[A.po.logit_k + 3 * n + 2];
+      const uint32_t* bw = A.bits_rgbh + ((size_t)tile * 4 + wave) * 128;
+      const uint32_t mb[2] = {bw[lane * 2], bw[lane * 2 + 1]};
+      const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy_rgbh + (size_t)tile * FRAG_TILE_128, FRAG_TILE_128 * 4);
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int i = c_row(reg, h);
+        const float4 d0 = *reinterpret_cast<const float4*>(dr + 4 * i);
+        const float4 d1 = *reinterpret_cast<const float4*>(dr + TILE_ROWS + 4 * i);
+        const float4 d2 = *reinterpret_cast<const float4*>(dr + 2 * TILE_ROWS + 4 * i);
+        float4 v4 = make_float4(d0.x * w0 + d1.x * w1 + d2.x * w2, d0.y * w0 + d1.y * w1 + d2.y * w2,
+                                d0.z * w0 + d1.z * w1 + d2.z * w2, d0.w * w0 + d1.w * w1 + d2.w * w2);
+        v4 = mask4(v4, (mb[reg >> 3] >> (4 * (reg & 7))) & 15u);
+        db_rgbh += (v4.x + v4.y) + (v4.z + v4.w);
+        *reinterpret_cast<float4*>(act + ea(n, reg)) = v4;
+        buf_store4(v4, dy, lane * 16, (wave * 16 + reg) * 1024);
+      }
+    }
+    __syncthreads();
+    // ---- per-ray sums of dpre_rgbh (gradient of the per-ray condition columns of the rgb branch):
+    //      thread (n, half) walks 64 tile rows of feature n in LDS and flushes at ray boundaries ----
+    {
+      const int n = tid & 127, hf = tid >> 7;
+      const int row0 = 64 * hf;
+      const int grow0 = tile * TILE_ROWS + row0;
+      int ray = grow0 / A.S;
+      int nextb = (ray + 1) * A.S - tile * TILE_ROWS;   // first tile row of the next ray
+      const int nvalid = A.rows - tile * TILE_ROWS;      // tile rows >= nvalid are padding
+      float ray_sum = 0.f;
+#pragma unroll 1
+      for (int g = row0 / 4; g < row0 / 4 + 16; ++g) {
+        const float4 v4 = *reinterpret_cast<const float4*>(act + act_addr(n, g));
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int pr = 4 * g + e;
+          while (pr >= nextb) {
+            if (ray < A.B && ray_sum != 0.f) atomicAdd(A.dray + (size_t)ray * RGB_W + n, ray_sum);
+            ray_sum = 0.f; ++ray; nextb += A.S;
+          }
+          if (pr < nvalid) ray_sum += v[e];
+        }
+      }
+      if (ray < A.B && ray_sum != 0.f) atomicAdd(A.dray + (size_t)ray * RGB_W + n, ray_sum);
+    }
+
+    f32x16 acc[4][2];
+    // ---- d bottleneck = dpre_rgbh . W_rgbh[0:256]^T   (K=128 -> N=256), linear ----
+    zero_acc<2>(acc);
+    mfma_k_loop<2, true>(acc, act, 32, wpk4 + (A.pk.bwd_rgbhT / 4) + wave * 32 * 64, lane);
+    {
+      const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy_bn + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
+      __syncthreads();
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int n = wave * 64 + 32 * cb + j;
+        float bsum = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
+          bsum += (v.x + v.y) + (v.z + v.w);
+          *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
+          buf_store4(v, dy, lane * 16, wv + (cb * 16 + reg) * 1024);
+        }
+        db_bn[cb] += bsum;
+      }
+      __syncthreads();
+    }
+
+    // ---- d h8 = dbn . W_bn^T + d sigma_raw (x) w_alpha ; mask h8 > 0 -> dpre_7 ----
+    // ---- then l = 7..1:  d h_l = dpre_l . W_l[0:256]^T ; mask h_l > 0 -> dpre_{l-1} ----
+#pragma unroll 1
+    for (int l = TRUNK_DEPTH; l >= 1; --l) {
+      // the output of this step is dpre_{l-1}; its mask is sign(pre_{l-1}) = bits_trunk[l-1]
+      const uint4 mq = *reinterpret_cast<const uint4*>(A.bits_trunk + (((size_t)(l - 1) * A.ntiles + tile) * 4 + wave) * 256 + lane * 4);
+      const uint32_t mb[4] = {mq.x, mq.y, mq.z, mq.w};
+      zero_acc<2>(acc);
+      const int woff = (l == TRUNK_DEPTH) ? A.pk.bwd_bnT : A.pk.bwd_LT[l];
+      mfma_k_loop<2, true>(acc, act, 64, wpk4 + (woff / 4) + wave * 64 * 64, lane);
+      const __amdgpu_buffer_rsrc_t dy =
+          make_rsrc(A.dy_trunk + (size_t)(l - 1) * layer_fl + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
+      __syncthreads();
+      float bs[2];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        const int n = wave * 64 + 32 * cb + j;
+        const float wa = (l == TRUNK_DEPTH) ? prm[A.po.alpha_k + n] : 0.f;
+        float bsum = 0.f;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int i = c_row(reg, h);
+          float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
+          if (l == TRUNK_DEPTH) {
+            const float4 ds = *reinterpret_cast<const float4*>(dr + 3 * TILE_ROWS + 4 * i);
+            v.x = fmaf(ds.x, wa, v.x); v.y = fmaf(ds.y, wa, v.y); v.z = fmaf(ds.z, wa, v.z); v.w = fmaf(ds.w, wa, v.w);
+          }
+          v = mask4(v, (mb[2 * cb + (reg >> 3)] >> (4 * (reg & 7))) & 15u);
+          bsum += (v.x + v.y) + (v.z + v.w);
+          *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
+          buf_store4(v, dy, lane * 16, wv + (cb * 16 + reg) * 1024);
+        }
+        bs[cb] = bsum;
+      }
+      // runtime layer index -> static register: add into the matching accumulator
+#pragma unroll
+      for (int q = 0; q < TRUNK_DEPTH; ++q)
+        if (q == l - 1) { db_trunk[q][0] += bs[0]; db_trunk[q][1] += bs[1]; }
+      __syncthreads();
+    }
+  }
+
+  // ---- flush the per-workgroup partials ----
+  float* sp = A.small_part + (size_t)blockIdx.x * SMALL_PART;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    const int n = wave * 64 + 32 * cb + j;
+#pragma unroll
+    for (int l = 0; l < TRUNK_DEPTH; ++l) {
+      const float v = db_trunk[l][cb] + __shfl_xor(db_trunk[l][cb], 32);
+      if (h == 0) sp[SP_DB_TRUNK + l * TRUNK_W + n] = v;
+    }
+    const float vb = db_bn[cb] + __shfl_xor(db_bn[cb], 32);
+    if (h == 0) sp[SP_DB_BN + n] = vb;
+  }
+  {
+    const int n = wave * 32 + j;
+    const float vr = db_rgbh + __shfl_xor(db_rgbh, 32);
+    if (h == 0) sp[SP_DB_RGBH + n] = vr;
+  }
+  __syncthreads();
+  if (tid < TILE_ROWS) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dr[c * TILE_ROWS + tid] = dsum[c];
+  }
+  __syncthreads();
+  if (tid < 4) {
+    float s = 0.f;
+    for (int q = 0; q < TILE_ROWS; ++q) s += dr[tid * TILE_ROWS + q];
+    sp[tid < 3 ? SP_DB_LOGIT + tid : SP_DB_ALPHA] = s;
+  }
+}
+
+void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)(ACT_FLOATS + 4 * TILE_ROWS) * sizeof(float);
+  (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(256), lds, stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing: canonical [in,out] kernels -> per-wave B-fragment streams
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weights_kernel(const PackDesc* __restrict__ descs, const float* __restrict__ params,
+                                    float* __restrict__ ws) {
+  const PackDesc d = descs[blockIdx.y];
+  const float* __restrict__ src = params + d.src_off;
+  float* __restrict__ dst = ws + d.dst_off;
+  const int total = d.K * (d.ncb == 2 ? 256 : 128);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int e = idx & 3, lane = (idx >> 2) & 63;
+    const int per_it = 256;                       // floats per (wave, it)
+    const int nit = d.ncb == 2 ? d.K / 4 : d.K / 8;
+    const int it = (idx / per_it) % nit, w = idx / (per_it * nit);
+    int k, n;
+    if (d.ncb == 2) { k = 4 * it + 2 * (e >> 1) + (lane >> 5); n = 64 * w + 32 * (e & 1) + (lane & 31); }
+    else            { k = 8 * it + 2 * e + (lane >> 5);        n = 32 * w + (lane & 31); }
+    float v = 0.f;
+    if (k < d.kvalid) v = d.transposed ? src[(size_t)n * d.src_ld + k] : src[(size_t)(d.src_row0 + k) * d.src_ld + n];
+    dst[idx] = v;
+  }
+}
+
+void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float* ws, hipStream_t stream) {
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(64, ndesc), dim3(256), 0, stream, d_descs, params, ws);
+}
+
+}  // namespace nrf

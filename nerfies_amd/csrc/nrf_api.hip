@@ -1,0 +1,639 @@
+// C-ABI layer of the MI355X nerfies hot path: handle, flat-parameter layout, workspace plan and the
+// launch sequences that stand in for NerfModel.apply (models.py:289-375) and the gradient half of
+// training.train_step (training.py:168-265).  See include/nerfies_amd.h for the contract.
+#include "../../include/nerfies_amd.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "nrf_internal.h"
+
+using namespace nrf;
+
+namespace {
+
+thread_local char g_err[256] = "ok";
+
+int fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+int fail_hip(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), where);
+  return NRF_E_HIP;
+}
+
+constexpr size_t ALIGN_F = 64;   // workspace sub-buffers are aligned to 64 floats (256 B)
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct LevelWs {   // float offsets from the workspace base, per level (0 = coarse, 1 = fine)
+  size_t wpk, z, out4, rgb, depth, med, acc, weights, condterm;
+  size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
+  size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
+};
+
+struct WsPlan {
+  int B = -1;
+  uint32_t flags = 0;
+  int S[2], rows[2], ntiles[2];
+  size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
+  size_t pack_off_b, groups_off_b, reduce_off_b;
+  size_t cond, mse, zero_rgb, slabs;
+  LevelWs L[2];
+  size_t total_floats;
+  std::vector<PackDesc> pack;
+  std::vector<WgradGroup> groups;
+  std::vector<ReduceDesc> reduce;
+  int ntasks = 0;
+};
+
+}  // namespace
+
+struct nrf_handle_s {
+  nrf_model_desc d;
+  std::vector<nrf_tensor_info> layout;
+  int64_t nparams = 0;
+  MlpParamOffsets po[2];
+  PackOffsets pk;
+  int64_t app_off = -1, cam_off = -1, warp_embed_off = -1;
+  int P, PK, R, V, app_in_cond, nlevels;
+  int num_cus = 256;
+  bool cu_queried = false;
+  WsPlan plan;
+  // identity of the tables last uploaded to a workspace, and of the last stashed forward
+  void* uploaded_ws = nullptr;
+  int uploaded_B = -1;
+  uint32_t uploaded_flags = 0;
+  void* stashed_ws = nullptr;
+  int stashed_B = -1;
+};
+
+namespace {
+
+void add_leaf(nrf_handle h, const std::string& name, int rows, int cols, int64_t* off_out) {
+  nrf_tensor_info t;
+  memset(&t, 0, sizeof(t));
+  snprintf(t.name, sizeof(t.name), "%s", name.c_str());
+  t.offset = h->nparams;
+  t.rows = rows;
+  t.cols = cols;
+  if (off_out) *off_out = t.offset;
+  h->nparams += (int64_t)rows * cols;
+  h->nparams = (int64_t)align_up((size_t)h->nparams, 4);   // keep every leaf 16-byte aligned
+  h->layout.push_back(t);
+}
+
+void build_layout(nrf_handle h) {
+  const nrf_model_desc& d = h->d;
+  const int W = d.nerf_trunk_width;
+  for (int lv = 0; lv < h->nlevels; ++lv) {
+    const std::string base = lv == 0 ? "nerf_mlps_coarse" : "nerf_mlps_fine";
+    MlpParamOffsets& po = h->po[lv];
+    for (int i = 0; i < d.nerf_trunk_depth; ++i) {
+      int fin = i == 0 ? h->P : W;
+      if (i == d.nerf_skip_layer) fin += h->P;
+      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/kernel", fin, W, &po.trunk_k[i]);
+      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/bias", 1, W, &po.trunk_b[i]);
+    }
+    add_leaf(h, base + "/bottleneck/kernel", W, W, &po.bn_k);
+    add_leaf(h, base + "/bottleneck/bias", 1, W, &po.bn_b);
+    add_leaf(h, base + "/MLP_1/hidden_0/kernel", W + h->R, d.nerf_rgb_branch_width, &po.rgbh_k);
+    add_leaf(h, base + "/MLP_1/hidden_0/bias", 1, d.nerf_rgb_branch_width, &po.rgbh_b);
+    add_leaf(h, base + "/MLP_1/logit/kernel", d.nerf_rgb_branch_width, 3, &po.logit_k);
+    add_leaf(h, base + "/MLP_1/logit/bias", 1, 3, &po.logit_b);
+    add_leaf(h, base + "/MLP_2/logit/kernel", W, 1, &po.alpha_k);
+    add_leaf(h, base + "/MLP_2/logit/bias", 1, 1, &po.alpha_b);
+  }
+  if (d.use_appearance_metadata)
+    add_leaf(h, "appearance_encoder/embed/embedding", d.num_appearance_embeddings, d.num_appearance_features, &h->app_off);
+  if (d.use_camera_metadata)
+    add_leaf(h, "camera_encoder/embed/embedding", d.num_camera_embeddings, d.num_camera_features, &h->cam_off);
+}
+
+void build_pack_offsets(nrf_handle h) {
+  PackOffsets& pk = h->pk;
+  int o = 0;
+  auto take = [&](int n) { int r = o; o += n; return r; };
+  pk.fwd_L[0] = take(h->PK * 256);
+  for (int l = 1; l < TRUNK_DEPTH; ++l) pk.fwd_L[l] = take(256 * 256);
+  pk.fwd_L4b = take(h->PK * 256);
+  pk.fwd_bn = take(256 * 256);
+  pk.fwd_rgbh = take(256 * 128);
+  pk.bwd_rgbhT = take(128 * 256);
+  pk.bwd_bnT = take(256 * 256);
+  pk.bwd_LT[0] = 0;
+  for (int l = 1; l < TRUNK_DEPTH; ++l) pk.bwd_LT[l] = take(256 * 256);
+  pk.total = o;
+}
+
+// Lays out the workspace for B rays and (re)builds the descriptor tables.
+void build_plan(nrf_handle h, int B, uint32_t flags) {
+  WsPlan& p = h->plan;
+  if (p.B == B && p.flags == flags) return;
+  const nrf_model_desc& d = h->d;
+  const bool train = flags & NRF_FLAG_TRAIN;
+  p = WsPlan();
+  p.B = B;
+  p.flags = flags;
+  p.S[0] = d.num_coarse_samples;
+  p.S[1] = d.num_coarse_samples + d.num_fine_samples;
+  for (int lv = 0; lv < 2; ++lv) {
+    p.rows[lv] = B * p.S[lv];
+    p.ntiles[lv] = (p.rows[lv] + TILE_ROWS - 1) / TILE_ROWS;
+  }
+  const int G = h->num_cus;
+
+  // ---- wgrad groups (training) ----
+  const int target_tasks = 3 * G;
+  struct GroupSpec { int lv; int xk; size_t* xoff; int xstride; int kvalid; int Kb; int yk; size_t* yoff; int ystride; int Nb;
+                     int vec; int64_t dst; int dst_ld; int rows; int cols; int units; size_t xadd, yadd; };
+  std::vector<GroupSpec> specs;
+  const int Kb_pe = (h->PK + 31) / 32;
+  if (train) {
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      LevelWs& L = p.L[lv];
+      const MlpParamOffsets& po = h->po[lv];
+      const size_t layer = (size_t)p.ntiles[lv] * FRAG_TILE_256;
+      for (int l = 0; l < TRUNK_DEPTH; ++l) {
+        if (l == 0) {
+          specs.push_back({lv, SRC_PLAIN, &L.st_pe, h->PK * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
+                           po.trunk_k[0], 256, h->P, 256, Kb_pe * 8, 0, 0});
+        } else {
+          specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
+                           po.trunk_k[l], 256, 256, 256, 64, (size_t)(l - 1) * layer, (size_t)l * layer});
+          if (l == d.nerf_skip_layer)
+            specs.push_back({lv, SRC_PLAIN, &L.st_pe, h->PK * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
+                             po.trunk_k[l] + 256 * 256, 256, h->P, 256, Kb_pe * 8, 0, (size_t)l * layer});
+        }
+      }
+      specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, SRC_FRAG256, &L.dy_bn, FRAG_TILE_256, 8, 0,
+                       po.bn_k, 256, 256, 256, 64, (size_t)7 * layer, 0});
+      specs.push_back({lv, SRC_FRAG256, &L.st_bn, FRAG_TILE_256, 256, 8, SRC_FRAG128, &L.dy_rgbh, FRAG_TILE_128, 4, 0,
+                       po.rgbh_k, 128, 256, 128, 32, 0, 0});
+      // narrow heads on the VALU: alpha (X = h8, vec.w) and rgb logits (X = rgb hidden, vec.xyz)
+      specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, 0, nullptr, 0, 0, 1,
+                       po.alpha_k, 1, 256, 1, 12, (size_t)7 * layer, 0});
+      specs.push_back({lv, SRC_FRAG128, &L.st_rgbh, FRAG_TILE_128, 128, 4, 0, nullptr, 0, 0, 3,
+                       po.logit_k, 3, 128, 3, 6, 0, 0});
+    }
+  }
+
+  // ---- float layout ----
+  size_t o = 0;
+  auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, ALIGN_F); return r; };
+  // tables region (bytes -> floats)
+  size_t total_units = 0;
+  for (auto& s : specs) total_units += (size_t)s.units * p.ntiles[s.lv];
+  const size_t units_per_task = specs.empty() ? 1 : (total_units + target_tasks - 1) / target_tasks;
+  std::vector<int> nsplit(specs.size());
+  int ntasks = 0;
+  for (size_t i = 0; i < specs.size(); ++i) {
+    const size_t u = (size_t)specs[i].units * p.ntiles[specs[i].lv];
+    int ns = (int)((u + units_per_task - 1) / units_per_task);
+    if (ns < 1) ns = 1;
+    if (ns > p.ntiles[specs[i].lv]) ns = p.ntiles[specs[i].lv];
+    nsplit[i] = ns;
+    ntasks += ns;
+  }
+  p.ntasks = ntasks;
+  const int npack = 2 * 21;
+  const int nreduce_max = 2 * 40;
+  const size_t table_bytes = align_up(npack * sizeof(PackDesc), 256) + align_up(specs.size() * sizeof(WgradGroup) + 256, 256) +
+                             align_up(nreduce_max * sizeof(ReduceDesc), 256);
+  p.tables = take(table_bytes / 4);
+  p.pack_off_b = 0;
+  p.groups_off_b = align_up(npack * sizeof(PackDesc), 256);
+  p.reduce_off_b = p.groups_off_b + align_up(specs.size() * sizeof(WgradGroup) + 256, 256);
+
+  p.cond = take((size_t)B * (h->R > 0 ? h->R : 1));
+  p.mse = take(64);
+  p.zero_rgb = take((size_t)B * 3);
+  for (int lv = 0; lv < h->nlevels; ++lv) {
+    LevelWs& L = p.L[lv];
+    const size_t nt = p.ntiles[lv];
+    L.wpk = take(h->pk.total);
+    L.z = take((size_t)p.rows[lv]);
+    L.out4 = take(nt * TILE_ROWS * 4);
+    L.rgb = take((size_t)B * 3);
+    L.depth = take(B);
+    L.med = take(B);
+    L.acc = take(B);
+    L.weights = take((size_t)p.rows[lv]);
+    L.condterm = take((size_t)B * RGB_W);
+    if (train) {
+      L.st_pe = take(nt * h->PK * TILE_ROWS);
+      L.st_h = take(nt * FRAG_TILE_256 * TRUNK_DEPTH);
+      L.st_bn = take(nt * FRAG_TILE_256);
+      L.st_rgbh = take(nt * FRAG_TILE_128);
+      L.bits_trunk = take(nt * 4 * 256 * TRUNK_DEPTH);
+      L.bits_rgbh = take(nt * 4 * 128);
+      L.d_raw4 = take(nt * TILE_ROWS * 4);
+      L.dy_trunk = take(nt * FRAG_TILE_256 * TRUNK_DEPTH);
+      L.dy_bn = take(nt * FRAG_TILE_256);
+      L.dy_rgbh = take(nt * FRAG_TILE_128);
+      L.dray = take((size_t)B * RGB_W);
+      L.small_part = take((size_t)G * SMALL_PART);
+      L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
+    }
+  }
+
+  // ---- pack descriptors (both levels, forward and transposed streams) ----
+  for (int lv = 0; lv < h->nlevels; ++lv) {
+    const MlpParamOffsets& po = h->po[lv];
+    const int64_t base = (int64_t)p.L[lv].wpk;
+    const PackOffsets& pk = h->pk;
+    auto add = [&](int64_t src, int dst, int ld, int row0, int kvalid, int K, int ncb, int tr) {
+      PackDesc q;
+      q.src_off = src; q.dst_off = base + dst; q.src_ld = ld; q.src_row0 = row0; q.kvalid = kvalid; q.K = K; q.ncb = ncb;
+      q.transposed = tr;
+      p.pack.push_back(q);
+    };
+    add(po.trunk_k[0], pk.fwd_L[0], 256, 0, h->P, h->PK, 2, 0);
+    for (int l = 1; l < TRUNK_DEPTH; ++l) add(po.trunk_k[l], pk.fwd_L[l], 256, 0, 256, 256, 2, 0);
+    add(po.trunk_k[d.nerf_skip_layer], pk.fwd_L4b, 256, 256, h->P, h->PK, 2, 0);
+    add(po.bn_k, pk.fwd_bn, 256, 0, 256, 256, 2, 0);
+    add(po.rgbh_k, pk.fwd_rgbh, 128, 0, 256, 256, 1, 0);
+    add(po.rgbh_k, pk.bwd_rgbhT, 128, 0, 128, 128, 2, 1);
+    add(po.bn_k, pk.bwd_bnT, 256, 0, 256, 256, 2, 1);
+    for (int l = 1; l < TRUNK_DEPTH; ++l) add(po.trunk_k[l], pk.bwd_LT[l], 256, 0, 256, 256, 2, 1);
+  }
+
+  // ---- wgrad groups + slabs + reduce descriptors ----
+  if (train) {
+    int first = 0;
+    for (size_t i = 0; i < specs.size(); ++i) {
+      const GroupSpec& s = specs[i];
+      WgradGroup g;
+      memset(&g, 0, sizeof(g));
+      g.x_off = (int64_t)(*s.xoff + s.xadd);
+      g.x_kind = s.xk; g.x_tile_stride = s.xstride; g.x_kvalid = s.kvalid; g.Kb = s.Kb;
+      g.dy_off = s.yoff ? (int64_t)(*s.yoff + s.yadd) : 0;
+      g.dy_kind = s.yk; g.dy_tile_stride = s.ystride; g.Nb = s.Nb;
+      g.ntiles = p.ntiles[s.lv];
+      g.nsplit = nsplit[i];
+      g.tiles_per = (g.ntiles + g.nsplit - 1) / g.nsplit;
+      g.first_task = first;
+      first += g.nsplit;
+      ReduceDesc r;
+      memset(&r, 0, sizeof(r));
+      r.dst_off = s.dst; r.dst_ld = s.dst_ld; r.rows = s.rows; r.cols = s.cols;
+      if (s.vec) {
+        g.vec_off = (int64_t)p.L[s.lv].d_raw4;
+        g.vslab_off = (int64_t)take((size_t)g.nsplit * 2 * g.Kb * 32 * 4);
+        g.slab_off = 0;
+        r.src_off = g.vslab_off + (s.vec == 1 ? 3 : 0);
+        r.src_ld = 4; r.part_stride = (int64_t)g.Kb * 32 * 4; r.nparts = 2 * g.nsplit;
+      } else {
+        g.vec_off = -1; g.vslab_off = 0;
+        g.slab_off = (int64_t)take((size_t)g.nsplit * g.Kb * 32 * g.Nb * 32);
+        r.src_off = g.slab_off; r.src_ld = g.Nb * 32; r.part_stride = (int64_t)g.Kb * 32 * g.Nb * 32; r.nparts = g.nsplit;
+      }
+      p.groups.push_back(g);
+      p.reduce.push_back(r);
+    }
+    // bias gradients and per-ray condition rows
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      const MlpParamOffsets& po = h->po[lv];
+      const LevelWs& L = p.L[lv];
+      const int grid = p.ntiles[lv] < G ? p.ntiles[lv] : G;
+      auto small = [&](int64_t dst, int cols, int sp_off) {
+        ReduceDesc r;
+        memset(&r, 0, sizeof(r));
+        r.dst_off = dst; r.dst_ld = cols; r.rows = 1; r.cols = cols;
+        r.src_off = (int64_t)L.small_part + sp_off; r.src_ld = cols; r.part_stride = SMALL_PART; r.nparts = grid;
+        p.reduce.push_back(r);
+      };
+      for (int l = 0; l < TRUNK_DEPTH; ++l) small(po.trunk_b[l], 256, l * 256);
+      small(po.bn_b, 256, 2048);
+      small(po.rgbh_b, 128, 2304);
+      small(po.logit_b, 3, 2432);
+      small(po.alpha_b, 1, 2435);
+      if (h->R > 0) {
+        ReduceDesc r;
+        memset(&r, 0, sizeof(r));
+        r.dst_off = po.rgbh_k + 256 * 128; r.dst_ld = 128; r.rows = h->R; r.cols = 128;
+        r.src_off = (int64_t)L.cond_grad; r.src_ld = 128; r.part_stride = 0; r.nparts = 1;
+        p.reduce.push_back(r);
+      }
+    }
+  }
+  p.total_floats = o;
+}
+
+int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
+  WsPlan& p = h->plan;
+  if (h->uploaded_ws == (void*)ws && h->uploaded_B == p.B && h->uploaded_flags == p.flags) return NRF_OK;
+  char* base = reinterpret_cast<char*>(ws + p.tables);
+  hipError_t e;
+  if (!p.pack.empty()) {
+    e = hipMemcpyAsync(base + p.pack_off_b, p.pack.data(), p.pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload pack table");
+  }
+  if (!p.groups.empty()) {
+    e = hipMemcpyAsync(base + p.groups_off_b, p.groups.data(), p.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload wgrad table");
+  }
+  if (!p.reduce.empty()) {
+    e = hipMemcpyAsync(base + p.reduce_off_b, p.reduce.data(), p.reduce.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload reduce table");
+  }
+  h->uploaded_ws = ws;
+  h->uploaded_B = p.B;
+  h->uploaded_flags = p.flags;
+  return NRF_OK;
+}
+
+void query_device(nrf_handle h) {
+  if (h->cu_queried) return;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0)
+    h->num_cus = cus;
+  h->cu_queried = true;
+}
+
+int check_launch(const char* where) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail_hip(e, where);
+  return NRF_OK;
+}
+
+#define CK(call)                      \
+  do {                                \
+    int rc_ = (call);                 \
+    if (rc_ != NRF_OK) return rc_;    \
+  } while (0)
+
+int validate_rays(nrf_handle h, const nrf_rays* rays) {
+  if (!rays || !rays->origins || !rays->directions) return fail(NRF_E_NULL, "rays / origins / directions is null");
+  if (rays->num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
+  if (h->d.use_camera_metadata && !rays->camera_ids) return fail(NRF_E_NULL, "camera_ids required (use_camera_metadata)");
+  if (h->app_in_cond && !rays->appearance_ids) return fail(NRF_E_NULL, "appearance_ids required");
+  return NRF_OK;
+}
+
+ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train) {
+  const WsPlan& p = h->plan;
+  const LevelWs& L = p.L[lv];
+  ChainFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params; a.po = h->po[lv]; a.wpk = ws + L.wpk; a.pk = h->pk;
+  a.condterm = ws + L.condterm; a.zvals = ws + L.z; a.origins = rays->origins; a.directions = rays->directions;
+  a.points = nullptr; a.out4 = reinterpret_cast<float4*>(ws + L.out4);
+  a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
+  a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation;
+  if (train) {
+    a.st_pe = ws + L.st_pe; a.st_h = ws + L.st_h; a.st_bn = ws + L.st_bn; a.st_rgbh = ws + L.st_rgbh;
+    a.bits_trunk = reinterpret_cast<uint32_t*>(ws + L.bits_trunk);
+    a.bits_rgbh = reinterpret_cast<uint32_t*>(ws + L.bits_rgbh);
+  }
+  return a;
+}
+
+int copy_out(float* dst, const float* src, size_t n, hipStream_t stream) {
+  if (!dst) return NRF_OK;
+  hipError_t e = hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, stream);
+  return e == hipSuccess ? NRF_OK : fail_hip(e, "copy output");
+}
+
+int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_rand* rnd, const nrf_outputs* out,
+                 uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream) {
+  CK(validate_rays(h, rays));
+  if (!params || !ws) return fail(NRF_E_NULL, "params / workspace is null");
+  query_device(h);
+  const int B = rays->num_rays;
+  build_plan(h, B, flags & NRF_FLAG_TRAIN);
+  WsPlan& p = h->plan;
+  if (ws_bytes < p.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (see nrf_workspace_bytes)");
+  const nrf_model_desc& d = h->d;
+  const bool train = flags & NRF_FLAG_TRAIN;
+  if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
+  CK(upload_tables(h, ws, stream));
+  const char* tables = reinterpret_cast<const char*>(ws + p.tables);
+
+  launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
+  const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
+  launch_ray_prep(params, viewdirs, rays->appearance_ids, rays->camera_ids, B, d.num_nerf_viewdir_freqs, d.use_viewdirs,
+                  h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
+                  d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->R, h->po[0].rgbh_k, h->po[0].rgbh_b,
+                  h->po[h->nlevels - 1].rgbh_k, h->po[h->nlevels - 1].rgbh_b, ws + p.cond, ws + p.L[0].condterm,
+                  h->nlevels > 1 ? ws + p.L[1].condterm : nullptr, stream);
+  launch_sample_coarse(rnd ? rnd->t_rand : nullptr, B, p.S[0], d.near_plane, d.far_plane, d.use_stratified_sampling,
+                       d.use_linear_disparity, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0, ws + p.L[0].z, stream);
+  for (int lv = 0; lv < h->nlevels; ++lv) {
+    const LevelWs& L = p.L[lv];
+    if (lv == 1) {
+      launch_sample_fine(ws + p.L[0].z, ws + p.L[0].weights, B, d.num_coarse_samples, d.num_fine_samples,
+                         d.use_stratified_sampling, rnd ? rnd->u : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0,
+                         ws + L.z, stream);
+    }
+    ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train);
+    const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    launch_chain_fwd(a, train, grid, stream);
+    launch_composite_fwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
+                         d.use_white_background, d.use_sample_at_infinity, ws + L.rgb, ws + L.depth, ws + L.med,
+                         ws + L.acc, ws + L.weights, stream);
+    if (out) {
+      const nrf_level_out& lo = lv == 0 ? out->coarse : out->fine;
+      CK(copy_out(lo.rgb, ws + L.rgb, (size_t)B * 3, stream));
+      CK(copy_out(lo.depth, ws + L.depth, B, stream));
+      CK(copy_out(lo.med_depth, ws + L.med, B, stream));
+      CK(copy_out(lo.acc, ws + L.acc, B, stream));
+      CK(copy_out(lo.weights, ws + L.weights, (size_t)p.rows[lv], stream));
+      CK(copy_out(lo.z_vals, ws + L.z, (size_t)p.rows[lv], stream));
+    }
+  }
+  CK(check_launch("nrf_forward"));
+  h->stashed_ws = train ? (void*)ws : nullptr;
+  h->stashed_B = train ? B : -1;
+  return NRF_OK;
+}
+
+// d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
+int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
+                  float* grad, float* stats, float* ws, hipStream_t stream) {
+  WsPlan& p = h->plan;
+  const nrf_model_desc& d = h->d;
+  const int B = p.B;
+  const char* tables = reinterpret_cast<const char*>(ws + p.tables);
+  hipError_t e = hipMemsetAsync(grad, 0, (size_t)h->nparams * sizeof(float), stream);
+  if (e != hipSuccess) return fail_hip(e, "zero grad");
+  e = hipMemsetAsync(ws + p.mse, 0, 64 * sizeof(float), stream);
+  if (e != hipSuccess) return fail_hip(e, "zero mse");
+  for (int lv = 0; lv < h->nlevels; ++lv) {
+    const LevelWs& L = p.L[lv];
+    e = hipMemsetAsync(ws + L.dray, 0, (size_t)B * RGB_W * sizeof(float), stream);
+    if (e != hipSuccess) return fail_hip(e, "zero dray");
+    const float loss_scale = 2.0f / (3.0f * (float)B);   // d/d rgb of mean over (B,3) (training.py:172)
+    launch_composite_bwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
+                         d.use_white_background, d.use_sample_at_infinity, d.sigma_activation, ws + L.rgb, target,
+                         target ? nullptr : d_rgb[lv], loss_scale, reinterpret_cast<float4*>(ws + L.d_raw4),
+                         p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, stream);
+    ChainBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.params = params; a.po = h->po[lv]; a.wpk = ws + L.wpk; a.pk = h->pk;
+    a.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
+    a.S = p.S[lv]; a.B = B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
+    a.bits_trunk = reinterpret_cast<const uint32_t*>(ws + L.bits_trunk);
+    a.bits_rgbh = reinterpret_cast<const uint32_t*>(ws + L.bits_rgbh);
+    a.dy_trunk = ws + L.dy_trunk; a.dy_bn = ws + L.dy_bn; a.dy_rgbh = ws + L.dy_rgbh; a.dray = ws + L.dray;
+    a.small_part = ws + L.small_part;
+    const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    launch_chain_bwd(a, grid, stream);
+    launch_cond_wgrad(ws + p.cond, ws + L.dray, B, h->R, ws + L.cond_grad, stream);
+  }
+  launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b), (int)p.groups.size(), p.ntasks, ws, stream);
+  launch_reduce(reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b), (int)p.reduce.size(), ws, grad, stream);
+  if (stats) launch_finish_stats(ws + p.mse, B, stats, stream);
+  return check_launch("nrf_backward");
+}
+
+}  // namespace
+
+extern "C" {
+
+int nrf_version(void) { return NRF_VERSION; }
+const char* nrf_last_error(void) { return g_err; }
+
+int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
+  if (!desc || !out) return fail(NRF_E_NULL, "desc / out is null");
+  const nrf_model_desc& d = *desc;
+  if (d.nerf_trunk_width != TRUNK_W || d.nerf_trunk_depth != TRUNK_DEPTH || d.nerf_skip_layer != SKIP_LAYER)
+    return fail(NRF_E_UNSUPPORTED, "MFMA chain is built for an 8x256 trunk with the skip at layer 4");
+  if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width != RGB_W)
+    return fail(NRF_E_UNSUPPORTED, "rgb branch must be 1 x 128");
+  if (d.use_alpha_condition) return fail(NRF_E_UNSUPPORTED, "use_alpha_condition (alpha-branch conditioning) not built yet");
+  if (d.use_warp) return fail(NRF_E_UNSUPPORTED, "SE3 warp field not built yet in this round");
+  if (!d.use_viewdirs && !d.use_camera_metadata) return fail(NRF_E_UNSUPPORTED, "rgb branch needs at least one condition");
+  if (d.num_coarse_samples < 3 || d.num_coarse_samples > 256) return fail(NRF_E_SHAPE, "num_coarse_samples must be in [3,256]");
+  if (d.num_fine_samples < 0 || d.num_coarse_samples + d.num_fine_samples > 512)
+    return fail(NRF_E_SHAPE, "num_coarse_samples + num_fine_samples must be <= 512");
+  if (d.num_nerf_point_freqs < 1 || d.num_nerf_point_freqs > 10) return fail(NRF_E_SHAPE, "num_nerf_point_freqs must be in [1,10]");
+  if (d.num_nerf_viewdir_freqs < 0 || d.num_nerf_viewdir_freqs > 8) return fail(NRF_E_SHAPE, "num_nerf_viewdir_freqs must be in [0,8]");
+  if (d.sigma_activation != NRF_ACT_RELU && d.sigma_activation != NRF_ACT_SOFTPLUS) return fail(NRF_E_UNSUPPORTED, "sigma_activation");
+  nrf_handle h = new nrf_handle_s();
+  h->d = d;
+  h->nlevels = d.num_fine_samples > 0 ? 2 : 1;
+  h->P = 3 + 6 * d.num_nerf_point_freqs;
+  h->PK = (h->P + 3) / 4 * 4;
+  h->V = d.use_viewdirs ? 3 + 6 * d.num_nerf_viewdir_freqs : 0;
+  h->app_in_cond = (d.use_appearance_metadata && d.use_alpha_condition) ? 1 : 0;   // models.py:206
+  h->R = h->V + (h->app_in_cond ? d.num_appearance_features : 0) + (d.use_camera_metadata ? d.num_camera_features : 0);
+  if (h->R > 64) { delete h; return fail(NRF_E_SHAPE, "rgb condition wider than 64"); }
+  build_layout(h);
+  build_pack_offsets(h);
+  *out = h;
+  return NRF_OK;
+}
+
+int nrf_destroy(nrf_handle h) {
+  delete h;
+  return NRF_OK;
+}
+
+int nrf_param_count(nrf_handle h, int64_t* n) {
+  if (!h || !n) return fail(NRF_E_NULL, "null");
+  *n = h->nparams;
+  return NRF_OK;
+}
+
+int nrf_param_layout(nrf_handle h, nrf_tensor_info* out, int32_t* n) {
+  if (!h || !n) return fail(NRF_E_NULL, "null");
+  if (out) {
+    if (*n < (int32_t)h->layout.size()) return fail(NRF_E_SHAPE, "layout array too small");
+    memcpy(out, h->layout.data(), h->layout.size() * sizeof(nrf_tensor_info));
+  }
+  *n = (int32_t)h->layout.size();
+  return NRF_OK;
+}
+
+int nrf_workspace_bytes(nrf_handle h, int32_t num_rays, uint32_t flags, size_t* bytes) {
+  if (!h || !bytes) return fail(NRF_E_NULL, "null");
+  if (num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
+  query_device(h);
+  build_plan(h, num_rays, flags & NRF_FLAG_TRAIN);
+  *bytes = h->plan.total_floats * sizeof(float);
+  return NRF_OK;
+}
+
+int nrf_forward(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_step_scalars* scalars,
+                const nrf_rand* rnd, const nrf_outputs* out, uint32_t flags, void* workspace, size_t workspace_bytes,
+                void* stream) {
+  (void)scalars;
+  if (!h) return fail(NRF_E_NULL, "handle is null");
+  return forward_impl(h, params, rays, rnd, out, flags, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int nrf_backward(nrf_handle h, const float* params, const nrf_rays* rays, const float* d_rgb_coarse,
+                 const float* d_rgb_fine, float* grad_params, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !params || !rays || !grad_params || !workspace) return fail(NRF_E_NULL, "null argument");
+  if (h->stashed_ws != workspace || h->stashed_B != rays->num_rays)
+    return fail(NRF_E_STATE, "nrf_backward needs a preceding nrf_forward(NRF_FLAG_TRAIN) on this workspace");
+  if (workspace_bytes < h->plan.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small");
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const float* zero = ws + h->plan.zero_rgb;
+  if (!d_rgb_coarse || (h->nlevels > 1 && !d_rgb_fine)) {
+    hipError_t e = hipMemsetAsync(ws + h->plan.zero_rgb, 0, (size_t)rays->num_rays * 3 * sizeof(float), st);
+    if (e != hipSuccess) return fail_hip(e, "zero d_rgb");
+  }
+  const float* dr[2] = {d_rgb_coarse ? d_rgb_coarse : zero, d_rgb_fine ? d_rgb_fine : zero};
+  return backward_impl(h, params, rays, dr, nullptr, grad_params, nullptr, ws, st);
+}
+
+int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
+                             const nrf_step_scalars* scalars, const nrf_rand* rnd, float* grad_params, float* stats,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  (void)scalars;
+  if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
+  CK(forward_impl(h, params, rays, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes, (hipStream_t)stream));
+  const float* dr[2] = {nullptr, nullptr};
+  return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream);
+}
+
+int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n, float lr, float beta1, float beta2,
+                  float eps, int64_t step, float grad_scale, void* stream) {
+  if (!params || !m || !v || !grad) return fail(NRF_E_NULL, "null argument");
+  if (n <= 0) return fail(NRF_E_SHAPE, "n must be positive");
+  launch_adam(params, m, v, grad, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);
+  return check_launch("nrf_adam_step");
+}
+
+int nrf_sample_along_rays(const float* origins, const float* directions, int32_t num_rays, int32_t num_samples,
+                          float near_plane, float far_plane, int32_t stratified, int32_t linear_disparity,
+                          const float* t_rand, uint64_t seed, uint64_t offset, float* z_vals, void* stream) {
+  (void)origins; (void)directions;   // z_vals do not depend on the ray; points are formed inside the MLP kernel
+  if (!z_vals) return fail(NRF_E_NULL, "z_vals is null");
+  if (num_rays <= 0 || num_samples < 2) return fail(NRF_E_SHAPE, "bad shape");
+  launch_sample_coarse(t_rand, num_rays, num_samples, near_plane, far_plane, stratified, linear_disparity, seed, offset,
+                       z_vals, (hipStream_t)stream);
+  return check_launch("nrf_sample_along_rays");
+}
+
+int nrf_volumetric_rendering(const float* rgb_sigma, const float* z_vals, const float* directions, int32_t num_rays,
+                             int32_t num_samples, int32_t white_background, int32_t sample_at_infinity,
+                             const nrf_level_out* out, void* stream) {
+  if (!rgb_sigma || !z_vals || !directions || !out) return fail(NRF_E_NULL, "null argument");
+  if (num_rays <= 0 || num_samples < 1 || num_samples > 512) return fail(NRF_E_SHAPE, "num_samples must be in [1,512]");
+  launch_composite_fwd(reinterpret_cast<const float4*>(rgb_sigma), z_vals, directions, num_rays, num_samples,
+                       white_background, sample_at_infinity, out->rgb, out->depth, out->med_depth, out->acc, out->weights,
+                       (hipStream_t)stream);
+  return check_launch("nrf_volumetric_rendering");
+}
+
+int nrf_sample_pdf(const float* z_coarse, const float* weights_coarse, int32_t num_rays, int32_t num_coarse,
+                   int32_t num_fine, int32_t stratified, const float* u, uint64_t seed, uint64_t offset, float* z_out,
+                   void* stream) {
+  if (!z_coarse || !weights_coarse || !z_out) return fail(NRF_E_NULL, "null argument");
+  if (num_rays <= 0 || num_coarse < 3 || num_coarse > 256 || num_fine < 1 || num_coarse + num_fine > 512)
+    return fail(NRF_E_SHAPE, "need 3 <= num_coarse <= 256 and num_coarse + num_fine <= 512");
+  launch_sample_fine(z_coarse, weights_coarse, num_rays, num_coarse, num_fine, stratified, u, seed, offset, z_out,
+                     (hipStream_t)stream);
+  return check_launch("nrf_sample_pdf");
+}
+
+}  // extern "C"

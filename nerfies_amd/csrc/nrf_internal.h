@@ -1,0 +1,151 @@
+// Internal declarations shared by the HIP kernels and the C-ABI layer.
+// gfx950 (MI355X) only: wave = 64 lanes, MFMA f32 32x32x2, 160 KiB LDS / CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nrf {
+
+constexpr int TILE_ROWS = 128;   // rows (ray samples) per workgroup tile
+constexpr int TRUNK_W = 256;     // NeRF trunk width the MFMA chain is built for
+constexpr int RGB_W = 128;       // rgb branch width
+constexpr int TRUNK_DEPTH = 8;
+constexpr int SKIP_LAYER = 4;
+constexpr int ACT_FLOATS = TRUNK_W * TILE_ROWS;        // LDS activation tile
+constexpr int FRAG_TILE_256 = TRUNK_W * TILE_ROWS;     // floats per stash tile, 256 wide
+constexpr int FRAG_TILE_128 = RGB_W * TILE_ROWS;
+constexpr int SMALL_PART = 3080;  // per-workgroup small-gradient partials (see mlp_chain.hip)
+
+// Offsets (in floats) of one NeRF MLP's leaves inside the flat parameter buffer
+// (canonical flax layout: kernel [in,out] row-major, then bias).
+struct MlpParamOffsets {
+  int64_t trunk_k[TRUNK_DEPTH];
+  int64_t trunk_b[TRUNK_DEPTH];
+  int64_t bn_k, bn_b;
+  int64_t rgbh_k, rgbh_b;      // [256+R,128], [128]
+  int64_t logit_k, logit_b;    // [128,3], [3]
+  int64_t alpha_k, alpha_b;    // [256,1], [1]
+};
+
+// Offsets (floats) inside one MLP's packed-weight block (see pack kernel).
+struct PackOffsets {
+  int fwd_L[TRUNK_DEPTH];  // L0: K=PK ; others K=256
+  int fwd_L4b;             // skip layer's posenc rows, K=PK
+  int fwd_bn, fwd_rgbh;
+  int bwd_rgbhT, bwd_bnT;
+  int bwd_LT[TRUNK_DEPTH]; // [1..7] used (dX of layer l), [0] unused unless warp
+  int total;
+};
+
+struct ChainFwdArgs {
+  const float* params;       // flat canonical parameters
+  MlpParamOffsets po;
+  const float* wpk;          // packed weights of this MLP
+  PackOffsets pk;
+  const float* condterm;     // [B][128]: rgb-branch per-ray term incl. bias
+  const float* zvals;        // [B*S]
+  const float* origins;      // [B][3]
+  const float* directions;   // [B][3]
+  const float* points;       // [rows][3] warped points, or nullptr -> o + z d
+  float4* out4;              // [ntiles*128] (r,g,b,sigma) post-activation
+  int S, B, rows, ntiles;
+  int F, P, PK;              // point freqs, 3+6F, P rounded up to a multiple of 4
+  int sigma_act;
+  // activation stash (training only)
+  float* st_pe;              // [ntiles][PK][128]
+  float* st_h;               // [8][ntiles][256*128]  h1..h8, fragment-native
+  float* st_bn;              // [ntiles][256*128]
+  float* st_rgbh;            // [ntiles][128*128]
+  // ReLU sign bits for the dgrad pass, one bit per accumulator element, fragment-native
+  uint32_t* bits_trunk;      // [8][ntiles][4 waves][64 lanes] x 4 dwords
+  uint32_t* bits_rgbh;       // [ntiles][4 waves][64 lanes] x 2 dwords
+};
+
+struct ChainBwdArgs {
+  const float* params;
+  MlpParamOffsets po;
+  const float* wpk;
+  PackOffsets pk;
+  const float4* d_raw4;      // [ntiles*128] dL/d(raw rgb, raw sigma); 0 on pad rows
+  int S, B, rows, ntiles;
+  const uint32_t* bits_trunk;
+  const uint32_t* bits_rgbh;
+  float* dy_trunk;           // [8][ntiles][256*128]  dpre_0..dpre_7
+  float* dy_bn;              // [ntiles][256*128]
+  float* dy_rgbh;            // [ntiles][128*128]
+  float* dray;               // [B][128] += per-ray sums of dpre_rgbh (atomics)
+  float* small_part;         // [gridDim.x][SMALL_PART]
+};
+
+// One split-K slice of a weight-gradient GEMM  dW[k][n] = sum_rows X[row][k] dY[row][n].
+enum { SRC_FRAG256 = 0, SRC_FRAG128 = 1, SRC_PLAIN = 2 };
+struct WgradTask {
+  const float* X;  int x_kind;  int x_tile_stride;  int x_kvalid;  int Kb;
+  const float* dY; int dy_kind; int dy_tile_stride; int Nb;   // Nb == 0: vector columns only
+  int tile_begin, tile_end;
+  float* slab;     // [Kb*32][Nb*32]
+  // optional narrow dY columns done on the VALU: vec[row] = float4 (d raw rgb, d raw sigma);
+  // vslab[2][Kb*32][4] (two row halves) accumulates X^T vec.
+  const float4* vec; float* vslab;
+};
+
+// A layer's wgrad GEMM, cut into `nsplit` tasks of `tiles_per` tiles.  Offsets are in floats
+// from the workspace base, so the table depends only on (model, num_rays).
+struct WgradGroup {
+  int64_t x_off, dy_off, slab_off;
+  int64_t vec_off, vslab_off;     // vec_off < 0: no vector columns
+  int x_kind, x_tile_stride, x_kvalid, Kb;
+  int dy_kind, dy_tile_stride, Nb;
+  int ntiles, nsplit, tiles_per, first_task;
+};
+
+struct ReduceDesc {
+  int64_t dst_off;    // floats from the flat gradient buffer
+  int64_t src_off;    // floats from the workspace base
+  int64_t part_stride;
+  int dst_ld, rows, cols, src_ld, nparts, pad_;
+};
+
+struct PackDesc {
+  int64_t src_off;    // canonical kernel [*, src_ld] row-major, floats from the flat params
+  int64_t dst_off;    // floats from the workspace base
+  int src_ld;
+  int src_row0;       // first source row (forward) / unused (transposed)
+  int kvalid;         // number of valid k
+  int K;              // padded K (multiple of 4, or 8 when ncb==1)
+  int ncb;            // 2 -> N=256, 1 -> N=128
+  int transposed;     // B[k][n] = src[n][k]
+};
+
+// ---- launchers (all asynchronous on `stream`) ----
+void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float* ws, hipStream_t stream);
+void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
+void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
+void launch_wgrad(const WgradGroup* d_groups, int ngroups, int ntasks, float* ws, hipStream_t stream);
+void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
+
+void launch_ray_prep(const float* params, const float* viewdirs, const int32_t* app_ids,
+                     const int32_t* cam_ids, int B, int Fv, int use_viewdirs, int app_feat,
+                     int64_t app_off, int cam_feat, int64_t cam_off, int R,
+                     int64_t rgbh_k_c, int64_t rgbh_b_c, int64_t rgbh_k_f, int64_t rgbh_b_f,
+                     float* cond, float* condterm_c, float* condterm_f, hipStream_t stream);
+void launch_sample_coarse(const float* t_rand, int B, int N, float near_p, float far_p,
+                          int stratified, int lindisp, uint64_t seed, uint64_t offset,
+                          float* z, hipStream_t stream);
+void launch_composite_fwd(const float4* out4, const float* z, const float* dirs, int B, int S,
+                          int white_bkgd, int sample_at_inf, float* rgb, float* depth,
+                          float* med_depth, float* acc, float* weights, hipStream_t stream);
+void launch_composite_bwd(const float4* out4, const float* z, const float* dirs, int B, int S,
+                          int white_bkgd, int sample_at_inf, int sigma_act, const float* rgb_out,
+                          const float* target, const float* d_rgb, float loss_scale,
+                          float4* d_raw4, int rows_pad, float* mse_sum, hipStream_t stream);
+void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int Nf, int stratified,
+                        const float* u, uint64_t seed, uint64_t offset, float* z_out,
+                        hipStream_t stream);
+void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst /*[R][128]*/,
+                       hipStream_t stream);
+void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t stream);
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
+                 float b2, float eps, int64_t step, float gscale, hipStream_t stream);
+
+}  // namespace nrf

@@ -1,0 +1,410 @@
+// Per-ray kernels of the nerfies hot path for gfx950 (one 64-lane wave per ray; prefix
+// products / sums and the inverse-CDF search done with wave shuffles and wave-private LDS).
+//
+// Replaces (reference, /root/reference/nerfies):
+//   model_utils.sample_along_rays        model_utils.py:36-73
+//   model_utils.volumetric_rendering     model_utils.py:76-136 (+ depth helpers :218-263)
+//   model_utils.piecewise_constant_pdf / sample_pdf   model_utils.py:139-215
+//   models.NerfModel.get_condition_inputs (viewdir posenc + GLO gathers)  models.py:186-228
+//   training._compute_loss_and_stats MSE/psnr   training.py:172,225 ; utils.py:94-103
+//   flax.optim.Adam.apply_gradient        training.py:268-269
+#include "nrf_internal.h"
+
+namespace nrf {
+
+// ------------------------------------------------------------------ Philox4x32-10
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+
+// uniform in [0,1) for element `idx` of stream `stream_id`
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint32_t stream_id, uint32_t idx) {
+  uint32_t c[4] = {idx, stream_id, (uint32_t)offset, (uint32_t)(offset >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------ wave helpers (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_incl_sum(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v += t; }
+  return v;
+}
+__device__ __forceinline__ float wave_incl_prod(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o); if (lane >= o) v *= t; }
+  return v;
+}
+
+// ------------------------------------------------------------------ ray prep
+// cond[ray] = [posenc(viewdir) | appearance code (only with use_alpha_condition, models.py:206) |
+// camera code]; condterm_{c,f}[ray][n] = cond . W_rgbh[256:, n] + b_rgbh[n].
+__global__ __launch_bounds__(128) void ray_prep_kernel(
+    const float* __restrict__ params, const float* __restrict__ viewdirs, const int32_t* __restrict__ app_ids,
+    const int32_t* __restrict__ cam_ids, int B, int Fv, int use_viewdirs, int app_feat, int64_t app_off,
+    int cam_feat, int64_t cam_off, int R, int64_t kc, int64_t bc, int64_t kf, int64_t bf,
+    float* __restrict__ cond, float* __restrict__ ct_c, float* __restrict__ ct_f) {
+  __shared__ float s_cond[64];
+  const int ray = blockIdx.x, t = threadIdx.x;
+  const int V = use_viewdirs ? 3 + 6 * Fv : 0;
+  if (t < R) {
+    float v;
+    if (t < V) {
+      if (t < 3) v = viewdirs[3 * ray + t];
+      else {
+        const int q = t - 3, f = q / 6, rem = q - 6 * f, is_cos = rem / 3, c = rem - 3 * is_cos;
+        float a = __fmul_rn(viewdirs[3 * ray + c], (float)(1 << f));
+        if (is_cos) a = __fadd_rn(a, 1.57079632679489661923f);
+        v = sinf(a);
+      }
+    } else if (t < V + app_feat) {
+      v = params[app_off + (int64_t)app_ids[ray] * app_feat + (t - V)];
+    } else {
+      v = params[cam_off + (int64_t)cam_ids[ray] * cam_feat + (t - V - app_feat)];
+    }
+    s_cond[t] = v;
+    cond[(size_t)ray * R + t] = v;
+  }
+  __syncthreads();
+  float a = params[bc + t], b = ct_f ? params[bf + t] : 0.f;
+  for (int c = 0; c < R; ++c) {
+    const float x = s_cond[c];
+    a = fmaf(x, params[kc + (int64_t)(TRUNK_W + c) * RGB_W + t], a);
+    if (ct_f) b = fmaf(x, params[kf + (int64_t)(TRUNK_W + c) * RGB_W + t], b);
+  }
+  ct_c[(size_t)ray * RGB_W + t] = a;
+  if (ct_f) ct_f[(size_t)ray * RGB_W + t] = b;
+}
+
+void launch_ray_prep(const float* params, const float* viewdirs, const int32_t* app_ids, const int32_t* cam_ids,
+                     int B, int Fv, int use_viewdirs, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
+                     int R, int64_t rgbh_k_c, int64_t rgbh_b_c, int64_t rgbh_k_f, int64_t rgbh_b_f, float* cond,
+                     float* condterm_c, float* condterm_f, hipStream_t stream) {
+  hipLaunchKernelGGL(ray_prep_kernel, dim3(B), dim3(128), 0, stream, params, viewdirs, app_ids, cam_ids, B, Fv,
+                     use_viewdirs, app_feat, app_off, cam_feat, cam_off, R, rgbh_k_c, rgbh_b_c, rgbh_k_f, rgbh_b_f,
+                     cond, condterm_c, condterm_f);
+}
+
+// ------------------------------------------------------------------ coarse sampling
+__device__ __forceinline__ float coarse_z(int s, int N, float near_p, float far_p, int lindisp) {
+  const float t = (s == N - 1) ? 1.0f : (float)s / (float)(N - 1);   // linspace(0,1,N)
+  if (!lindisp) return near_p * (1.f - t) + far_p * t;               // model_utils.py:58
+  return 1.f / (1.f / near_p * (1.f - t) + 1.f / far_p * t);         // model_utils.py:60
+}
+
+__global__ void sample_coarse_kernel(const float* __restrict__ t_rand, int B, int N, float near_p, float far_p,
+                                     int stratified, int lindisp, uint64_t seed, uint64_t offset,
+                                     float* __restrict__ z) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * N) return;
+  const int s = idx % N;
+  const float zc = coarse_z(s, N, near_p, far_p, lindisp);
+  if (!stratified) { z[idx] = zc; return; }
+  // model_utils.py:62-66
+  const float zl = s > 0 ? coarse_z(s - 1, N, near_p, far_p, lindisp) : zc;
+  const float zu = s < N - 1 ? coarse_z(s + 1, N, near_p, far_p, lindisp) : zc;
+  const float lower = s > 0 ? .5f * (zc + zl) : zc;
+  const float upper = s < N - 1 ? .5f * (zu + zc) : zc;
+  const float t = t_rand ? t_rand[idx] : philox_uniform(seed, offset, 0u, (uint32_t)idx);
+  z[idx] = lower + (upper - lower) * t;
+}
+
+void launch_sample_coarse(const float* t_rand, int B, int N, float near_p, float far_p, int stratified, int lindisp,
+                          uint64_t seed, uint64_t offset, float* z, hipStream_t stream) {
+  const int total = B * N;
+  hipLaunchKernelGGL(sample_coarse_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t_rand, B, N, near_p,
+                     far_p, stratified, lindisp, seed, offset, z);
+}
+
+// ------------------------------------------------------------------ compositing
+constexpr int MAX_E = 8;   // up to 512 samples per ray
+
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const float4* __restrict__ out4, const float* __restrict__ z, const float* __restrict__ dirs, int B, int S,
+    int white_bkgd, int sample_at_inf, float* __restrict__ o_rgb, float* __restrict__ o_depth,
+    float* __restrict__ o_med, float* __restrict__ o_acc, float* __restrict__ o_w) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= B) return;
+  const float dx = dirs[3 * ray], dy = dirs[3 * ray + 1], dz = dirs[3 * ray + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float last = sample_at_inf ? 1e10f : 1e-19f;
+  const float* zr = z + (size_t)ray * S;
+  const float4* cr = out4 + (size_t)ray * S;
+  float Tc = 1.f, Wc = 0.f;
+  float r0 = 0.f, r1 = 0.f, r2 = 0.f, dep = 0.f, acc_all = 0.f, acc_nl = 0.f, med = 0.f;
+  bool found = false;
+  const int E = (S + 63) >> 6;
+  for (int e = 0; e < E; ++e) {
+    const int s = e * 64 + lane;
+    const bool valid = s < S;
+    float zi = 0.f, alpha = 0.f, tt = 1.f;
+    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      zi = zr[s]; c = cr[s];
+      const float dist = (s + 1 < S ? zr[s + 1] - zi : last) * dnorm;   // model_utils.py:104-109
+      alpha = 1.0f - expf(-c.w * dist);                                // :110
+      tt = 1.0f - alpha + 1e-10f;                                      // :114
+    }
+    const float incl = wave_incl_prod(tt, lane);
+    float T = __shfl_up(incl, 1);
+    if (lane == 0) T = 1.f;
+    T *= Tc;
+    const float w = alpha * T;                                         // :116
+    const float cum = wave_incl_sum(w, lane) + Wc;
+    if (valid && o_w) o_w[(size_t)ray * S + s] = w;
+    r0 += w * c.x; r1 += w * c.y; r2 += w * c.z; dep += w * zi; acc_all += w;
+    if (s < S - 1) acc_nl += w;
+    // median depth: first sample whose cumulative weight reaches 0.5 (model_utils.py:218-263)
+    const unsigned long long m = __ballot(valid && cum >= 0.5f);
+    if (!found && m) {
+      const int first = __ffsll((long long)m) - 1;
+      med = __shfl(zi, first);
+      found = true;
+    }
+    Tc *= __shfl(incl, 63);
+    Wc = __shfl(cum, 63);
+  }
+  r0 = wave_sum(r0); r1 = wave_sum(r1); r2 = wave_sum(r2); dep = wave_sum(dep);
+  acc_all = wave_sum(acc_all); acc_nl = wave_sum(acc_nl);
+  if (lane == 0) {
+    if (white_bkgd) { r0 += 1.f - acc_all; r1 += 1.f - acc_all; r2 += 1.f - acc_all; }   // :122-123
+    if (o_rgb) { o_rgb[3 * ray] = r0; o_rgb[3 * ray + 1] = r1; o_rgb[3 * ray + 2] = r2; }
+    if (o_depth) o_depth[ray] = dep;
+    if (o_med) o_med[ray] = med;
+    if (o_acc) o_acc[ray] = sample_at_inf ? acc_nl : acc_all;                             // :125-126
+  }
+}
+
+void launch_composite_fwd(const float4* out4, const float* z, const float* dirs, int B, int S, int white_bkgd,
+                          int sample_at_inf, float* rgb, float* depth, float* med_depth, float* acc, float* weights,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(composite_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, out4, z, dirs, B, S, white_bkgd,
+                     sample_at_inf, rgb, depth, med_depth, acc, weights);
+}
+
+// Reverse pass of volumetric_rendering + sigmoid / sigma activation + the MSE loss.
+// With g_i = c_i . dL/drgb, t_i = 1-alpha_i+1e-10 and Q_i = sum_{k>i} g_k alpha_k prod_{i<j<k} t_j
+// (reverse affine recurrence Q_i = g_{i+1} alpha_{i+1} + t_{i+1} Q_{i+1}; division free):
+//   dL/dalpha_i = T_i (g_i - Q_i);  dL/dsigma_i = dist_i exp(-sigma_i dist_i) dL/dalpha_i;  dL/dc_i = w_i dL/drgb.
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float4* __restrict__ out4, const float* __restrict__ z, const float* __restrict__ dirs, int B, int S,
+    int white_bkgd, int sample_at_inf, int sigma_act, const float* __restrict__ rgb_out,
+    const float* __restrict__ target, const float* __restrict__ d_rgb, float loss_scale,
+    float4* __restrict__ d_raw4, int rows_pad, float* __restrict__ mse_sum) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (blockIdx.x == 0) {   // zero the tile padding rows so they contribute nothing to any gradient
+    for (int r = B * S + threadIdx.x; r < rows_pad; r += blockDim.x) d_raw4[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (ray >= B) return;
+  float g0, g1, g2;
+  if (d_rgb) { g0 = d_rgb[3 * ray]; g1 = d_rgb[3 * ray + 1]; g2 = d_rgb[3 * ray + 2]; }
+  else {
+    const float e0 = rgb_out[3 * ray] - target[3 * ray], e1 = rgb_out[3 * ray + 1] - target[3 * ray + 1],
+                e2 = rgb_out[3 * ray + 2] - target[3 * ray + 2];
+    g0 = loss_scale * e0; g1 = loss_scale * e1; g2 = loss_scale * e2;   // d mean((rgb-t)^2) (training.py:172)
+    if (lane == 0 && mse_sum) atomicAdd(mse_sum, e0 * e0 + e1 * e1 + e2 * e2);
+  }
+  const float gsum = g0 + g1 + g2;
+  const float dx = dirs[3 * ray], dy = dirs[3 * ray + 1], dz = dirs[3 * ray + 2];
+  const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+  const float last = sample_at_inf ? 1e10f : 1e-19f;
+  const float* zr = z + (size_t)ray * S;
+  const float4* cr = out4 + (size_t)ray * S;
+  const int E = (S + 63) >> 6;
+  float Tv[MAX_E], av[MAX_E], tv[MAX_E], dv[MAX_E], gv[MAX_E];
+  float4 cv[MAX_E];
+  float Tc = 1.f;
+#pragma unroll
+  for (int e = 0; e < MAX_E; ++e) {
+    if (e < E) {
+      const int s = e * 64 + lane;
+      const bool valid = s < S;
+      float alpha = 0.f, tt = 1.f, dist = 0.f;
+      float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (valid) {
+        const float zi = zr[s]; c = cr[s];
+        dist = (s + 1 < S ? zr[s + 1] - zi : last) * dnorm;
+        alpha = 1.0f - expf(-c.w * dist);
+        tt = 1.0f - alpha + 1e-10f;
+      }
+      const float incl = wave_incl_prod(tt, lane);
+      float T = __shfl_up(incl, 1);
+      if (lane == 0) T = 1.f;
+      T *= Tc;
+      Tc *= __shfl(incl, 63);
+      float g = c.x * g0 + c.y * g1 + c.z * g2;
+      if (white_bkgd) g -= gsum;
+      Tv[e] = T; av[e] = alpha; tv[e] = tt; dv[e] = dist; gv[e] = valid ? g : 0.f; cv[e] = c;
+    }
+  }
+  float Qin = 0.f;   // Q of the last sample of the chunk being processed
+#pragma unroll
+  for (int e = MAX_E - 1; e >= 0; --e) {
+    if (e < E) {
+      const int s = e * 64 + lane;
+      const bool valid = s < S;
+      // suffix composition C_l = m_l o m_{l+1} o ... o m_63, m_s(Q) = g_s alpha_s + t_s Q
+      float Aa = valid ? gv[e] * av[e] : 0.f, Bb = valid ? tv[e] : 1.f;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const float Ar = __shfl_down(Aa, o), Br = __shfl_down(Bb, o);
+        if (lane + o < 64) { Aa = Aa + Bb * Ar; Bb = Bb * Br; }
+      }
+      float An = __shfl_down(Aa, 1), Bn = __shfl_down(Bb, 1);
+      if (lane == 63) { An = 0.f; Bn = 1.f; }
+      const float Q = An + Bn * Qin;
+      Qin = __shfl(Aa, 0) + __shfl(Bb, 0) * Qin;
+      if (valid) {
+        const float4 c = cv[e];
+        const float w = av[e] * Tv[e];
+        const float dalpha = Tv[e] * (gv[e] - Q);
+        const float dsigma = dv[e] * expf(-c.w * dv[e]) * dalpha;
+        float4 o;
+        o.x = w * g0 * c.x * (1.f - c.x);           // through sigmoid (models.py:276)
+        o.y = w * g1 * c.y * (1.f - c.y);
+        o.z = w * g2 * c.z * (1.f - c.z);
+        o.w = sigma_act == 1 ? dsigma * (1.f - expf(-c.w)) : (c.w > 0.f ? dsigma : 0.f);   // softplus' / relu'
+        d_raw4[(size_t)ray * S + s] = o;
+      }
+    }
+  }
+}
+
+void launch_composite_bwd(const float4* out4, const float* z, const float* dirs, int B, int S, int white_bkgd,
+                          int sample_at_inf, int sigma_act, const float* rgb_out, const float* target, const float* d_rgb,
+                          float loss_scale, float4* d_raw4, int rows_pad, float* mse_sum, hipStream_t stream) {
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, out4, z, dirs, B, S, white_bkgd,
+                     sample_at_inf, sigma_act, rgb_out, target, d_rgb, loss_scale, d_raw4, rows_pad, mse_sum);
+}
+
+// ------------------------------------------------------------------ hierarchical sampling
+constexpr int SF_MAXC = 256;   // max coarse samples
+constexpr int SF_MAXT = 512;   // max coarse + fine samples
+
+__global__ __launch_bounds__(256) void sample_fine_kernel(
+    const float* __restrict__ z_c, const float* __restrict__ w_c, int B, int Nc, int Nf, int stratified,
+    const float* __restrict__ u_in, uint64_t seed, uint64_t offset, float* __restrict__ z_out) {
+  __shared__ float s_bins[4][SF_MAXC];
+  __shared__ float s_cdf[4][SF_MAXC];
+  __shared__ float s_all[4][SF_MAXT];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int ray_raw = blockIdx.x * 4 + wv;
+  const bool live = ray_raw < B;
+  const int ray = live ? ray_raw : B - 1;
+  const float* zr = z_c + (size_t)ray * Nc;
+  const float* wr = w_c + (size_t)ray * Nc;
+  float* bins = s_bins[wv]; float* cdf = s_cdf[wv]; float* all = s_all[wv];
+  const int n = Nc - 1;         // bins (midpoints);  n-1 = Nc-2 interior weights (models.py:353-355)
+  // pdf = (w + 1e-5) / sum ; cdf = [0, cumsum(pdf)]   (model_utils.py:153-159)
+  float tot = 0.f;
+  for (int m = lane; m < n - 1; m += 64) tot += wr[m + 1] + 1e-5f;
+  tot = wave_sum(tot);
+  float carry = 0.f;
+  for (int m0 = 0; m0 < n - 1; m0 += 64) {
+    const int m = m0 + lane;
+    const float pdf = m < n - 1 ? (wr[m + 1] + 1e-5f) / tot : 0.f;
+    const float c = wave_incl_sum(pdf, lane) + carry;
+    if (m < n - 1) cdf[m + 1] = c;
+    carry = __shfl(c, 63);
+  }
+  if (lane == 0) cdf[0] = 0.f;
+  for (int m = lane; m < n; m += 64) bins[m] = .5f * (zr[m + 1] + zr[m]);
+  for (int s = lane; s < Nc; s += 64) all[s] = zr[s];
+  __syncthreads();
+  // inverse CDF (model_utils.py:162-184), as searchsorted(cdf, u, 'right') + clamps
+  for (int jx = lane; jx < Nf; jx += 64) {
+    float u;
+    if (stratified) u = u_in ? u_in[(size_t)ray * Nf + jx] : philox_uniform(seed, offset, 1u, (uint32_t)(ray * Nf + jx));
+    else u = (jx == Nf - 1) ? 1.0f : (float)jx / (float)(Nf - 1);
+    int lo_i = 0, hi_i = n;   // idx = #{i : cdf_i <= u}
+    while (lo_i < hi_i) { const int mid = (lo_i + hi_i) >> 1; if (cdf[mid] <= u) lo_i = mid + 1; else hi_i = mid; }
+    const int idx = lo_i;
+    const int lo = min(max(idx - 1, 0), n - 2), hi = min(max(idx, 1), n - 1);
+    const float c0 = cdf[lo], c1 = cdf[hi];
+    float denom = c1 - c0;
+    if (denom < 1e-5f) denom = 1.f;
+    const float t = (u - c0) / denom;
+    all[Nc + jx] = bins[lo] + t * (bins[hi] - bins[lo]);
+  }
+  __syncthreads();
+  // sort(concat(z_coarse, z_samples)) (model_utils.py:213) by stable rank counting
+  const int Ntot = Nc + Nf;
+  for (int a = lane; a < Ntot; a += 64) {
+    const float v = all[a];
+    int rank = 0;
+    for (int k = 0; k < Ntot; ++k) { const float o = all[k]; rank += (o < v || (o == v && k < a)) ? 1 : 0; }
+    if (live) z_out[(size_t)ray * Ntot + rank] = v;
+  }
+}
+
+void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int Nf, int stratified, const float* u,
+                        uint64_t seed, uint64_t offset, float* z_out, hipStream_t stream) {
+  hipLaunchKernelGGL(sample_fine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, z_c, w_c, B, Nc, Nf, stratified, u,
+                     seed, offset, z_out);
+}
+
+// ------------------------------------------------------------------ small gradient pieces
+// dW_rgbh[256+c][n] = sum_ray cond[ray][c] * dray[ray][n]
+__global__ __launch_bounds__(128) void cond_wgrad_kernel(const float* __restrict__ cond, const float* __restrict__ dray,
+                                                         int B, int R, float* __restrict__ dst) {
+  const int c = blockIdx.x, n = threadIdx.x;
+  float acc = 0.f;
+  for (int ray = 0; ray < B; ++ray) acc = fmaf(cond[(size_t)ray * R + c], dray[(size_t)ray * RGB_W + n], acc);
+  dst[(size_t)c * RGB_W + n] = acc;
+}
+
+void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst, hipStream_t stream) {
+  if (R > 0) hipLaunchKernelGGL(cond_wgrad_kernel, dim3(R), dim3(128), 0, stream, cond, dray, B, R, dst);
+}
+
+__global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, float* __restrict__ stats) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const float mc = mse_sums[0] / (3.f * B), mf = mse_sums[1] / (3.f * B);
+    stats[0] = mc; stats[1] = mf;
+    stats[2] = -10.f * logf(mc) / logf(10.f);   // utils.compute_psnr (utils.py:94-103)
+    stats[3] = -10.f * logf(mf) / logf(10.f);
+    stats[4] = mc + mf;                           // training.py:261
+    stats[5] = stats[6] = stats[7] = 0.f;
+  }
+}
+
+void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, mse_sums, B, stats);
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                            const float* __restrict__ g, int64_t n, float lr, float b1, float b2, float eps,
+                            float c1, float c2, float gscale) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+  }
+}
+
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
+                 int64_t step, float gscale, hipStream_t stream) {
+  const double t = (double)step + 1.0;
+  const float c1 = (float)(1.0 - pow((double)b1, t)), c2 = (float)(1.0 - pow((double)b2, t));
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, m, v, g, n, lr, b1, b2, eps, c1, c2, gscale);
+}
+
+}  // namespace nrf

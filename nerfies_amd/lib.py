@@ -1,0 +1,112 @@
+"""ctypes binding of include/nerfies_amd.h.  Fails loudly when the HIP extension is absent:
+there is no CPU or PyTorch fallback for the hot path."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, '_lib', 'libnerfies_amd.so')
+
+NRF_FLAG_TRAIN = 1
+ACT = {'relu': 0, 'softplus': 1}
+
+
+class NrfError(RuntimeError):
+  pass
+
+
+class ModelDesc(C.Structure):
+  _fields_ = [
+      ('num_coarse_samples', C.c_int32), ('num_fine_samples', C.c_int32), ('use_viewdirs', C.c_int32),
+      ('near_plane', C.c_float), ('far_plane', C.c_float),
+      ('nerf_trunk_depth', C.c_int32), ('nerf_trunk_width', C.c_int32),
+      ('nerf_rgb_branch_depth', C.c_int32), ('nerf_rgb_branch_width', C.c_int32), ('nerf_skip_layer', C.c_int32),
+      ('use_stratified_sampling', C.c_int32), ('num_nerf_point_freqs', C.c_int32),
+      ('num_nerf_viewdir_freqs', C.c_int32), ('sigma_activation', C.c_int32),
+      ('use_white_background', C.c_int32), ('use_linear_disparity', C.c_int32), ('use_sample_at_infinity', C.c_int32),
+      ('use_appearance_metadata', C.c_int32), ('num_appearance_embeddings', C.c_int32),
+      ('num_appearance_features', C.c_int32), ('use_camera_metadata', C.c_int32),
+      ('num_camera_embeddings', C.c_int32), ('num_camera_features', C.c_int32),
+      ('use_alpha_condition', C.c_int32), ('use_rgb_condition', C.c_int32), ('use_trunk_condition', C.c_int32),
+      ('use_warp', C.c_int32), ('num_warp_freqs', C.c_int32), ('num_warp_embeddings', C.c_int32),
+      ('num_warp_features', C.c_int32),
+  ]
+
+
+class TensorInfo(C.Structure):
+  _fields_ = [('name', C.c_char * 96), ('offset', C.c_int64), ('rows', C.c_int32), ('cols', C.c_int32)]
+
+
+class Rays(C.Structure):
+  _fields_ = [('num_rays', C.c_int32), ('origins', C.c_void_p), ('directions', C.c_void_p), ('viewdirs', C.c_void_p),
+              ('warp_ids', C.c_void_p), ('appearance_ids', C.c_void_p), ('camera_ids', C.c_void_p)]
+
+
+class StepScalars(C.Structure):
+  _fields_ = [('warp_alpha', C.c_float), ('time_alpha', C.c_float)]
+
+
+class Rand(C.Structure):
+  _fields_ = [('t_rand', C.c_void_p), ('u', C.c_void_p), ('seed', C.c_uint64), ('offset', C.c_uint64)]
+
+
+class LevelOut(C.Structure):
+  _fields_ = [('rgb', C.c_void_p), ('depth', C.c_void_p), ('med_depth', C.c_void_p), ('acc', C.c_void_p),
+              ('weights', C.c_void_p), ('z_vals', C.c_void_p)]
+
+
+class Outputs(C.Structure):
+  _fields_ = [('coarse', LevelOut), ('fine', LevelOut)]
+
+
+EXPORTS = [
+    'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',
+    'nrf_workspace_bytes', 'nrf_forward', 'nrf_backward', 'nrf_train_step_loss_grad', 'nrf_adam_step',
+    'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf',
+]
+
+_lib = None
+
+
+def load_library(path=None):
+  """Loads libnerfies_amd.so (built by nerfies_amd.build / __graft_entry__.build())."""
+  global _lib
+  if _lib is not None and path is None:
+    return _lib
+  path = path or LIB_PATH
+  if not os.path.exists(path):
+    raise NrfError(
+        f'HIP extension not built: {path} is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
+        '(needs hipcc). There is no CPU fallback for the hot path.')
+  lib = C.CDLL(path)
+  vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+  lib.nrf_version.restype = C.c_int
+  lib.nrf_last_error.restype = C.c_char_p
+  sigs = {
+      'nrf_create': [C.POINTER(ModelDesc), C.POINTER(vp)],
+      'nrf_destroy': [vp],
+      'nrf_param_count': [vp, C.POINTER(i64)],
+      'nrf_param_layout': [vp, C.POINTER(TensorInfo), C.POINTER(i32)],
+      'nrf_workspace_bytes': [vp, i32, u32, C.POINTER(C.c_size_t)],
+      'nrf_forward': [vp, vp, C.POINTER(Rays), C.POINTER(StepScalars), C.POINTER(Rand), C.POINTER(Outputs), u32, vp,
+                      C.c_size_t, vp],
+      'nrf_backward': [vp, vp, C.POINTER(Rays), vp, vp, vp, vp, C.c_size_t, vp],
+      'nrf_train_step_loss_grad': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand), vp, vp, vp,
+                                   C.c_size_t, vp],
+      'nrf_adam_step': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp],
+      'nrf_sample_along_rays': [vp, vp, i32, i32, f32, f32, i32, i32, vp, u64, u64, vp, vp],
+      'nrf_volumetric_rendering': [vp, vp, vp, i32, i32, i32, i32, C.POINTER(LevelOut), vp],
+      'nrf_sample_pdf': [vp, vp, i32, i32, i32, i32, vp, u64, u64, vp, vp],
+  }
+  for name, argtypes in sigs.items():
+    fn = getattr(lib, name)
+    fn.argtypes = argtypes
+    fn.restype = C.c_int
+  if path == LIB_PATH:
+    _lib = lib
+  return lib
+
+
+def check(rc, lib=None):
+  if rc != 0:
+    lib = lib or load_library()
+    raise NrfError(f'nerfies_amd error {rc}: {lib.nrf_last_error().decode()}')

@@ -1,0 +1,340 @@
+"""Host-side mirror of nerfies.models (reference: nerfies/models.py:31-489).
+
+`NerfModel.apply` keeps the reference signature (models.py:289-299); the work is done by the HIP
+library through the C-ABI (include/nerfies_amd.h).  Differences forced by the missing JAX runtime:
+  * `rngs={'coarse': k0, 'fine': k1}`: a key is either an int seed (on-device Philox) or a float
+    tensor of explicit uniforms, (B,N_c) for 'coarse' and (B,N_f) for 'fine' (parity runs);
+  * arrays are torch tensors on the GPU; params are a `FlatParams` (fast path) or a flax-style
+    nested dict (copied into a flat buffer per call).
+"""
+import ctypes as C
+import dataclasses
+from typing import Any, Dict, Mapping, Optional, Sequence, Tuple
+
+import torch
+
+from nerfies_amd import lib as L
+from nerfies_amd import params as P
+
+
+def _ptr(t: Optional[torch.Tensor]):
+  return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t, device):
+  return torch.as_tensor(t, device=device).to(torch.float32).contiguous()
+
+
+def _ids(t, device):
+  if t is None:
+    return None
+  t = torch.as_tensor(t, device=device)
+  if t.dim() == 2 and t.shape[-1] == 1:   # glo.py:50-51 squeezes the trailing 1
+    t = t[..., 0]
+  return t.to(torch.int32).contiguous()
+
+
+def _act_name(a):
+  if isinstance(a, str):
+    return a
+  name = getattr(a, '__name__', str(a))
+  for k in ('softplus', 'relu'):
+    if k in name:
+      return k
+  raise ValueError(f'unsupported activation {a!r}')
+
+
+@dataclasses.dataclass
+class NerfModel:
+  """Attributes mirror nerfies.models.NerfModel (models.py:75-119)."""
+  num_coarse_samples: int
+  num_fine_samples: int
+  use_viewdirs: bool
+  near: float
+  far: float
+  noise_std: Optional[float]
+  nerf_trunk_depth: int
+  nerf_trunk_width: int
+  nerf_rgb_branch_depth: int
+  nerf_rgb_branch_width: int
+  nerf_skips: Tuple[int, ...]
+  alpha_channels: int
+  rgb_channels: int
+  use_stratified_sampling: bool
+  num_nerf_point_freqs: int
+  num_nerf_viewdir_freqs: int
+  appearance_ids: Sequence[int]
+  camera_ids: Sequence[int]
+  warp_ids: Sequence[int]
+  num_appearance_features: int
+  num_camera_features: int
+  num_warp_features: int
+  num_warp_freqs: int
+  activation: Any = 'relu'
+  sigma_activation: Any = 'relu'
+  use_white_background: bool = False
+  use_linear_disparity: bool = False
+  use_sample_at_infinity: bool = True
+  warp_field_type: str = 'se3'
+  warp_metadata_encoder_type: str = 'glo'
+  use_appearance_metadata: bool = False
+  use_camera_metadata: bool = False
+  use_warp: bool = False
+  use_warp_jacobian: bool = False
+  use_weights: bool = False
+  use_trunk_condition: bool = False
+  use_alpha_condition: bool = False
+  use_rgb_condition: bool = False
+  warp_kwargs: Mapping[str, Any] = dataclasses.field(default_factory=dict)
+  metadata_encoded: bool = False
+
+  def __post_init__(self):
+    self._handle = None
+    self._layout = None
+    self._ws = {}
+    self._lib = None
+
+  # models.py:121-131
+  @property
+  def num_appearance_embeddings(self):
+    return max(self.appearance_ids) + 1
+
+  @property
+  def num_warp_embeddings(self):
+    return max(self.warp_ids) + 1
+
+  @property
+  def num_camera_embeddings(self):
+    return max(self.camera_ids) + 1
+
+  # ---- C-ABI plumbing -------------------------------------------------------------------
+  def desc(self) -> L.ModelDesc:
+    if self.noise_std not in (None, 0, 0.0):
+      raise L.NrfError('noise_std regularisation is not built (no preset sets it, defaults.gin)')
+    if _act_name(self.activation) != 'relu':
+      raise L.NrfError('only relu trunk activation is built')
+    if self.alpha_channels != 1 or self.rgb_channels != 3:
+      raise L.NrfError('alpha_channels/rgb_channels must be 1/3')
+    skips = tuple(self.nerf_skips)
+    if len(skips) > 1:
+      raise L.NrfError('at most one skip layer')
+    d = L.ModelDesc()
+    d.num_coarse_samples = self.num_coarse_samples
+    d.num_fine_samples = self.num_fine_samples
+    d.use_viewdirs = int(self.use_viewdirs)
+    d.near_plane = float(self.near)
+    d.far_plane = float(self.far)
+    d.nerf_trunk_depth = self.nerf_trunk_depth
+    d.nerf_trunk_width = self.nerf_trunk_width
+    d.nerf_rgb_branch_depth = self.nerf_rgb_branch_depth
+    d.nerf_rgb_branch_width = self.nerf_rgb_branch_width
+    d.nerf_skip_layer = skips[0] if skips else -1
+    d.use_stratified_sampling = int(self.use_stratified_sampling)
+    d.num_nerf_point_freqs = self.num_nerf_point_freqs
+    d.num_nerf_viewdir_freqs = self.num_nerf_viewdir_freqs
+    d.sigma_activation = L.ACT[_act_name(self.sigma_activation)]
+    d.use_white_background = int(self.use_white_background)
+    d.use_linear_disparity = int(self.use_linear_disparity)
+    d.use_sample_at_infinity = int(self.use_sample_at_infinity)
+    d.use_appearance_metadata = int(self.use_appearance_metadata)
+    d.num_appearance_embeddings = self.num_appearance_embeddings if self.use_appearance_metadata else 0
+    d.num_appearance_features = self.num_appearance_features
+    d.use_camera_metadata = int(self.use_camera_metadata)
+    d.num_camera_embeddings = self.num_camera_embeddings if self.use_camera_metadata else 0
+    d.num_camera_features = self.num_camera_features
+    d.use_alpha_condition = int(self.use_alpha_condition)
+    d.use_rgb_condition = int(self.use_rgb_condition)
+    d.use_trunk_condition = int(self.use_trunk_condition)
+    d.use_warp = int(self.use_warp)
+    d.num_warp_freqs = self.num_warp_freqs
+    d.num_warp_embeddings = self.num_warp_embeddings if self.use_warp else 0
+    d.num_warp_features = self.num_warp_features
+    return d
+
+  @property
+  def lib(self):
+    if self._lib is None:
+      self._lib = L.load_library()
+    return self._lib
+
+  @property
+  def handle(self):
+    if self._handle is None:
+      h = C.c_void_p()
+      d = self.desc()
+      L.check(self.lib.nrf_create(C.byref(d), C.byref(h)), self.lib)
+      self._handle = h
+    return self._handle
+
+  @property
+  def layout(self) -> P.ParamLayout:
+    if self._layout is None:
+      n = C.c_int32(0)
+      L.check(self.lib.nrf_param_layout(self.handle, None, C.byref(n)), self.lib)
+      infos = (L.TensorInfo * n.value)()
+      L.check(self.lib.nrf_param_layout(self.handle, infos, C.byref(n)), self.lib)
+      total = C.c_int64(0)
+      L.check(self.lib.nrf_param_count(self.handle, C.byref(total)), self.lib)
+      self._layout = P.layout_from_infos(infos, total.value)
+    return self._layout
+
+  def workspace(self, num_rays: int, train: bool, device) -> torch.Tensor:
+    key = (int(num_rays), bool(train), str(device))
+    ws = self._ws.get(key)
+    if ws is None:
+      nbytes = C.c_size_t(0)
+      L.check(self.lib.nrf_workspace_bytes(self.handle, num_rays, L.NRF_FLAG_TRAIN if train else 0, C.byref(nbytes)),
+              self.lib)
+      ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
+      self._ws[key] = ws
+    return ws
+
+  def flat_params(self, variables, device) -> P.FlatParams:
+    params = variables['params'] if isinstance(variables, dict) and 'params' in variables else variables
+    if isinstance(params, P.FlatParams):
+      return params
+    if isinstance(params, dict) and 'model' in params and 'nerf_mlps_coarse' not in params:
+      params = params['model']
+    return P.FlatParams(P.flat_from_tree(params, self.layout, device), self.layout)
+
+  def _rays_struct(self, rays_dict, device):
+    origins = _f32(rays_dict['origins'], device)
+    directions = _f32(rays_dict['directions'], device)
+    viewdirs = _f32(rays_dict['viewdirs'], device) if 'viewdirs' in rays_dict else None
+    md = rays_dict.get('metadata', {}) or {}
+    keep = [origins, directions, viewdirs]
+    r = L.Rays()
+    r.num_rays = origins.shape[0]
+    r.origins, r.directions, r.viewdirs = _ptr(origins), _ptr(directions), _ptr(viewdirs)
+    for field, key in (('warp_ids', 'warp'), ('appearance_ids', 'appearance'), ('camera_ids', 'camera')):
+      t = _ids(md.get(key), device)
+      keep.append(t)
+      setattr(r, field, _ptr(t))
+    return r, keep
+
+  def _rand_struct(self, rngs, num_rays, device):
+    rnd = L.Rand()
+    keep = []
+    rngs = rngs or {}
+    for field, key, n in (('t_rand', 'coarse', self.num_coarse_samples), ('u', 'fine', self.num_fine_samples)):
+      k = rngs.get(key)
+      if isinstance(k, torch.Tensor) and k.is_floating_point() and k.dim() == 2:
+        if tuple(k.shape) != (num_rays, n):
+          raise L.NrfError(f"rngs[{key!r}] uniforms must have shape {(num_rays, n)}")
+        t = _f32(k, device)
+        keep.append(t)
+        setattr(rnd, field, _ptr(t))
+      elif k is not None:
+        seed = int(k.item()) if isinstance(k, torch.Tensor) else int(k)
+        rnd.seed = (rnd.seed * 0x9E3779B97F4A7C15 + seed) & 0xFFFFFFFFFFFFFFFF
+    return rnd, keep
+
+  # ---- NerfModel.__call__ (models.py:289-375) ---------------------------------------------
+  def apply(self, variables, rays_dict: Dict[str, Any], warp_extra: Dict[str, Any] = None, metadata_encoded=False,
+            use_warp=True, return_points=False, return_weights=False, return_warp_jacobian=False,
+            deterministic=False, rngs=None, *, train=False):
+    """Returns {'coarse': {...}, 'fine': {...}} like the reference.  `train=True` keeps the
+    activation stash so `backward` can follow (used by training.train_step / autograd)."""
+    del deterministic   # accepted and unused, as in the reference (models.py:298)
+    if metadata_encoded:
+      raise L.NrfError('metadata_encoded=True is not built yet')
+    if return_points or return_warp_jacobian:
+      raise L.NrfError('return_points / return_warp_jacobian need the warp field (not built yet)')
+    device = torch.as_tensor(rays_dict['origins']).device
+    if device.type != 'cuda':
+      raise L.NrfError('rays must live on the GPU: the hot path has no CPU fallback')
+    fp = self.flat_params(variables, device)
+    rays, keep = self._rays_struct(rays_dict, device)
+    B = rays.num_rays
+    rnd, keep2 = self._rand_struct(rngs, B, device)
+    return_weights = self.use_weights or return_weights
+    S = (self.num_coarse_samples, self.num_coarse_samples + self.num_fine_samples)
+    out = L.Outputs()
+    ret = {}
+    levels = [('coarse', out.coarse, S[0])] + ([('fine', out.fine, S[1])] if self.num_fine_samples > 0 else [])
+    for name, lo, s in levels:
+      d = {'rgb': torch.empty(B, 3, device=device), 'depth': torch.empty(B, device=device),
+           'med_depth': torch.empty(B, device=device), 'acc': torch.empty(B, device=device)}
+      if return_weights:
+        d['weights'] = torch.empty(B, s, device=device)
+      for k, t in d.items():
+        setattr(lo, k, _ptr(t))
+      ret[name] = d
+    scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
+    ws = self.workspace(B, train, device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    L.check(self.lib.nrf_forward(self.handle, _ptr(fp.flat), C.byref(rays), C.byref(scal), C.byref(rnd), C.byref(out),
+                                 L.NRF_FLAG_TRAIN if train else 0, _ptr(ws), ws.numel() * 4, stream), self.lib)
+    del keep, keep2
+    return ret
+
+  def backward(self, variables, rays_dict, d_rgb_coarse, d_rgb_fine, grad_out: torch.Tensor = None):
+    """VJP of the last `apply(..., train=True)` on the same rays: returns the flat parameter gradient."""
+    device = torch.as_tensor(rays_dict['origins']).device
+    fp = self.flat_params(variables, device)
+    rays, keep = self._rays_struct(rays_dict, device)
+    grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
+    dc = None if d_rgb_coarse is None else _f32(d_rgb_coarse, device)
+    df = None if d_rgb_fine is None else _f32(d_rgb_fine, device)
+    ws = self.workspace(rays.num_rays, True, device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    L.check(self.lib.nrf_backward(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(dc), _ptr(df), _ptr(grad), _ptr(ws),
+                                  ws.numel() * 4, stream), self.lib)
+    del keep
+    return grad
+
+  def loss_and_grad(self, fp: P.FlatParams, batch, warp_extra=None, rngs=None, grad_out=None, stats_out=None):
+    """forward + MSE_coarse + MSE_fine + backward in one library call (training.py:168-265)."""
+    device = fp.flat.device
+    rays, keep = self._rays_struct(batch, device)
+    rnd, keep2 = self._rand_struct(rngs, rays.num_rays, device)
+    target = _f32(batch['rgb'], device)[..., :3].contiguous()
+    grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
+    stats = stats_out if stats_out is not None else torch.empty(8, device=device)
+    scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
+    ws = self.workspace(rays.num_rays, True, device)
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    L.check(self.lib.nrf_train_step_loss_grad(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
+                                              C.byref(rnd), _ptr(grad), _ptr(stats), _ptr(ws), ws.numel() * 4, stream),
+            self.lib)
+    del keep, keep2
+    return grad, stats
+
+  def __del__(self):
+    try:
+      if self._handle is not None and self._lib is not None:
+        self._lib.nrf_destroy(self._handle)
+    except Exception:   # interpreter shutdown
+      pass
+
+
+def construct_nerf(key, config, batch_size: int, appearance_ids: Sequence[int], camera_ids: Sequence[int],
+                   warp_ids: Sequence[int], near: float, far: float, use_warp_jacobian: bool = False,
+                   use_weights: bool = False, device='cuda'):
+  """models.construct_nerf (models.py:378-489): builds the model and reference-initialised params.
+
+  `key` is an int seed.  `config` is any object with the ModelConfig attributes (configs.py:35-105).
+  `batch_size` is accepted for signature parity (shape inference is not needed here)."""
+  del batch_size
+  g = lambda name, default=None: getattr(config, name, default)
+  model = NerfModel(
+      num_coarse_samples=g('num_coarse_samples', 64), num_fine_samples=g('num_fine_samples', 128),
+      use_viewdirs=g('use_viewdirs', True), near=near, far=far, noise_std=g('noise_std'),
+      nerf_trunk_depth=g('nerf_trunk_depth', 8), nerf_trunk_width=g('nerf_trunk_width', 256),
+      nerf_rgb_branch_depth=g('nerf_rgb_branch_depth', 1), nerf_rgb_branch_width=g('nerf_rgb_branch_width', 128),
+      nerf_skips=tuple(g('nerf_skips', (4,))), alpha_channels=g('alpha_channels', 1), rgb_channels=g('rgb_channels', 3),
+      use_stratified_sampling=g('use_stratified_sampling', True), num_nerf_point_freqs=g('num_nerf_point_freqs', 10),
+      num_nerf_viewdir_freqs=g('num_nerf_viewdir_freqs', 4), appearance_ids=appearance_ids, camera_ids=camera_ids,
+      warp_ids=warp_ids, num_appearance_features=g('appearance_metadata_dims', 8),
+      num_camera_features=g('camera_metadata_dims', 2), num_warp_features=g('num_warp_features', 8),
+      num_warp_freqs=g('num_warp_freqs', 8), activation=g('activation', 'relu'),
+      sigma_activation=g('sigma_activation', 'relu'), use_white_background=g('use_white_background', False),
+      use_linear_disparity=g('use_linear_disparity', False), use_sample_at_infinity=g('use_sample_at_infinity', True),
+      warp_field_type=g('warp_field_type', 'translation'),
+      warp_metadata_encoder_type=g('warp_metadata_encoder_type', 'glo'),
+      use_appearance_metadata=g('use_appearance_metadata', False), use_camera_metadata=g('use_camera_metadata', False),
+      use_warp=g('use_warp', False), use_warp_jacobian=use_warp_jacobian, use_weights=use_weights,
+      use_alpha_condition=g('use_alpha_condition', False), use_rgb_condition=g('use_rgb_condition', False),
+      warp_kwargs=dict(g('warp_kwargs', {}) or {}))
+  flat = P.init_flat(model.layout, int(key), device)
+  return model, P.FlatParams(flat, model.layout)

@@ -1,0 +1,102 @@
+"""Host-side mirror of nerfies.training (reference: nerfies/training.py:35-271).
+
+`train_step` keeps the reference signature and return triple.  One call = forward + loss +
+backward inside the HIP library, one flat-buffer all-reduce over RCCL (the reference's
+lax.pmean(grad), training.py:266, with the 1/n folded into Adam) and a fused Adam step
+(flax.optim.Adam, training.py:268-269).  State is updated IN PLACE (device buffers are donated,
+as `donate_argnums` does in train.py:254-262).
+"""
+import ctypes as C
+import dataclasses
+from typing import Any, Dict, Optional
+
+import torch
+import torch.distributed as dist
+
+from nerfies_amd import lib as L
+from nerfies_amd import models
+from nerfies_amd import params as P
+
+
+@dataclasses.dataclass
+class ScalarParams:
+  """training.ScalarParams (training.py:35-43)."""
+  learning_rate: float
+  elastic_loss_weight: float = 0.0
+  warp_reg_loss_weight: float = 0.0
+  warp_reg_loss_alpha: float = -2.0
+  warp_reg_loss_scale: float = 0.001
+  background_loss_weight: float = 0.0
+  background_noise_std: float = 0.001
+
+
+class Optimizer:
+  """flax.optim.Adam state over the flat buffer (defaults beta=(0.9,0.999), eps=1e-8)."""
+
+  def __init__(self, target: P.FlatParams, beta1=0.9, beta2=0.999, eps=1e-8):
+    self.target = target
+    self.m = torch.zeros_like(target.flat)
+    self.v = torch.zeros_like(target.flat)
+    self.grad = torch.zeros_like(target.flat)
+    self.step = 0
+    self.beta1, self.beta2, self.eps = beta1, beta2, eps
+
+  def apply_gradient(self, grad: torch.Tensor, learning_rate: float, grad_scale: float = 1.0):
+    lib = L.load_library()
+    p = self.target.flat
+    stream = C.c_void_p(torch.cuda.current_stream(p.device).cuda_stream)
+    L.check(lib.nrf_adam_step(C.c_void_p(p.data_ptr()), C.c_void_p(self.m.data_ptr()), C.c_void_p(self.v.data_ptr()),
+                              C.c_void_p(grad.data_ptr()), p.numel(), float(learning_rate), self.beta1, self.beta2,
+                              self.eps, int(self.step), float(grad_scale), stream), lib)
+    self.step += 1
+    return self
+
+
+@dataclasses.dataclass
+class TrainState:
+  """model_utils.TrainState (model_utils.py:25-33)."""
+  optimizer: Optimizer
+  warp_alpha: float = 0.0
+  time_alpha: float = 0.0
+
+  @property
+  def warp_extra(self):
+    return {'alpha': self.warp_alpha, 'time_alpha': self.time_alpha}
+
+  def replace(self, **kw):
+    return dataclasses.replace(self, **kw)
+
+
+def _world():
+  if dist.is_available() and dist.is_initialized():
+    return dist.get_world_size()
+  return 1
+
+
+def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[str, Any],
+               scalar_params: ScalarParams, use_elastic_loss: bool = False, elastic_reduce_method: str = 'median',
+               elastic_loss_type: str = 'log_svals', use_background_loss: bool = False,
+               use_warp_reg_loss: bool = False):
+  """One optimisation step (training.py:138-271).  `batch` holds this rank's ray shard
+  ('rgb','origins','directions','metadata').  Returns (new_state, stats, rng_key)."""
+  if use_elastic_loss or use_background_loss or use_warp_reg_loss:
+    raise L.NrfError('elastic / background / warp-reg losses need the warp field (SURVEY 8f rank 1; not built yet)')
+  del elastic_reduce_method, elastic_loss_type
+  # random.split(rng_key, 4) (training.py:168): derive the per-step stream keys from an int key
+  rng_key = int(rng_key)
+  mix = lambda k, i: (k * 6364136223846793005 + 1442695040888963407 + i) & 0xFFFFFFFFFFFFFFFF
+  next_key, fine_key, coarse_key = mix(rng_key, 0), mix(rng_key, 1), mix(rng_key, 2)
+  opt = state.optimizer
+  grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
+                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad)
+  n = _world()
+  if n > 1:   # lax.pmean(grad) / lax.pmean(stats) (training.py:266-267): sum here, 1/n in Adam
+    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    stats = stats / n
+  opt.apply_gradient(grad, learning_rate=scalar_params.learning_rate, grad_scale=1.0 / n)
+  out = {
+      'coarse': {'loss/rgb': stats[0], 'loss/total': stats[0], 'metric/psnr': stats[2]},
+      'fine': {'loss/rgb': stats[1], 'loss/total': stats[1], 'metric/psnr': stats[3]},
+  }
+  return state, out, next_key

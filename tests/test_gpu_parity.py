@@ -1,0 +1,287 @@
+"""GPU parity tests: the HIP path (through the C-ABI) vs the CPU oracle on identical inputs.
+
+Tolerances: the north star asks for <= 1e-3 max-abs on rendered rgb/depth in fp32; the fp32-MFMA
+path is expected to land near 1e-5, so the tests use tighter bounds where stable.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfies_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda:0'
+
+
+def _lib():
+  from nerfies_amd import lib as L
+  return L, L.load_library()
+
+
+def _stream():
+  return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+  return C.c_void_p(t.data_ptr())
+
+
+class Cfg:
+  num_nerf_point_freqs = 8
+  sigma_activation = 'softplus'
+  use_stratified_sampling = False
+  num_coarse_samples = 64
+  num_fine_samples = 128
+
+
+def _make(B, seed=0, cfg=Cfg, **spec_kw):
+  from nerfies_amd import models, params as P
+  kw = dict(num_coarse_samples=cfg.num_coarse_samples, num_fine_samples=cfg.num_fine_samples,
+            num_nerf_point_freqs=cfg.num_nerf_point_freqs, use_stratified_sampling=cfg.use_stratified_sampling)
+  kw.update(spec_kw)
+  spec = O.ModelSpec(**kw)
+  oparams = O.init_params(spec, seed=seed, trained_like=True, dtype=torch.float32)
+  batch = O.synthetic_batch(B, seed=seed + 1, dtype=torch.float32)
+  model, fp = models.construct_nerf(0, cfg, B, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], spec.near, spec.far)
+  P.flat_from_tree(oparams, model.layout, DEV, out=fp.flat)
+  gb = {'origins': batch['origins'].to(DEV), 'directions': batch['directions'].to(DEV), 'rgb': batch['rgb'].to(DEV),
+        'metadata': {}}
+  p64 = O.tree_map(lambda t: t.double(), oparams)
+  b64 = {k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in batch.items()}
+  return spec, model, fp, gb, p64, b64
+
+
+def test_library_loads_on_gpu():
+  L, lib = _lib()
+  assert lib.nrf_version() >= 100
+  assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('stratified', [0, 1])
+@pytest.mark.parametrize('lindisp', [0, 1])
+def test_sample_along_rays(stratified, lindisp):
+  L, lib = _lib()
+  B, N = 50, 64
+  t_rand = torch.rand(B, N)
+  z = torch.empty(B, N, device=DEV)
+  tr = t_rand.to(DEV)
+  L.check(lib.nrf_sample_along_rays(None, None, B, N, 0.05, 0.9, stratified, lindisp, _p(tr), 0, 0, _p(z), _stream()))
+  o = torch.zeros(B, 3, dtype=torch.float64)
+  zo, _ = O.sample_along_rays(o, o, N, 0.05, 0.9, bool(stratified), bool(lindisp), t_rand.double())
+  np.testing.assert_allclose(z.cpu().numpy(), zo.numpy(), atol=2e-6)
+
+
+def test_sample_along_rays_philox_in_range_and_reproducible():
+  L, lib = _lib()
+  B, N = 33, 64
+  z1 = torch.empty(B, N, device=DEV); z2 = torch.empty(B, N, device=DEV); z3 = torch.empty(B, N, device=DEV)
+  for z, seed in ((z1, 7), (z2, 7), (z3, 8)):
+    L.check(lib.nrf_sample_along_rays(None, None, B, N, 0.05, 0.9, 1, 0, None, seed, 0, _p(z), _stream()))
+  assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+  zd = torch.empty(B, N, device=DEV)
+  L.check(lib.nrf_sample_along_rays(None, None, B, N, 0.05, 0.9, 0, 0, None, 0, 0, _p(zd), _stream()))
+  step = (0.9 - 0.05) / (N - 1)
+  assert (z1 - zd).abs().max() <= 0.5 * step * 1.001
+  assert (z1[:, 1:] >= z1[:, :-1]).all()
+  assert (z1 - zd).std() > 0.1 * step
+
+
+@pytest.mark.parametrize('S', [1, 33, 64, 192, 512])
+@pytest.mark.parametrize('white,inf', [(0, 1), (1, 1), (0, 0)])
+def test_volumetric_rendering(S, white, inf):
+  L, lib = _lib()
+  rng = np.random.default_rng(S)
+  B = 37
+  rgbs = torch.tensor(rng.uniform(size=(B, S, 4)), dtype=torch.float32)
+  rgbs[..., 3] = torch.tensor(rng.uniform(0, 40, size=(B, S)) ** 1.5, dtype=torch.float32)
+  rgbs[0, :, 3] = 0.0
+  z = torch.tensor(np.sort(rng.uniform(0.05, 1.0, size=(B, S)), -1), dtype=torch.float32)
+  d = torch.tensor(rng.normal(size=(B, 3)), dtype=torch.float32)
+  outs = {k: torch.empty(*s, device=DEV) for k, s in
+          dict(rgb=(B, 3), depth=(B,), med_depth=(B,), acc=(B,), weights=(B, S)).items()}
+  lo = L.LevelOut()
+  for k, t in outs.items():
+    setattr(lo, k, _p(t))
+  g = [t.to(DEV) for t in (rgbs, z, d)]
+  L.check(lib.nrf_volumetric_rendering(_p(g[0]), _p(g[1]), _p(g[2]), B, S, white, inf, C.byref(lo), _stream()))
+  ref = O.volumetric_rendering(rgbs[..., :3].double(), rgbs[..., 3].double(), z.double(), d.double(), bool(white), bool(inf))
+  for k in ('rgb', 'depth', 'acc', 'weights'):
+    np.testing.assert_allclose(outs[k].cpu().numpy(), ref[k].numpy(), atol=2e-5, err_msg=k)
+  # med_depth is a selection: allow a neighbouring sample only where the cumulative weight is within fp32 noise of 0.5
+  med = outs['med_depth'].cpu().double()
+  bad = (med - ref['med_depth']).abs() > 1e-6
+  if bad.any():
+    cum = torch.cumsum(ref['weights'], -1)
+    assert ((cum - 0.5).abs().min(-1).values[bad] < 1e-5).all()
+
+
+@pytest.mark.parametrize('Nc,Nf', [(64, 128), (128, 128), (3, 5), (256, 256), (65, 31)])
+@pytest.mark.parametrize('stratified', [0, 1])
+def test_sample_pdf(Nc, Nf, stratified):
+  L, lib = _lib()
+  rng = np.random.default_rng(Nc * 7 + Nf)
+  B = 41
+  zc = torch.tensor(np.sort(rng.uniform(0.05, 1.0, size=(B, Nc)), -1), dtype=torch.float32)
+  w = torch.tensor(rng.uniform(size=(B, Nc)) ** 6, dtype=torch.float32)
+  w[1] = 0.0
+  u = torch.tensor(rng.uniform(size=(B, Nf)), dtype=torch.float32)
+  zo = torch.empty(B, Nc + Nf, device=DEV)
+  g = [t.to(DEV) for t in (zc, w, u)]
+  L.check(lib.nrf_sample_pdf(_p(g[0]), _p(g[1]), B, Nc, Nf, stratified, _p(g[2]), 0, 0, _p(zo), _stream()))
+  zmid = .5 * (zc[..., 1:] + zc[..., :-1]).double()
+  o = torch.zeros(B, 3, dtype=torch.float64)
+  ref, _ = O.sample_pdf(zmid, w[..., 1:-1].double(), o, o, zc.double(), Nf, bool(stratified), u.double())
+  got = zo.cpu()
+  assert (got[:, 1:] >= got[:, :-1]).all()
+  np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=5e-6)
+
+
+@pytest.mark.parametrize('B', [64, 37])
+def test_forward_parity(B):
+  spec, model, fp, gb, p64, b64 = _make(B)
+  out = model.apply({'params': fp}, gb, {'alpha': 0.0, 'time_alpha': 0.0}, return_weights=True)
+  ref = O.nerf_model_apply(p64, spec, b64)
+  for lvl in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'weights'):
+      got = out[lvl][k].cpu().double()
+      err = (got - ref[lvl][k]).abs().max().item()
+      assert err < 1e-4, (lvl, k, err)     # north-star bound is 1e-3
+    med_err = (out[lvl]['med_depth'].cpu().double() - ref[lvl]['med_depth']).abs()
+    assert (med_err < 1e-4).float().mean() > 0.9
+
+
+def test_forward_parity_stratified_explicit_uniforms():
+  class C2(Cfg):
+    use_stratified_sampling = True
+  B = 48
+  spec, model, fp, gb, p64, b64 = _make(B, cfg=C2)
+  t_rand = torch.rand(B, 64); u = torch.rand(B, 128)
+  out = model.apply({'params': fp}, gb, {'alpha': 0.0}, rngs={'coarse': t_rand.to(DEV), 'fine': u.to(DEV)})
+  ref = O.nerf_model_apply(p64, spec, b64, t_rand=t_rand.double(), u=u.double())
+  for lvl in ('coarse', 'fine'):
+    assert (out[lvl]['rgb'].cpu().double() - ref[lvl]['rgb']).abs().max() < 1e-4
+    assert (out[lvl]['depth'].cpu().double() - ref[lvl]['depth']).abs().max() < 1e-4
+
+
+def test_forward_eval_equals_train_mode():
+  spec, model, fp, gb, _, _ = _make(40)
+  a = model.apply({'params': fp}, gb, {}, train=False)
+  b = model.apply({'params': fp}, gb, {}, train=True)
+  for lvl in ('coarse', 'fine'):
+    assert torch.equal(a[lvl]['rgb'], b[lvl]['rgb'])
+
+
+def _grad_compare(model, grad, ograds, tol=2e-3):
+  from nerfies_amd import params as P
+  got = P.tree_from_flat(grad.cpu(), model.layout)
+  worst = 0.0
+  for name, t in O.tree_leaves_with_path(ograds):
+    node = got
+    for part in name.split('/'):
+      node = node[part]
+    ref = t.float()
+    scale = max(ref.abs().max().item(), 1e-7)
+    err = (node - ref).abs().max().item() / scale
+    worst = max(worst, err)
+    assert err < tol, (name, err, scale)
+  return worst
+
+
+@pytest.mark.parametrize('B', [64, 37])
+def test_loss_and_grad_parity(B):
+  spec, model, fp, gb, p64, b64 = _make(B)
+  grad, stats = model.loss_and_grad(fp, gb)
+  loss, ostats, ograds, _ = O.loss_and_grad(p64, spec, b64)
+  assert abs(stats[4].item() - loss.item()) < 1e-5
+  assert abs(stats[0].item() - ostats['coarse']['loss/rgb'].item()) < 1e-5
+  assert abs(stats[3].item() - ostats['fine']['metric/psnr'].item()) < 1e-3
+  _grad_compare(model, grad, ograds)
+
+
+def test_backward_with_upstream_gradients_matches_loss_mode():
+  spec, model, fp, gb, _, _ = _make(64)
+  grad1, _ = model.loss_and_grad(fp, gb)
+  grad1 = grad1.clone()
+  out = model.apply({'params': fp}, gb, {}, train=True)
+  B = 64
+  dc = 2.0 / (3 * B) * (out['coarse']['rgb'] - gb['rgb'])
+  df = 2.0 / (3 * B) * (out['fine']['rgb'] - gb['rgb'])
+  grad2 = model.backward({'params': fp}, gb, dc, df)
+  assert (grad1 - grad2).abs().max() <= 1e-6 * max(grad1.abs().max().item(), 1e-12) + 1e-9
+
+
+def test_data_parallel_gradient_equals_full_batch():
+  """n-way ray-sharded gradients averaged == the single-device gradient on the same rays
+  (the property lax.pmean relies on, training.py:266), at the headline size B=1024."""
+  spec, model, fp, gb, _, _ = _make(1024)
+  full, st = model.loss_and_grad(fp, gb)
+  full = full.clone()
+  acc = torch.zeros_like(full)
+  n = 4
+  for r in range(n):
+    sl = slice(r * 256, (r + 1) * 256)
+    shard = {k: (v[sl] if torch.is_tensor(v) else v) for k, v in gb.items()}
+    g, _ = model.loss_and_grad(fp, shard)
+    acc += g
+  acc /= n
+  scale = full.abs().max().item()
+  assert (acc - full).abs().max().item() < 2e-5 * scale + 1e-9
+  assert torch.isfinite(full).all() and scale > 0
+
+
+def test_adam_step_matches_oracle():
+  L, lib = _lib()
+  n = 10007
+  p = torch.randn(n); m = torch.randn(n) * 0.1; v = torch.rand(n) * 0.01; g = torch.randn(n)
+  gp, gm, gv, gg = [t.clone().to(DEV) for t in (p, m, v, g)]
+  L.check(lib.nrf_adam_step(_p(gp), _p(gm), _p(gv), _p(gg), n, 1e-3, 0.9, 0.999, 1e-8, 41, 0.5, _stream()))
+  rp, rm, rv = O.adam_update(p.double(), m.double(), v.double(), 0.5 * g.double(), 41, 1e-3)
+  np.testing.assert_allclose(gp.cpu().numpy(), rp.numpy(), rtol=2e-6, atol=1e-7)
+  np.testing.assert_allclose(gm.cpu().numpy(), rm.numpy(), rtol=2e-6, atol=1e-7)
+  np.testing.assert_allclose(gv.cpu().numpy(), rv.numpy(), rtol=2e-6, atol=1e-9)
+
+
+def test_train_step_reduces_loss():
+  from nerfies_amd import training
+  spec, model, fp, gb, _, _ = _make(256)
+  from nerfies_amd import params as P
+  fp = P.FlatParams(P.init_flat(model.layout, 3, DEV), model.layout)
+  state = training.TrainState(optimizer=training.Optimizer(fp))
+  sp = training.ScalarParams(learning_rate=1e-3)
+  key = 0
+  losses = []
+  for _ in range(40):
+    state, stats, key = training.train_step(model, key, state, gb, sp)
+    losses.append(stats['fine']['loss/rgb'].item())
+  assert np.isfinite(losses).all()
+  assert losses[-1] < 0.7 * losses[0], losses[::8]
+  assert state.optimizer.step == 40
+
+
+def test_render_image_chunks_and_pads():
+  from nerfies_amd import evaluation, training
+  spec, model, fp, gb, p64, b64 = _make(70)
+  H, W = 7, 10
+  rays = {'origins': gb['origins'].reshape(H, W, 3), 'directions': gb['directions'].reshape(H, W, 3)}
+  state = training.TrainState(optimizer=training.Optimizer(fp))
+  fn = lambda k0, k1, params, r, extra: model.apply({'params': params}, r, extra)
+  img = evaluation.render_image(state, rays, fn, 1, 0, chunk=32)
+  whole = model.apply({'params': fp}, gb, {})
+  assert img['rgb'].shape == (H, W, 3)
+  np.testing.assert_allclose(img['rgb'].reshape(-1, 3).cpu().numpy(), whole['fine']['rgb'].cpu().numpy(), atol=1e-6)
+
+
+def test_errors_are_reported_not_fatal():
+  L, lib = _lib()
+  from nerfies_amd import models
+  class Bad(Cfg):
+    nerf_trunk_width = 128
+  with pytest.raises(L.NrfError):
+    models.construct_nerf(0, Bad, 8, [0], [0], [0], 0.1, 1.0)
+  spec, model, fp, gb, _, _ = _make(16)
+  with pytest.raises(L.NrfError):   # backward without a stashed forward on that workspace
+    model.apply({'params': fp}, gb, {}, train=False)
+    model.backward({'params': fp}, gb, gb['rgb'], gb['rgb'])

@@ -179,10 +179,11 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
 
 /* flax.optim.Adam.apply_gradient (training.py:268-269; flax 0.3.4 optim/adam.py):
  * g = grad*grad_scale (grad_scale = 1/world_size folds lax.pmean, training.py:266),
- * m,v updated in place, step = number of updates already applied. */
+ * m,v updated in place, step = number of updates already applied.  Hyper-parameters are doubles
+ * (flax keeps them as Python floats: 1-beta2 is formed in double, then rounded to fp32). */
 int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n,
-                  float lr, float beta1, float beta2, float eps, int64_t step,
-                  float grad_scale, void* stream);
+                  double lr, double beta1, double beta2, double eps, int64_t step,
+                  double grad_scale, void* stream);
 
 /* ---- individual operators (same device code the fused path runs), exposed so
  * parity tests can check each reference function in isolation. ---- */

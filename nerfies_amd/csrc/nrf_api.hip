@@ -595,8 +595,8 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream);
 }
 
-int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n, float lr, float beta1, float beta2,
-                  float eps, int64_t step, float grad_scale, void* stream) {
+int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n, double lr, double beta1, double beta2,
+                  double eps, int64_t step, double grad_scale, void* stream) {
   if (!params || !m || !v || !grad) return fail(NRF_E_NULL, "null argument");
   if (n <= 0) return fail(NRF_E_SHAPE, "n must be positive");
   launch_adam(params, m, v, grad, n, lr, beta1, beta2, eps, step, grad_scale, (hipStream_t)stream);

@@ -145,7 +145,7 @@ void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int N
 void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst /*[R][128]*/,
                        hipStream_t stream);
 void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t stream);
-void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1,
-                 float b2, float eps, int64_t step, float gscale, hipStream_t stream);
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
+                 double b2, double eps, int64_t step, double gscale, hipStream_t stream);
 
 }  // namespace nrf

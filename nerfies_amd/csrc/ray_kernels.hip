@@ -387,24 +387,25 @@ void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t
 
 // ------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-                            const float* __restrict__ g, int64_t n, float lr, float b1, float b2, float eps,
-                            float c1, float c2, float gscale) {
+                            const float* __restrict__ g, int64_t n, float lr, float b1, float omb1, float b2,
+                            float omb2, float eps, float c1, float c2, float gscale) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
     const float gi = g[i] * gscale;
-    const float mi = b1 * m[i] + (1.f - b1) * gi;
-    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi; v[i] = vi;
     p[i] = p[i] - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
   }
 }
 
-void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, float lr, float b1, float b2, float eps,
-                 int64_t step, float gscale, hipStream_t stream) {
+void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1, double b2, double eps,
+                 int64_t step, double gscale, hipStream_t stream) {
   const double t = (double)step + 1.0;
-  const float c1 = (float)(1.0 - pow((double)b1, t)), c2 = (float)(1.0 - pow((double)b2, t));
+  const float c1 = (float)(1.0 - pow(b1, t)), c2 = (float)(1.0 - pow(b2, t));
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, m, v, g, n, lr, b1, b2, eps, c1, c2, gscale);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, stream, p, m, v, g, n, (float)lr, (float)b1,
+                     (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, c1, c2, (float)gscale);
 }
 
 }  // namespace nrf

@@ -78,7 +78,7 @@ def load_library(path=None):
         f'HIP extension not built: {path} is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
         '(needs hipcc). There is no CPU fallback for the hot path.')
   lib = C.CDLL(path)
-  vp, i32, i64, u32, u64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float
+  vp, i32, i64, u32, u64, f32, f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
   lib.nrf_version.restype = C.c_int
   lib.nrf_last_error.restype = C.c_char_p
   sigs = {
@@ -92,7 +92,7 @@ def load_library(path=None):
       'nrf_backward': [vp, vp, C.POINTER(Rays), vp, vp, vp, vp, C.c_size_t, vp],
       'nrf_train_step_loss_grad': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand), vp, vp, vp,
                                    C.c_size_t, vp],
-      'nrf_adam_step': [vp, vp, vp, vp, i64, f32, f32, f32, f32, i64, f32, vp],
+      'nrf_adam_step': [vp, vp, vp, vp, i64, f64, f64, f64, f64, i64, f64, vp],
       'nrf_sample_along_rays': [vp, vp, i32, i32, f32, f32, i32, i32, vp, u64, u64, vp, vp],
       'nrf_volumetric_rendering': [vp, vp, vp, i32, i32, i32, i32, C.POINTER(LevelOut), vp],
       'nrf_sample_pdf': [vp, vp, i32, i32, i32, i32, vp, u64, u64, vp, vp],

@@ -232,7 +232,7 @@ class NerfModel:
   # ---- NerfModel.__call__ (models.py:289-375) ---------------------------------------------
   def apply(self, variables, rays_dict: Dict[str, Any], warp_extra: Dict[str, Any] = None, metadata_encoded=False,
             use_warp=True, return_points=False, return_weights=False, return_warp_jacobian=False,
-            deterministic=False, rngs=None, *, train=False):
+            deterministic=False, rngs=None, *, train=False, return_z_vals=False):
     """Returns {'coarse': {...}, 'fine': {...}} like the reference.  `train=True` keeps the
     activation stash so `backward` can follow (used by training.train_step / autograd)."""
     del deterministic   # accepted and unused, as in the reference (models.py:298)
@@ -257,6 +257,8 @@ class NerfModel:
            'med_depth': torch.empty(B, device=device), 'acc': torch.empty(B, device=device)}
       if return_weights:
         d['weights'] = torch.empty(B, s, device=device)
+      if return_z_vals:   # extra (not in the reference dict): the sample depths of this level
+        d['z_vals'] = torch.empty(B, s, device=device)
       for k, t in d.items():
         setattr(lo, k, _ptr(t))
       ret[name] = d

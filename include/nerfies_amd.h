@@ -185,6 +185,21 @@ int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t 
                   double lr, double beta1, double beta2, double eps, int64_t step,
                   double grad_scale, void* stream);
 
+/* ---- measurement: per-kernel wall time from HIP events recorded on the launch stream ----
+ * (the reference only has utils.TimeTracker host timers, utils.py:418-465, around an
+ * asynchronously dispatched step; these are device-side).  Off by default; when on, entry points
+ * are no longer hipGraph-capturable. */
+typedef struct nrf_profile_entry {
+  char name[32];           /* e.g. "mlp_fwd_fine", "wgrad" */
+  double ms;               /* accumulated since the last read */
+  int32_t launches;
+  int32_t pad_;
+  double flops_per_launch; /* ALGORITHMIC flops (2/MAC, dense layers, unpadded) */
+} nrf_profile_entry;
+int nrf_profile_enable(nrf_handle h, int32_t on);
+/* Waits for the recorded events, returns and resets the accumulators.  out may be NULL to query *n. */
+int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n);
+
 /* ---- individual operators (same device code the fused path runs), exposed so
  * parity tests can check each reference function in isolation. ---- */
 

@@ -51,41 +51,82 @@ __device__ __forceinline__ int act_addr(int k, int i) { return k * TILE_ROWS + 4
 //   wp     : this wave's packed weights, [it][lane] float4.
 //   NCB=2  : it covers 4 k  (float4 = {ks0 cb0, ks0 cb1, ks1 cb0, ks1 cb1}), nit = K/4
 //   NCB=1  : it covers 8 k  (float4 = ks0..ks3),                               nit = K/8
-template <int NCB, bool SWZ>
-__device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[4][NCB], const float* lds_in, int nit,
-                                            const float4* __restrict__ wp, int lane) {
-  const int i = lane & 31, kk = lane >> 5;
-  constexpr int KS = (NCB == 2) ? 2 : 4;   // k-steps (of 2 k) per iteration
-  auto lda = [&](int it, int s) -> float4 {
-    const int k = it * (2 * KS) + 2 * s + kk;
-    const int a = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
-    return *reinterpret_cast<const float4*>(lds_in + a);
-  };
-  float4 b_n = wp[lane];
-  float4 a_n[KS];
+template <int NCB, int KS>
+__device__ __forceinline__ void mfma_block(f32x16 (&acc)[4][NCB], const float4 (&a)[KS], const float4& b) {
+  const float bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-  for (int s = 0; s < KS; ++s) a_n[s] = lda(0, s);
-  for (int it = 0; it < nit; ++it) {
-    const float4 b = b_n;
-    float4 a[KS];
+  for (int s = 0; s < KS; ++s) {
+    const float av[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a[s] = a_n[s];
-    const int itn = (it + 1 < nit) ? it + 1 : it;
-    b_n = wp[itn * 64 + lane];
+    for (int rb = 0; rb < 4; ++rb) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a_n[s] = lda(itn, s);
-    const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float av[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
-#pragma unroll
-      for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-          acc[rb][cb] = mfma32(av[rb], bv[(NCB == 2) ? (2 * s + cb) : s], acc[rb][cb]);
-        }
+      for (int cb = 0; cb < NCB; ++cb) {
+        acc[rb][cb] = mfma32(av[rb], bv[(NCB == 2) ? (2 * s + cb) : s], acc[rb][cb]);
       }
     }
+  }
+}
+
+// Software pipeline, pinned with sched_barrier so the compiler cannot sink the loads back to their
+// uses: weights (L2, ~1-2k cycles under load) are fetched a PAIR of iterations (2048 MFMA cycles)
+// ahead, the LDS A operands one iteration (1024 cycles) ahead.
+// First weight pair of a layer.  Issued BEFORE the previous layer's epilogue so that these loads sit
+// ahead of the epilogue's stash stores in the in-order vmcnt queue (gfx9 counts stores in vmcnt).
+struct WPair { float4 b0, b1; };
+__device__ __forceinline__ WPair prefetch_pair(const float4* __restrict__ wp, int nit, int lane) {
+  WPair w;
+  w.b0 = wp[lane];
+  w.b1 = wp[(nit > 1 ? 1 : 0) * 64 + lane];
+  return w;
+}
+
+template <int NCB, bool SWZ>
+__device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[4][NCB], const float* lds_in, int nit,
+                                            const float4* __restrict__ wp, int lane, const WPair& first) {
+  const int i = lane & 31, kk = lane >> 5;
+  constexpr int KS = (NCB == 2) ? 2 : 4;   // k-steps (of 2 k) per iteration
+  auto lda = [&](float4 (&a)[KS], int it) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = it * (2 * KS) + 2 * s + kk;
+      const int ad = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
+      a[s] = *reinterpret_cast<const float4*>(lds_in + ad);
+    }
+  };
+  const int last = nit - 1;
+  float4 bc0 = first.b0;
+  float4 bc1 = first.b1;
+  float4 ac[KS];
+  lda(ac, 0);
+  int it = 0;
+  for (; it + 2 <= nit; it += 2) {
+    const int n0 = it + 2 < last ? it + 2 : last, n1 = it + 3 < last ? it + 3 : last;
+    const float4 bn0 = wp[n0 * 64 + lane];
+    const float4 bn1 = wp[n1 * 64 + lane];
+    float4 an[KS];
+    lda(an, it + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NCB, KS>(acc, ac, bc0);
+    __builtin_amdgcn_sched_barrier(0);
+    lda(ac, n0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block<NCB, KS>(acc, an, bc1);
+    __builtin_amdgcn_sched_barrier(0);
+    bc0 = bn0; bc1 = bn1;
+  }
+  if (it < nit) mfma_block<NCB, KS>(acc, ac, bc0);   // odd tail (K = 52: 13 iterations)
+}
+
+// acc = bias[n] broadcast down the rows: the bias add rides in the MFMA accumulator for free.
+template <int NCB>
+__device__ __forceinline__ void bias_acc(f32x16 (&acc)[4][NCB], const float* __restrict__ bias, int ncol0, int lane) {
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) {
+    const float bv = bias[ncol0 + 32 * cb + (lane & 31)];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = bv;
   }
 }
 
@@ -127,7 +168,7 @@ __device__ __forceinline__ uint32_t sign_nibble(const float4& v) {
 // bits_wave: this (layer, tile, wave)'s mask words, [lane][2*NCB] dwords; dword = cb*2 + reg/8,
 // nibble = reg%8, bit = row block.
 template <int NCB, bool RELU, bool STASH>
-__device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[4][NCB], const float* __restrict__ bias,
+__device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[4][NCB],
                                              int ncol0, float* act, __amdgpu_buffer_rsrc_t stash, int stash_soff,
                                              uint32_t* bits_wave, int lane) {
   const int j = lane & 31;
@@ -137,13 +178,10 @@ __device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[4][NCB], const float*
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = ncol0 + 32 * cb + j;
-    const float bv = bias[n];
     mb[2 * cb] = mb[2 * cb + 1] = 0u;
 #pragma unroll
     for (int reg = 0; reg < 16; ++reg) {
-      float4 v;
-      v.x = acc[0][cb][reg] + bv; v.y = acc[1][cb][reg] + bv;
-      v.z = acc[2][cb][reg] + bv; v.w = acc[3][cb][reg] + bv;
+      float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
       if (RELU) {
         if (STASH) mb[2 * cb + (reg >> 3)] |= sign_nibble(v) << (4 * (reg & 7));
         v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w);
@@ -225,18 +263,25 @@ __global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A)
     const int wv_soff = wave * 2 * 16 * 1024;                          // bytes: this wave's slice of a tile
 
     // ---- trunk: 8 x Dense(256)+ReLU, skip concat [h, posenc] at layer 4 (modules.py:41-50) ----
+    const float4* wL0 = wpk4 + (A.pk.fwd_L[0] / 4) + wave * (PK / 4) * 64;
+    WPair wnext = prefetch_pair(wL0, PK / 4, lane);
 #pragma unroll 1
     for (int l = 0; l < TRUNK_DEPTH; ++l) {
-      zero_acc<2>(acc);
+      bias_acc<2>(acc, prm + A.po.trunk_b[l], wave * 64, lane);
       if (l == 0) {
-        mfma_k_loop<2, false>(acc, pe, PK / 4, wpk4 + (A.pk.fwd_L[0] / 4) + wave * (PK / 4) * 64, lane);
+        mfma_k_loop<2, false>(acc, pe, PK / 4, wL0, lane, wnext);
       } else {
-        mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane);
-        if (l == SKIP_LAYER)
-          mfma_k_loop<2, false>(acc, pe, PK / 4, wpk4 + (A.pk.fwd_L4b / 4) + wave * (PK / 4) * 64, lane);
+        mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane, wnext);
+        if (l == SKIP_LAYER) {
+          const float4* w4b = wpk4 + (A.pk.fwd_L4b / 4) + wave * (PK / 4) * 64;
+          mfma_k_loop<2, false>(acc, pe, PK / 4, w4b, lane, prefetch_pair(w4b, PK / 4, lane));
+        }
       }
+      // the next layer's first weights go out before this layer's stash stores
+      wnext = prefetch_pair(wpk4 + ((l + 1 < TRUNK_DEPTH ? A.pk.fwd_L[l + 1] : A.pk.fwd_bn) / 4) + wave * 64 * 64, 64, lane);
+      __builtin_amdgcn_sched_barrier(0);
       fwd_epilogue<2, true, STASH>(
-          acc, prm + A.po.trunk_b[l], wave * 64, act,
+          acc, wave * 64, act,
           make_rsrc(STASH ? A.st_h + l * st_h_layer + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff,
           STASH ? A.bits_trunk + (((size_t)l * A.ntiles + tile) * 4 + wave) * 256 : nullptr, lane);
     }
@@ -255,10 +300,13 @@ __global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A)
     }
 
     // ---- bottleneck: Dense(256), no activation (modules.py:149-150) ----
-    zero_acc<2>(acc);
-    mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_bn / 4) + wave * 64 * 64, lane);
+    bias_acc<2>(acc, prm + A.po.bn_b, wave * 64, lane);
+    mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_bn / 4) + wave * 64 * 64, lane, wnext);
+    const float4* wrgb = wpk4 + (A.pk.fwd_rgbh / 4) + wave * 32 * 64;
+    wnext = prefetch_pair(wrgb, 32, lane);
+    __builtin_amdgcn_sched_barrier(0);
     fwd_epilogue<2, false, STASH>(
-        acc, prm + A.po.bn_b, wave * 64, act,
+        acc, wave * 64, act,
         make_rsrc(STASH ? A.st_bn + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff, nullptr, lane);
 
     // ---- rgb branch hidden: Dense(256+R -> 128)+ReLU; the R per-ray condition columns are
@@ -266,7 +314,7 @@ __global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A)
     {
       f32x16 acc1[4][1];
       zero_acc<1>(acc1);
-      mfma_k_loop<1, true>(acc1, act, 32, wpk4 + (A.pk.fwd_rgbh / 4) + wave * 32 * 64, lane);
+      mfma_k_loop<1, true>(acc1, act, 32, wrgb, lane, wnext);
       const int n = wave * 32 + j;
       const __amdgpu_buffer_rsrc_t st = make_rsrc(STASH ? A.st_rgbh + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4);
       const EpiAddr ea(lane);
@@ -429,7 +477,12 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
     f32x16 acc[4][2];
     // ---- d bottleneck = dpre_rgbh . W_rgbh[0:256]^T   (K=128 -> N=256), linear ----
     zero_acc<2>(acc);
-    mfma_k_loop<2, true>(acc, act, 32, wpk4 + (A.pk.bwd_rgbhT / 4) + wave * 32 * 64, lane);
+    {
+      const float4* w0 = wpk4 + (A.pk.bwd_rgbhT / 4) + wave * 32 * 64;
+      mfma_k_loop<2, true>(acc, act, 32, w0, lane, prefetch_pair(w0, 32, lane));
+    }
+    WPair wnext = prefetch_pair(wpk4 + (A.pk.bwd_bnT / 4) + wave * 64 * 64, 64, lane);
+    __builtin_amdgcn_sched_barrier(0);
     {
       const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy_bn + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
       __syncthreads();
@@ -458,7 +511,9 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
       const uint32_t mb[4] = {mq.x, mq.y, mq.z, mq.w};
       zero_acc<2>(acc);
       const int woff = (l == TRUNK_DEPTH) ? A.pk.bwd_bnT : A.pk.bwd_LT[l];
-      mfma_k_loop<2, true>(acc, act, 64, wpk4 + (woff / 4) + wave * 64 * 64, lane);
+      mfma_k_loop<2, true>(acc, act, 64, wpk4 + (woff / 4) + wave * 64 * 64, lane, wnext);
+      wnext = prefetch_pair(wpk4 + (A.pk.bwd_LT[l > 1 ? l - 1 : 1] / 4) + wave * 64 * 64, 64, lane);
+      __builtin_amdgcn_sched_barrier(0);
       const __amdgpu_buffer_rsrc_t dy =
           make_rsrc(A.dy_trunk + (size_t)(l - 1) * layer_fl + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
       __syncthreads();

@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -41,7 +42,10 @@ struct WsPlan {
   uint32_t flags = 0;
   int S[2], rows[2], ntiles[2];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
-  size_t pack_off_b, groups_off_b, reduce_off_b;
+  size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b;
+  std::vector<WgradSegment> segs;
+  std::vector<int> seg_begin;
+  int wgrad_nwg = 0;
   size_t cond, mse, zero_rgb, slabs;
   LevelWs L[2];
   size_t total_floats;
@@ -53,7 +57,44 @@ struct WsPlan {
 
 }  // namespace
 
+namespace {
+struct ProfSlot { std::string name; double flops; hipEvent_t a = nullptr, b = nullptr; bool used = false; };
+struct ProfAcc { std::string name; double ms = 0; int launches = 0; double flops = 0; };
+struct Prof {
+  bool on = false;
+  std::vector<ProfSlot> slots;   // events recorded and not yet read
+  size_t next = 0;
+  std::vector<ProfAcc> acc;
+  void begin(const char* name, double flops, hipStream_t st) {
+    if (!on) return;
+    if (next == slots.size()) { slots.emplace_back(); (void)hipEventCreate(&slots.back().a); (void)hipEventCreate(&slots.back().b); }
+    ProfSlot& s = slots[next];
+    s.name = name; s.flops = flops; s.used = true;
+    (void)hipEventRecord(s.a, st);
+  }
+  void end(hipStream_t st) {
+    if (!on) return;
+    (void)hipEventRecord(slots[next].b, st);
+    ++next;
+  }
+  void drain() {
+    for (size_t i = 0; i < next; ++i) {
+      ProfSlot& s = slots[i];
+      (void)hipEventSynchronize(s.b);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, s.a, s.b);
+      ProfAcc* a = nullptr;
+      for (auto& x : acc) if (x.name == s.name) a = &x;
+      if (!a) { acc.emplace_back(); a = &acc.back(); a->name = s.name; }
+      a->ms += ms; a->launches += 1; a->flops = s.flops;
+    }
+    next = 0;
+  }
+};
+}  // namespace
+
 struct nrf_handle_s {
+  Prof prof;
   nrf_model_desc d;
   std::vector<nrf_tensor_info> layout;
   int64_t nparams = 0;
@@ -148,7 +189,6 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
   const int G = h->num_cus;
 
   // ---- wgrad groups (training) ----
-  const int target_tasks = 3 * G;
   struct GroupSpec { int lv; int xk; size_t* xoff; int xstride; int kvalid; int Kb; int yk; size_t* yoff; int ystride; int Nb;
                      int vec; int64_t dst; int dst_ld; int rows; int cols; int units; size_t xadd, yadd; };
   std::vector<GroupSpec> specs;
@@ -185,29 +225,63 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
   // ---- float layout ----
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, ALIGN_F); return r; };
-  // tables region (bytes -> floats)
-  size_t total_units = 0;
-  for (auto& s : specs) total_units += (size_t)s.units * p.ntiles[s.lv];
-  const size_t units_per_task = specs.empty() ? 1 : (total_units + target_tasks - 1) / target_tasks;
-  std::vector<int> nsplit(specs.size());
-  int ntasks = 0;
-  for (size_t i = 0; i < specs.size(); ++i) {
-    const size_t u = (size_t)specs[i].units * p.ntiles[specs[i].lv];
-    int ns = (int)((u + units_per_task - 1) / units_per_task);
-    if (ns < 1) ns = 1;
-    if (ns > p.ntiles[specs[i].lv]) ns = p.ntiles[specs[i].lv];
-    nsplit[i] = ns;
-    ntasks += ns;
+  // ---- stream-K partition of the wgrad work: equal cost per workgroup, one workgroup per CU ----
+  // cost of one 128-row tile of a group, in units of a full 256x256 layer tile; the narrow groups
+  // are staging/latency bound, so they are charged more than their MFMA share.
+  auto env_cost = [](const char* name, double dflt) {
+    const char* e = getenv(name);
+    return e ? atof(e) : dflt;
+  };
+  const double c_vec256 = env_cost("NRF_COST_VEC256", 0.35), c_vec128 = env_cost("NRF_COST_VEC128", 0.20),
+               c_pe = env_cost("NRF_COST_PE", 0.45), c_rgbh = env_cost("NRF_COST_RGBH", 0.65);
+  auto tile_cost = [&](const GroupSpec& sp) -> double {
+    if (sp.Nb == 0) return sp.Kb == 8 ? c_vec256 : c_vec128;   // vector columns only (VALU + HBM stream)
+    const double mm = (double)sp.Kb * sp.Nb / 64.0;
+    return mm < 0.3 ? c_pe : (mm < 0.6 ? c_rgbh : 1.0);
+  };
+  std::vector<int> nsplit(specs.size(), 0);
+  if (!specs.empty()) {
+    double total = 0;
+    for (auto& sp : specs) total += tile_cost(sp) * p.ntiles[sp.lv];
+    const int nwg = G;
+    const double quota = total / nwg;
+    p.seg_begin.assign(1, 0);
+    int w = 0;
+    double room = quota;
+    for (size_t gi = 0; gi < specs.size(); ++gi) {
+      const double c = tile_cost(specs[gi]);
+      int t0 = 0;
+      const int nt = p.ntiles[specs[gi].lv];
+      while (t0 < nt) {
+        int take_n = (int)floor(room / c + 1e-9);
+        if (take_n <= 0 && w < nwg - 1) {            // this workgroup is full: move on
+          p.seg_begin.push_back((int)p.segs.size());
+          ++w; room += quota;
+          continue;
+        }
+        if (take_n <= 0) take_n = nt - t0;           // last workgroup absorbs rounding leftovers
+        if (w == nwg - 1) take_n = nt - t0;
+        if (take_n > nt - t0) take_n = nt - t0;
+        p.segs.push_back({(int)gi, t0, t0 + take_n, nsplit[gi]});
+        nsplit[gi] += 1;
+        t0 += take_n;
+        room -= take_n * c;
+      }
+    }
+    while ((int)p.seg_begin.size() < nwg + 1) p.seg_begin.push_back((int)p.segs.size());
+    p.wgrad_nwg = nwg;
   }
-  p.ntasks = ntasks;
+  p.ntasks = (int)p.segs.size();
   const int npack = 2 * 21;
   const int nreduce_max = 2 * 40;
-  const size_t table_bytes = align_up(npack * sizeof(PackDesc), 256) + align_up(specs.size() * sizeof(WgradGroup) + 256, 256) +
-                             align_up(nreduce_max * sizeof(ReduceDesc), 256);
-  p.tables = take(table_bytes / 4);
+  // tables region (bytes -> floats)
   p.pack_off_b = 0;
   p.groups_off_b = align_up(npack * sizeof(PackDesc), 256);
   p.reduce_off_b = p.groups_off_b + align_up(specs.size() * sizeof(WgradGroup) + 256, 256);
+  p.segs_off_b = p.reduce_off_b + align_up(nreduce_max * sizeof(ReduceDesc), 256);
+  p.segbegin_off_b = p.segs_off_b + align_up(p.segs.size() * sizeof(WgradSegment) + 256, 256);
+  const size_t table_bytes = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
+  p.tables = take(table_bytes / 4);
 
   p.cond = take((size_t)B * (h->R > 0 ? h->R : 1));
   p.mse = take(64);
@@ -275,7 +349,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       g.dy_kind = s.yk; g.dy_tile_stride = s.ystride; g.Nb = s.Nb;
       g.ntiles = p.ntiles[s.lv];
       g.nsplit = nsplit[i];
-      g.tiles_per = (g.ntiles + g.nsplit - 1) / g.nsplit;
+      g.tiles_per = 0;
       g.first_task = first;
       first += g.nsplit;
       ReduceDesc r;
@@ -336,6 +410,12 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
   if (!p.groups.empty()) {
     e = hipMemcpyAsync(base + p.groups_off_b, p.groups.data(), p.groups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload wgrad table");
+  }
+  if (!p.segs.empty()) {
+    e = hipMemcpyAsync(base + p.segs_off_b, p.segs.data(), p.segs.size() * sizeof(WgradSegment), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload wgrad segments");
+    e = hipMemcpyAsync(base + p.segbegin_off_b, p.seg_begin.data(), p.seg_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload wgrad segment index");
   }
   if (!p.reduce.empty()) {
     e = hipMemcpyAsync(base + p.reduce_off_b, p.reduce.data(), p.reduce.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, stream);
@@ -400,6 +480,17 @@ int copy_out(float* dst, const float* src, size_t n, hipStream_t stream) {
   return e == hipSuccess ? NRF_OK : fail_hip(e, "copy output");
 }
 
+// algorithmic flops per MLP row (2 flop / MAC, dense layers only, unpadded)
+double fwd_flops_row(nrf_handle h) {
+  const double P = h->P, R = h->R;
+  return 2.0 * (P * 256 + 6 * 65536.0 + (256 + P) * 256 + 65536.0 + 256 + (256 + R) * 128 + 128 * 3);
+}
+double dgrad_flops_row() { return 2.0 * (128 * 3 + 256 * 128 + 65536.0 + 256 + 7 * 65536.0); }
+double wgrad_flops_row(nrf_handle h) {
+  const double P = h->P, R = h->R;
+  return 2.0 * (2 * P * 256 + 7 * 65536.0 + 65536.0 + (256 + R) * 128 + 256 + 128 * 3);
+}
+
 int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_rand* rnd, const nrf_outputs* out,
                  uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream) {
   CK(validate_rays(h, rays));
@@ -415,6 +506,8 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
 
+  Prof& pf = h->prof;
+  pf.begin("pack_prep_sample", 0, stream);
   launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
   launch_ray_prep(params, viewdirs, rays->appearance_ids, rays->camera_ids, B, d.num_nerf_viewdir_freqs, d.use_viewdirs,
@@ -424,19 +517,26 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
                   h->nlevels > 1 ? ws + p.L[1].condterm : nullptr, stream);
   launch_sample_coarse(rnd ? rnd->t_rand : nullptr, B, p.S[0], d.near_plane, d.far_plane, d.use_stratified_sampling,
                        d.use_linear_disparity, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0, ws + p.L[0].z, stream);
+  pf.end(stream);
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
     if (lv == 1) {
+      pf.begin("sample_pdf", 0, stream);
       launch_sample_fine(ws + p.L[0].z, ws + p.L[0].weights, B, d.num_coarse_samples, d.num_fine_samples,
                          d.use_stratified_sampling, rnd ? rnd->u : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0,
                          ws + L.z, stream);
+      pf.end(stream);
     }
     ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train);
     const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
     launch_chain_fwd(a, train, grid, stream);
+    pf.end(stream);
+    pf.begin("composite_fwd", 0, stream);
     launch_composite_fwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
                          d.use_white_background, d.use_sample_at_infinity, ws + L.rgb, ws + L.depth, ws + L.med,
                          ws + L.acc, ws + L.weights, stream);
+    pf.end(stream);
     if (out) {
       const nrf_level_out& lo = lv == 0 ? out->coarse : out->fine;
       CK(copy_out(lo.rgb, ws + L.rgb, (size_t)B * 3, stream));
@@ -469,10 +569,12 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     e = hipMemsetAsync(ws + L.dray, 0, (size_t)B * RGB_W * sizeof(float), stream);
     if (e != hipSuccess) return fail_hip(e, "zero dray");
     const float loss_scale = 2.0f / (3.0f * (float)B);   // d/d rgb of mean over (B,3) (training.py:172)
+    h->prof.begin("composite_bwd", 0, stream);
     launch_composite_bwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
                          d.use_white_background, d.use_sample_at_infinity, d.sigma_activation, ws + L.rgb, target,
                          target ? nullptr : d_rgb[lv], loss_scale, reinterpret_cast<float4*>(ws + L.d_raw4),
                          p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, stream);
+    h->prof.end(stream);
     ChainBwdArgs a;
     memset(&a, 0, sizeof(a));
     a.params = params; a.po = h->po[lv]; a.wpk = ws + L.wpk; a.pk = h->pk;
@@ -483,12 +585,24 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     a.dy_trunk = ws + L.dy_trunk; a.dy_bn = ws + L.dy_bn; a.dy_rgbh = ws + L.dy_rgbh; a.dray = ws + L.dray;
     a.small_part = ws + L.small_part;
     const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row() * p.rows[lv], stream);
     launch_chain_bwd(a, grid, stream);
+    h->prof.end(stream);
+    h->prof.begin("cond_wgrad", 0, stream);
     launch_cond_wgrad(ws + p.cond, ws + L.dray, B, h->R, ws + L.cond_grad, stream);
+    h->prof.end(stream);
   }
-  launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b), (int)p.groups.size(), p.ntasks, ws, stream);
+  double wg_rows = 0;
+  for (int lv = 0; lv < h->nlevels; ++lv) wg_rows += p.rows[lv];
+  h->prof.begin("wgrad", wgrad_flops_row(h) * wg_rows, stream);
+  launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b),
+               reinterpret_cast<const WgradSegment*>(tables + p.segs_off_b),
+               reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws, stream);
+  h->prof.end(stream);
+  h->prof.begin("grad_reduce", 0, stream);
   launch_reduce(reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b), (int)p.reduce.size(), ws, grad, stream);
   if (stats) launch_finish_stats(ws + p.mse, B, stats, stream);
+  h->prof.end(stream);
   return check_launch("nrf_backward");
 }
 
@@ -593,6 +707,31 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
   CK(forward_impl(h, params, rays, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes, (hipStream_t)stream));
   const float* dr[2] = {nullptr, nullptr};
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream);
+}
+
+int nrf_profile_enable(nrf_handle h, int32_t on) {
+  if (!h) return fail(NRF_E_NULL, "handle is null");
+  h->prof.drain();
+  h->prof.acc.clear();
+  h->prof.on = on != 0;
+  return NRF_OK;
+}
+
+int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n) {
+  if (!h || !n) return fail(NRF_E_NULL, "null");
+  h->prof.drain();
+  const int32_t cnt = (int32_t)h->prof.acc.size();
+  if (out) {
+    if (*n < cnt) return fail(NRF_E_SHAPE, "profile array too small");
+    for (int32_t i = 0; i < cnt; ++i) {
+      memset(&out[i], 0, sizeof(out[i]));
+      snprintf(out[i].name, sizeof(out[i].name), "%s", h->prof.acc[i].name.c_str());
+      out[i].ms = h->prof.acc[i].ms; out[i].launches = h->prof.acc[i].launches; out[i].flops_per_launch = h->prof.acc[i].flops;
+    }
+    h->prof.acc.clear();
+  }
+  *n = cnt;
+  return NRF_OK;
 }
 
 int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n, double lr, double beta1, double beta2,

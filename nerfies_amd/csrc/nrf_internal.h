@@ -99,6 +99,9 @@ struct WgradGroup {
   int ntiles, nsplit, tiles_per, first_task;
 };
 
+// Stream-K style partition of the wgrad work: workgroup w runs segments [seg_begin[w], seg_begin[w+1]).
+struct WgradSegment { int group, tile_begin, tile_end, slab_idx; };
+
 struct ReduceDesc {
   int64_t dst_off;    // floats from the flat gradient buffer
   int64_t src_off;    // floats from the workspace base
@@ -121,7 +124,8 @@ struct PackDesc {
 void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
 void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
-void launch_wgrad(const WgradGroup* d_groups, int ngroups, int ntasks, float* ws, hipStream_t stream);
+void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
+                  hipStream_t stream);
 void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
 
 void launch_ray_prep(const float* params, const float* viewdirs, const int32_t* app_ids,

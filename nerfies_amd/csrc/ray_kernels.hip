@@ -357,17 +357,33 @@ void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int N
 }
 
 // ------------------------------------------------------------------ small gradient pieces
-// dW_rgbh[256+c][n] = sum_ray cond[ray][c] * dray[ray][n]
-__global__ __launch_bounds__(128) void cond_wgrad_kernel(const float* __restrict__ cond, const float* __restrict__ dray,
-                                                         int B, int R, float* __restrict__ dst) {
-  const int c = blockIdx.x, n = threadIdx.x;
-  float acc = 0.f;
-  for (int ray = 0; ray < B; ++ray) acc = fmaf(cond[(size_t)ray * R + c], dray[(size_t)ray * RGB_W + n], acc);
-  dst[(size_t)c * RGB_W + n] = acc;
+// dW_rgbh[256+c][n] = sum_ray cond[ray][c] * dray[ray][n].  One block per condition column c:
+// 8 ray groups x 128 outputs, 4 independent accumulators per thread, LDS tree over the groups.
+__global__ __launch_bounds__(1024) void cond_wgrad_kernel(const float* __restrict__ cond, const float* __restrict__ dray,
+                                                          int B, int R, float* __restrict__ dst) {
+  __shared__ float red[8][RGB_W];
+  const int c = blockIdx.x, n = threadIdx.x & 127, g = threadIdx.x >> 7;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int ray = g;
+  for (; ray + 24 < B; ray += 32) {
+    a0 = fmaf(cond[(size_t)ray * R + c], dray[(size_t)ray * RGB_W + n], a0);
+    a1 = fmaf(cond[(size_t)(ray + 8) * R + c], dray[(size_t)(ray + 8) * RGB_W + n], a1);
+    a2 = fmaf(cond[(size_t)(ray + 16) * R + c], dray[(size_t)(ray + 16) * RGB_W + n], a2);
+    a3 = fmaf(cond[(size_t)(ray + 24) * R + c], dray[(size_t)(ray + 24) * RGB_W + n], a3);
+  }
+  for (; ray < B; ray += 8) a0 = fmaf(cond[(size_t)ray * R + c], dray[(size_t)ray * RGB_W + n], a0);
+  red[g][n] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (g == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][n];
+    dst[(size_t)c * RGB_W + n] = s;
+  }
 }
 
 void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst, hipStream_t stream) {
-  if (R > 0) hipLaunchKernelGGL(cond_wgrad_kernel, dim3(R), dim3(128), 0, stream, cond, dray, B, R, dst);
+  if (R > 0) hipLaunchKernelGGL(cond_wgrad_kernel, dim3(R), dim3(1024), 0, stream, cond, dray, B, R, dst);
 }
 
 __global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, float* __restrict__ stats) {

@@ -193,22 +193,7 @@ __device__ __forceinline__ void wgrad_vec_body(const WgradTask& T, float* smem) 
     *reinterpret_cast<float4*>(T.vslab + ((size_t)hf * T.Kb * 32 + k) * 4) = make_float4(va[0], va[1], va[2], va[3]);
 }
 
-__global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict__ groups, int ngroups,
-                                                    float* __restrict__ ws) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  int gi = 0;
-  while (gi + 1 < ngroups && (int)blockIdx.x >= groups[gi + 1].first_task) ++gi;
-  const WgradGroup G = groups[gi];
-  const int split = blockIdx.x - G.first_task;
-  WgradTask T;
-  T.X = ws + G.x_off; T.x_kind = G.x_kind; T.x_tile_stride = G.x_tile_stride; T.x_kvalid = G.x_kvalid; T.Kb = G.Kb;
-  T.dY = ws + G.dy_off; T.dy_kind = G.dy_kind; T.dy_tile_stride = G.dy_tile_stride; T.Nb = G.Nb;
-  T.tile_begin = split * G.tiles_per;
-  T.tile_end = min(T.tile_begin + G.tiles_per, G.ntiles);
-  if (T.tile_end < T.tile_begin) T.tile_end = T.tile_begin;
-  T.slab = ws + G.slab_off + (size_t)split * (G.Kb * 32) * (G.Nb * 32);
-  T.vec = G.vec_off >= 0 ? reinterpret_cast<const float4*>(ws + G.vec_off) : nullptr;
-  T.vslab = ws + G.vslab_off + (size_t)split * 2 * (G.Kb * 32) * 4;
+__device__ __forceinline__ void wgrad_run_task(const WgradTask& T, float* smem) {
   if (T.Nb == 0) { wgrad_vec_body(T, smem); return; }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // 8 waves tile the [Kb][Nb] block grid: n-groups of 2 column blocks, the rest along k.
@@ -217,17 +202,39 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict
   const int wn = wave % ngn, wk = wave / ngn;
   const int nrb = (T.Kb + ngk - 1) / ngk;   // 4, 2 or 1
   const int kb0 = wk * nrb, nb0 = 2 * wn;
-  // waves whose k-blocks fall outside Kb still take part in the staging and barriers.
-  const bool active = kb0 + nrb <= T.Kb;
-  if (nrb == 4)      { if (active) wgrad_body<4>(T, smem, kb0, nb0); else wgrad_body<4>(T, smem, 0, nb0); }
-  else if (nrb == 2) { if (active) wgrad_body<2>(T, smem, kb0, nb0); else wgrad_body<2>(T, smem, 0, nb0); }
-  else               { if (active) wgrad_body<1>(T, smem, kb0, nb0); else wgrad_body<1>(T, smem, 0, nb0); }
+  if (nrb == 4)      wgrad_body<4>(T, smem, kb0, nb0);
+  else if (nrb == 2) wgrad_body<2>(T, smem, kb0, nb0);
+  else               wgrad_body<1>(T, smem, kb0, nb0);
 }
 
-void launch_wgrad(const WgradGroup* d_groups, int ngroups, int ntasks, float* ws, hipStream_t stream) {
+// One workgroup per CU; each walks its share of the linearised (layer, tile) work (equal cost per
+// workgroup, so there is exactly one round and no tail), flushing a partial slab per segment.
+__global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict__ groups,
+                                                    const WgradSegment* __restrict__ segs,
+                                                    const int* __restrict__ seg_begin, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int s0 = seg_begin[blockIdx.x], s1 = seg_begin[blockIdx.x + 1];
+  for (int si = s0; si < s1; ++si) {
+    const WgradSegment sg = segs[si];
+    const WgradGroup G = groups[sg.group];
+    WgradTask T;
+    T.X = ws + G.x_off; T.x_kind = G.x_kind; T.x_tile_stride = G.x_tile_stride; T.x_kvalid = G.x_kvalid; T.Kb = G.Kb;
+    T.dY = ws + G.dy_off; T.dy_kind = G.dy_kind; T.dy_tile_stride = G.dy_tile_stride; T.Nb = G.Nb;
+    T.tile_begin = sg.tile_begin;
+    T.tile_end = sg.tile_end;
+    T.slab = ws + G.slab_off + (size_t)sg.slab_idx * (G.Kb * 32) * (G.Nb * 32);
+    T.vec = G.vec_off >= 0 ? reinterpret_cast<const float4*>(ws + G.vec_off) : nullptr;
+    T.vslab = ws + G.vslab_off + (size_t)sg.slab_idx * 2 * (G.Kb * 32) * 4;
+    wgrad_run_task(T, smem);
+    __syncthreads();   // the next segment restages LDS
+  }
+}
+
+void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
+                  hipStream_t stream) {
   const size_t lds = (size_t)(2 * WG_STAGE + 256) * sizeof(float);
   (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(ntasks), dim3(512), lds, stream, d_groups, ngroups, ws);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws);
 }
 
 // dst[r][c] = sum_parts src[part][r][c]

@@ -58,10 +58,15 @@ class Outputs(C.Structure):
   _fields_ = [('coarse', LevelOut), ('fine', LevelOut)]
 
 
+class ProfileEntry(C.Structure):
+  _fields_ = [('name', C.c_char * 32), ('ms', C.c_double), ('launches', C.c_int32), ('pad_', C.c_int32),
+              ('flops_per_launch', C.c_double)]
+
+
 EXPORTS = [
     'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',
     'nrf_workspace_bytes', 'nrf_forward', 'nrf_backward', 'nrf_train_step_loss_grad', 'nrf_adam_step',
-    'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf',
+    'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf', 'nrf_profile_enable', 'nrf_profile_read',
 ]
 
 _lib = None
@@ -96,6 +101,8 @@ def load_library(path=None):
       'nrf_sample_along_rays': [vp, vp, i32, i32, f32, f32, i32, i32, vp, u64, u64, vp, vp],
       'nrf_volumetric_rendering': [vp, vp, vp, i32, i32, i32, i32, C.POINTER(LevelOut), vp],
       'nrf_sample_pdf': [vp, vp, i32, i32, i32, i32, vp, u64, u64, vp, vp],
+      'nrf_profile_enable': [vp, i32],
+      'nrf_profile_read': [vp, C.POINTER(ProfileEntry), C.POINTER(i32)],
   }
   for name, argtypes in sigs.items():
     fn = getattr(lib, name)

@@ -302,6 +302,18 @@ class NerfModel:
     del keep, keep2
     return grad, stats
 
+  def profile_enable(self, on=True):
+    L.check(self.lib.nrf_profile_enable(self.handle, int(bool(on))), self.lib)
+
+  def profile_read(self):
+    """[{name, ms, launches, flops_per_launch}] accumulated since the last read (device-side HIP events)."""
+    n = C.c_int32(0)
+    L.check(self.lib.nrf_profile_read(self.handle, None, C.byref(n)), self.lib)
+    arr = (L.ProfileEntry * max(n.value, 1))()
+    L.check(self.lib.nrf_profile_read(self.handle, arr, C.byref(n)), self.lib)
+    return [dict(name=arr[i].name.decode(), ms=arr[i].ms, launches=arr[i].launches,
+                 flops_per_launch=arr[i].flops_per_launch) for i in range(n.value)]
+
   def __del__(self):
     try:
       if self._handle is not None and self._lib is not None:

@@ -67,9 +67,6 @@ __device__ __forceinline__ void mfma_block(f32x16 (&acc)[4][NCB], const float4 (
   }
 }
 
-// Software pipeline, pinned with sched_barrier so the compiler cannot sink the loads back to their
-// uses: weights (L2, ~1-2k cycles under load) are fetched a PAIR of iterations (2048 MFMA cycles)
-// ahead, the LDS A operands one iteration (1024 cycles) ahead.
 // First weight pair of a layer.  Issued BEFORE the previous layer's epilogue so that these loads sit
 // ahead of the epilogue's stash stores in the in-order vmcnt queue (gfx9 counts stores in vmcnt).
 struct WPair { float4 b0, b1; };
@@ -80,41 +77,56 @@ __device__ __forceinline__ WPair prefetch_pair(const float4* __restrict__ wp, in
   return w;
 }
 
+// Software-pipelined K loop.  One "pair" = two iterations = 32 MFMAs (2048 cycles) against
+// 2 weight loads (issued a full pair ahead; L2 latency under load is ~1-2k cycles) and 2*KS LDS
+// A-operand reads (issued >= 16 MFMAs ahead).  The swizzle pattern repeats every 8 k, i.e. every
+// pair, so the per-lane LDS offsets are loop invariant and the loop body carries no address VALU;
+// sched_group_barrier spreads the loads between the MFMAs so the matrix pipe never drains.
+// Weight loads run up to one pair past the end of the layer (the pack buffer is padded for it).
 template <int NCB, bool SWZ>
 __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[4][NCB], const float* lds_in, int nit,
                                             const float4* __restrict__ wp, int lane, const WPair& first) {
   const int i = lane & 31, kk = lane >> 5;
-  constexpr int KS = (NCB == 2) ? 2 : 4;   // k-steps (of 2 k) per iteration
-  auto lda = [&](float4 (&a)[KS], int it) {
+  constexpr int KS = (NCB == 2) ? 2 : 4;              // k-steps (of 2 k) per iteration
+  constexpr int PAIR_FLOATS = 2 * (2 * KS) * TILE_ROWS;   // LDS floats covered by one pair
+  int off[2 * KS];                                     // per-lane float offsets of the pair's reads
+#pragma unroll
+  for (int t = 0; t < 2 * KS; ++t) {
+    const int k = 2 * t + kk;
+    off[t] = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
+  }
+  const float* ap = lds_in;
+  const float4* bp = wp + lane;
+  float4 bc0 = first.b0, bc1 = first.b1;
+  float4 a0[KS], a1[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) a0[s] = *reinterpret_cast<const float4*>(ap + off[s]);
+  const int npairs = nit >> 1;
+#pragma unroll 2
+  for (int pr = 0; pr < npairs; ++pr) {
+    const float4 bn0 = bp[128];
+    const float4 bn1 = bp[192];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a1[s] = *reinterpret_cast<const float4*>(ap + off[KS + s]);
+    mfma_block<NCB, KS>(acc, a0, bc0);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) a0[s] = *reinterpret_cast<const float4*>(ap + PAIR_FLOATS + off[s]);
+    mfma_block<NCB, KS>(acc, a1, bc1);
+    // order: 2 weight loads, KS A reads, then MFMAs with the next-pair A reads threaded through
+    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // VMEM read x2
+    __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);         // DS read xKS (odd iteration)
+    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // MFMA x8
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int k = it * (2 * KS) + 2 * s + kk;
-      const int ad = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
-      a[s] = *reinterpret_cast<const float4*>(lds_in + ad);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read (next even iteration)
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);        // MFMA x4
     }
-  };
-  const int last = nit - 1;
-  float4 bc0 = first.b0;
-  float4 bc1 = first.b1;
-  float4 ac[KS];
-  lda(ac, 0);
-  int it = 0;
-  for (; it + 2 <= nit; it += 2) {
-    const int n0 = it + 2 < last ? it + 2 : last, n1 = it + 3 < last ? it + 3 : last;
-    const float4 bn0 = wp[n0 * 64 + lane];
-    const float4 bn1 = wp[n1 * 64 + lane];
-    float4 an[KS];
-    lda(an, it + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block<NCB, KS>(acc, ac, bc0);
-    __builtin_amdgcn_sched_barrier(0);
-    lda(ac, n0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block<NCB, KS>(acc, an, bc1);
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 32 - 8 - 4 * KS, 0);
     bc0 = bn0; bc1 = bn1;
+    ap += PAIR_FLOATS;
+    bp += 128;
   }
-  if (it < nit) mfma_block<NCB, KS>(acc, ac, bc0);   // odd tail (K = 52: 13 iterations)
+  if (nit & 1) mfma_block<NCB, KS>(acc, a0, bc0);   // odd tail (K = 52: 13 iterations)
 }
 
 // acc = bias[n] broadcast down the rows: the bias add rides in the MFMA accumulator for free.

@@ -168,7 +168,7 @@ void build_pack_offsets(nrf_handle h) {
   pk.bwd_bnT = take(256 * 256);
   pk.bwd_LT[0] = 0;
   for (int l = 1; l < TRUNK_DEPTH; ++l) pk.bwd_LT[l] = take(256 * 256);
-  pk.total = o;
+  pk.total = o + 2048;   // slack: the K loop prefetches one pair past a layer's last weights
 }
 
 // Lays out the workspace for B rays and (re)builds the descriptor tables.

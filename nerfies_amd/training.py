@@ -73,6 +73,19 @@ def _world():
   return 1
 
 
+def psum_gradients(grad: torch.Tensor, stats: torch.Tensor):
+  """lax.pmean(grad) / lax.pmean(stats) (training.py:266-267) over the ray shards: ONE all-reduce of
+  the flat gradient buffer (RCCL over xGMI on GPUs, gloo in the CPU tests) plus one of the 8 stats.
+  The gradient is left as the SUM -- the 1/world factor is folded into the Adam kernel
+  (`grad_scale`) -- and the stats are returned averaged.  Returns (grad, stats, world)."""
+  n = _world()
+  if n > 1:
+    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    stats = stats / n
+  return grad, stats, n
+
+
 def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[str, Any],
                scalar_params: ScalarParams, use_elastic_loss: bool = False, elastic_reduce_method: str = 'median',
                elastic_loss_type: str = 'log_svals', use_background_loss: bool = False,
@@ -89,11 +102,7 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
   opt = state.optimizer
   grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
                                     rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad)
-  n = _world()
-  if n > 1:   # lax.pmean(grad) / lax.pmean(stats) (training.py:266-267): sum here, 1/n in Adam
-    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    stats = stats / n
+  grad, stats, n = psum_gradients(grad, stats)
   opt.apply_gradient(grad, learning_rate=scalar_params.learning_rate, grad_scale=1.0 / n)
   out = {
       'coarse': {'loss/rgb': stats[0], 'loss/total': stats[0], 'metric/psnr': stats[2]},

@@ -1,0 +1,81 @@
+"""Golden fixtures (tests/golden/*.npz, written by tests/golden/make_golden.py from the fp64 oracle).
+
+CPU: the oracle still reproduces its frozen outputs (fp64 tight; fp32 within the documented slack).
+GPU: the HIP path, called through the C-ABI, reproduces the same fixtures.
+Tolerances: rgb/depth/acc 1e-3 (north star) -- asserted at 2e-4; z_vals 2e-6; gradients 1e-3 of the
+leaf's max-abs (digest comparison)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import make_golden as G  # noqa: E402
+
+from oracle import nerfies_oracle as O  # noqa: E402
+
+CASES = sorted(G.CASES)
+
+
+def _load(name):
+  return dict(np.load(os.path.join(HERE, 'golden', name + '.npz')))
+
+
+@pytest.mark.parametrize('name', CASES)
+def test_oracle_reproduces_golden_fp64(name):
+  gold, out = _load(name), G.compute(name)
+  assert set(gold) == set(out)
+  for k in gold:
+    np.testing.assert_allclose(out[k], gold[k], rtol=1e-9, atol=1e-11, err_msg=f'{name}:{k}')
+
+
+@pytest.mark.parametrize('name', ['quarterhd_det', 'warp_se3'])
+def test_oracle_fp32_close_to_golden(name):
+  """The fp32 oracle (the timed CPU baseline) stays within the parity tolerance of the fp64 fixtures."""
+  gold = _load(name)
+  spec, params, batch, t_rand, u, alpha = G.case_inputs(name)
+  f = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+  p32 = O.tree_map(f, params)
+  b32 = {k: (O.tree_map(f, v) if isinstance(v, dict) else f(v)) for k, v in batch.items()}
+  ret = O.nerf_model_apply(p32, spec, b32, alpha, t_rand=f(t_rand) if t_rand is not None else None,
+                           u=f(u) if u is not None else None)
+  for lv in ret:
+    for k in ('rgb', 'depth', 'acc'):
+      np.testing.assert_allclose(ret[lv][k].detach().numpy(), gold[f'{lv}/{k}'], atol=2e-4, err_msg=f'{name}:{lv}/{k}')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_hip_matches_golden(name):
+  import helpers as H
+  gold = _load(name)
+  spec, params, batch, t_rand, u, alpha = G.case_inputs(name)
+  model, fp = H.gpu_model(spec, params, batch['origins'].shape[0])
+  gb = H.gpu_batch(batch)
+  rngs = None
+  if t_rand is not None:
+    rngs = {'coarse': t_rand.float().to(H.DEV), 'fine': u.float().to(H.DEV)}
+  out = model.apply({'params': fp}, gb, {'alpha': alpha}, rngs=rngs, return_weights=True, return_z_vals=True)
+  for lv in out:
+    for k, tol in (('rgb', 2e-4), ('depth', 2e-4), ('acc', 2e-4), ('weights', 2e-4), ('z_vals', 2e-6)):
+      np.testing.assert_allclose(out[lv][k].cpu().numpy(), gold[f'{lv}/{k}'], atol=tol, err_msg=f'{name}:{lv}/{k}')
+    # med_depth is a selection: allow a neighbouring sample when the cumulative weight sits on 0.5
+    md, z = out[lv]['med_depth'].cpu().numpy(), gold[f'{lv}/z_vals']
+    assert all(np.abs(z[i] - md[i]).min() < 2e-6 for i in range(len(md)))
+    assert (np.abs(md - gold[f'{lv}/med_depth']) < 2e-6).mean() >= 0.8
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha}, rngs=rngs)
+  torch.cuda.synchronize()
+  assert abs(stats[4].item() - float(gold['loss'])) < 2e-5
+  tree = fp.__class__(grad, model.layout).tree
+  for path, g in O.tree_leaves_with_path(tree):
+    want = gold['grad/' + path]
+    got = G.leaf_digest(g.double().cpu())
+    scale = max(want[4], 1e-9)
+    n = g.numel()
+    assert abs(got[0] - want[0]) <= 1e-3 * scale * np.sqrt(n) + 1e-9, (name, path, 'sum', got, want)
+    assert abs(got[1] - want[1]) <= 1e-3 * max(want[1], 1e-9) + 1e-3 * scale, (name, path, 'abs-sum', got, want)
+    assert abs(got[2] - want[2]) <= 1e-3 * scale + 1e-9 and abs(got[3] - want[3]) <= 1e-3 * scale + 1e-9, (name, path)
+    assert abs(got[4] - want[4]) <= 1e-3 * scale + 1e-9, (name, path, 'max')

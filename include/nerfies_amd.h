@@ -128,6 +128,8 @@ typedef struct nrf_level_out {
   float* acc;       /* (B,)  */
   float* weights;   /* (B,S) */
   float* z_vals;    /* (B,S)  (extra: the sample depths of this level) */
+  float* points;        /* (B,S,3) sample points before the warp (return_points, models.py:250-251) */
+  float* warped_points; /* (B,S,3) after SE3Field (models.py:266-267); both need use_warp */
 } nrf_level_out;
 
 typedef struct nrf_outputs {
@@ -136,7 +138,8 @@ typedef struct nrf_outputs {
 } nrf_outputs;
 
 /* flags for nrf_forward / nrf_workspace_bytes */
-#define NRF_FLAG_TRAIN 1u /* keep the activation stash nrf_backward needs */
+#define NRF_FLAG_TRAIN 1u   /* keep the activation stash nrf_backward needs */
+#define NRF_FLAG_NO_WARP 2u /* NerfModel.__call__(use_warp=False) (models.py:296) */
 
 int nrf_version(void);
 const char* nrf_last_error(void);

@@ -1,4 +1,8 @@
-"""Builds the HIP extension in-tree (nerfies_amd/_lib/libnerfies_amd.so) for gfx950."""
+"""Builds the HIP extension in-tree (nerfies_amd/_lib/libnerfies_amd.so) for gfx950.
+
+Each translation unit is compiled to an object in parallel (objects are cached by mtime under
+nerfies_amd/_lib/obj), then linked into one shared library."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -6,8 +10,10 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
+OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libnerfies_amd.so')
-SOURCES = ['mlp_chain.hip', 'wgrad.hip', 'ray_kernels.hip', 'nrf_api.hip']
+SOURCES = ['mlp_chain.hip', 'warp_chain.hip', 'wgrad.hip', 'ray_kernels.hip', 'nrf_api.hip']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 
 def find_hipcc():
@@ -17,29 +23,54 @@ def find_hipcc():
   raise RuntimeError('hipcc not found (set HIPCC or install ROCm)')
 
 
+def _headers():
+  hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+  hs.append(os.path.join(HERE, '..', 'include', 'nerfies_amd.h'))
+  return hs
+
+
 def needs_build():
   if not os.path.exists(LIB_PATH):
     return True
   t = os.path.getmtime(LIB_PATH)
-  deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
-  deps.append(os.path.join(HERE, '..', 'include', 'nerfies_amd.h'))
+  deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + _headers()
   return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _compile(hipcc, src, verbose):
+  obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + '.o')
+  path = os.path.join(CSRC, src)
+  newest = max(os.path.getmtime(p) for p in [path] + _headers())
+  if os.path.exists(obj) and os.path.getmtime(obj) > newest:
+    return obj
+  cmd = [hipcc] + FLAGS + ['-c', path, '-o', obj]
+  if verbose:
+    print(' '.join(cmd), flush=True)
+  res = subprocess.run(cmd, capture_output=True, text=True)
+  if res.returncode != 0:
+    raise RuntimeError(f'hipcc failed on {src}:\n' + res.stderr[-4000:])
+  return obj
 
 
 def build(force=False, verbose=False):
   if not force and not needs_build():
     return LIB_PATH
-  os.makedirs(LIB_DIR, exist_ok=True)
-  cmd = [find_hipcc(), '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared']
-  cmd += [os.path.join(CSRC, s) for s in SOURCES]
-  cmd += ['-o', LIB_PATH]
+  os.makedirs(OBJ_DIR, exist_ok=True)
+  if force:
+    for f in os.listdir(OBJ_DIR):
+      os.remove(os.path.join(OBJ_DIR, f))
+  hipcc = find_hipcc()
+  with concurrent.futures.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    objs = list(ex.map(lambda s: _compile(hipcc, s, verbose), SOURCES))
+  cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB_PATH]
   if verbose:
-    print(' '.join(cmd))
+    print(' '.join(cmd), flush=True)
   res = subprocess.run(cmd, capture_output=True, text=True)
   if res.returncode != 0:
-    raise RuntimeError('hipcc failed:\n' + res.stderr[-4000:])
+    raise RuntimeError('link failed:\n' + res.stderr[-4000:])
   return LIB_PATH
 
 
 if __name__ == '__main__':
-  print(build(force=True, verbose=True))
+  import sys
+  print(build(force='--force' in sys.argv, verbose=True))

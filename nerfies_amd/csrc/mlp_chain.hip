@@ -20,194 +20,14 @@
 //   * the training stash is written straight from the accumulator registers in
 //     "fragment-native" order (coalesced 1 KiB per wave store); the dgrad pass
 //     and the wgrad GEMM read it back in the same order.
-#include "nrf_internal.h"
+#include "chain_common.h"
 
 namespace nrf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-// Stash stores go through a wave-uniform buffer descriptor: the per-register offset rides in the
-// scalar offset, so one voffset VGPR (lane*16) serves every store (no per-store 64-bit address).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ void buf_store4(const float4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  u32x4 d;
-  d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
-}
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// LDS address (in floats) of granule (k, i): 4 consecutive tile rows 4i..4i+3 of feature k.
-__device__ __forceinline__ int act_addr(int k, int i) { return k * TILE_ROWS + 4 * (i ^ (k & 7)); }
-
-// acc[rb][cb] += A[128 x K] * B[K x 64(32)] for this wave.
-//   lds_in : feature-major tile, pitch 128 floats; SWZ selects the swizzled act layout.
-//   wp     : this wave's packed weights, [it][lane] float4.
-//   NCB=2  : it covers 4 k  (float4 = {ks0 cb0, ks0 cb1, ks1 cb0, ks1 cb1}), nit = K/4
-//   NCB=1  : it covers 8 k  (float4 = ks0..ks3),                               nit = K/8
-template <int NCB, int KS>
-__device__ __forceinline__ void mfma_block(f32x16 (&acc)[4][NCB], const float4 (&a)[KS], const float4& b) {
-  const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const float av[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        acc[rb][cb] = mfma32(av[rb], bv[(NCB == 2) ? (2 * s + cb) : s], acc[rb][cb]);
-      }
-    }
-  }
-}
-
-// First weight pair of a layer.  Issued BEFORE the previous layer's epilogue so that these loads sit
-// ahead of the epilogue's stash stores in the in-order vmcnt queue (gfx9 counts stores in vmcnt).
-struct WPair { float4 b0, b1; };
-__device__ __forceinline__ WPair prefetch_pair(const float4* __restrict__ wp, int nit, int lane) {
-  WPair w;
-  w.b0 = wp[lane];
-  w.b1 = wp[(nit > 1 ? 1 : 0) * 64 + lane];
-  return w;
-}
-
-// Software-pipelined K loop.  One "pair" = two iterations = 32 MFMAs (2048 cycles) against
-// 2 weight loads (issued a full pair ahead; L2 latency under load is ~1-2k cycles) and 2*KS LDS
-// A-operand reads (issued >= 16 MFMAs ahead).  The swizzle pattern repeats every 8 k, i.e. every
-// pair, so the per-lane LDS offsets are loop invariant and the loop body carries no address VALU;
-// sched_group_barrier spreads the loads between the MFMAs so the matrix pipe never drains.
-// Weight loads run up to one pair past the end of the layer (the pack buffer is padded for it).
-template <int NCB, bool SWZ>
-__device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[4][NCB], const float* lds_in, int nit,
-                                            const float4* __restrict__ wp, int lane, const WPair& first) {
-  const int i = lane & 31, kk = lane >> 5;
-  constexpr int KS = (NCB == 2) ? 2 : 4;              // k-steps (of 2 k) per iteration
-  constexpr int PAIR_FLOATS = 2 * (2 * KS) * TILE_ROWS;   // LDS floats covered by one pair
-  int off[2 * KS];                                     // per-lane float offsets of the pair's reads
-#pragma unroll
-  for (int t = 0; t < 2 * KS; ++t) {
-    const int k = 2 * t + kk;
-    off[t] = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
-  }
-  const float* ap = lds_in;
-  const float4* bp = wp + lane;
-  float4 bc0 = first.b0, bc1 = first.b1;
-  float4 a0[KS], a1[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) a0[s] = *reinterpret_cast<const float4*>(ap + off[s]);
-  const int npairs = nit >> 1;
-#pragma unroll 2
-  for (int pr = 0; pr < npairs; ++pr) {
-    const float4 bn0 = bp[128];
-    const float4 bn1 = bp[192];
-#pragma unroll
-    for (int s = 0; s < KS; ++s) a1[s] = *reinterpret_cast<const float4*>(ap + off[KS + s]);
-    mfma_block<NCB, KS>(acc, a0, bc0);
-#pragma unroll
-    for (int s = 0; s < KS; ++s) a0[s] = *reinterpret_cast<const float4*>(ap + PAIR_FLOATS + off[s]);
-    mfma_block<NCB, KS>(acc, a1, bc1);
-    // order: 2 weight loads, KS A reads, then MFMAs with the next-pair A reads threaded through
-    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // VMEM read x2
-    __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);         // DS read xKS (odd iteration)
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // MFMA x8
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read (next even iteration)
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);        // MFMA x4
-    }
-    __builtin_amdgcn_sched_group_barrier(0x008, 32 - 8 - 4 * KS, 0);
-    bc0 = bn0; bc1 = bn1;
-    ap += PAIR_FLOATS;
-    bp += 128;
-  }
-  if (nit & 1) mfma_block<NCB, KS>(acc, a0, bc0);   // odd tail (K = 52: 13 iterations)
-}
-
-// acc = bias[n] broadcast down the rows: the bias add rides in the MFMA accumulator for free.
-template <int NCB>
-__device__ __forceinline__ void bias_acc(f32x16 (&acc)[4][NCB], const float* __restrict__ bias, int ncol0, int lane) {
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) {
-    const float bv = bias[ncol0 + 32 * cb + (lane & 31)];
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = bv;
-  }
-}
-
-template <int NCB>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4][NCB]) {
-#pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
-}
-
-// row-in-block index of accumulator register `reg` for lane half h (C/D layout of 32x32 MFMA)
-__device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-// Epilogue-side form of act_addr(n, c_row(reg, h)): the swizzle only touches the low 3 bits of the
-// granule index, so 4 per-lane offsets (one per reg&3) plus an immediate cover all 16 registers.
-struct EpiAddr {
-  int sw[4];
-  __device__ __forceinline__ EpiAddr(int lane) {
-    const int jx = lane & 7, h = lane >> 5;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sw[q] = 4 * ((q + 4 * h) ^ jx);
-  }
-  __device__ __forceinline__ int operator()(int n, int reg) const { return n * TILE_ROWS + sw[reg & 3] + 32 * (reg >> 2); }
-};
-
-__device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-// sign bits of one float4 (4 row blocks of one accumulator register) -> 4-bit nibble
-__device__ __forceinline__ uint32_t sign_nibble(const float4& v) {
-  return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
-}
-
-// bits_wave: this (layer, tile, wave)'s mask words, [lane][2*NCB] dwords; dword = cb*2 + reg/8,
-// nibble = reg%8, bit = row block.
-template <int NCB, bool RELU, bool STASH>
-__device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[4][NCB],
-                                             int ncol0, float* act, __amdgpu_buffer_rsrc_t stash, int stash_soff,
-                                             uint32_t* bits_wave, int lane) {
-  const int j = lane & 31;
-  const EpiAddr ea(lane);
-  __syncthreads();   // every wave has finished reading the previous activations
-  uint32_t mb[2 * NCB];
-#pragma unroll
-  for (int cb = 0; cb < NCB; ++cb) {
-    const int n = ncol0 + 32 * cb + j;
-    mb[2 * cb] = mb[2 * cb + 1] = 0u;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
-      if (RELU) {
-        if (STASH) mb[2 * cb + (reg >> 3)] |= sign_nibble(v) << (4 * (reg & 7));
-        v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w);
-      }
-      *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
-      if (STASH) buf_store4(v, stash, lane * 16, stash_soff + (cb * 16 + reg) * 1024);
-    }
-  }
-  if (STASH && RELU) {
-#pragma unroll
-    for (int q = 0; q < 2 * NCB; ++q) bits_wave[lane * (2 * NCB) + q] = mb[q];
-  }
-  __syncthreads();
-}
 
 __device__ __forceinline__ float sigma_activation(float x, int kind) {
   if (kind == 1) {  // softplus, computed as jax.nn.softplus = logaddexp(x, 0)
@@ -401,10 +221,6 @@ void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t s
 // small_part layout (floats): db_trunk[8][256] | db_bn[256] | db_rgbh[128] | db_logit[3] | db_alpha
 constexpr int SP_DB_TRUNK = 0, SP_DB_BN = 2048, SP_DB_RGBH = 2304, SP_DB_LOGIT = 2432, SP_DB_ALPHA = 2435;
 
-__device__ __forceinline__ float4 mask4(const float4& v, uint32_t nib) {
-  return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
-}
-
 __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* act = smem;                 // [256][128] swizzled: current dpre tile
@@ -555,6 +371,64 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
       for (int q = 0; q < TRUNK_DEPTH; ++q)
         if (q == l - 1) { db_trunk[q][0] += bs[0]; db_trunk[q][1] += bs[1]; }
       __syncthreads();
+
+      // ---- warp on: d posenc = dpre_4 . W4[256:]^T + dpre_0 . W0^T  (256 -> PK columns).  Wave w owns
+      //      MFMA row block w (tile rows 4i + w) for all 64 columns; the result goes to the dpe tile in
+      //      LDS (aliases dr, dead since the l = 8 step), element (n, row) at n*128 + (row ^ (n & 31)). ----
+      if (A.d_points && (l - 1 == SKIP_LAYER || l == 1)) {
+        float* dpe = dr;
+        const bool first = (l - 1 == SKIP_LAYER);
+        const float4* wq = wpk4 + ((first ? A.pk.bwd_L4bT : A.pk.bwd_L0T) / 4) + lane;
+        f32x16 a2[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a2[0][r] = 0.f; a2[1][r] = 0.f; }
+        const int i = lane & 31, kk = lane >> 5;
+#pragma unroll 4
+        for (int it = 0; it < 64; ++it) {
+          const float4 b = wq[it * 64];
+          const int k0 = 4 * it + kk;
+          const float4 q0 = *reinterpret_cast<const float4*>(act + act_addr(k0, i));
+          const float4 q1 = *reinterpret_cast<const float4*>(act + act_addr(k0 + 2, i));
+          const float a0 = wave == 0 ? q0.x : wave == 1 ? q0.y : wave == 2 ? q0.z : q0.w;
+          const float a1 = wave == 0 ? q1.x : wave == 1 ? q1.y : wave == 2 ? q1.z : q1.w;
+          a2[0] = mfma32(a0, b.x, a2[0]); a2[1] = mfma32(a0, b.y, a2[1]);
+          a2[0] = mfma32(a1, b.z, a2[0]); a2[1] = mfma32(a1, b.w, a2[1]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+          const int n = 32 * cb + j;
+          if (n < A.PK) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int row = 4 * c_row(reg, h) + wave;
+              float* o = dpe + n * TILE_ROWS + (row ^ (n & 31));
+              *o = first ? a2[cb][reg] : *o + a2[cb][reg];
+            }
+          }
+        }
+        __syncthreads();
+        if (!first && tid < TILE_ROWS) {
+          // chain rule through SinusoidalEncoder: d sin(f x) = f cos(f x), d sin(f x + pi/2) = -f sin(f x),
+          // with sin / cos taken from the forward posenc stash.
+          const int row = tile * TILE_ROWS + tid;
+          const float* pe = A.st_pe + (size_t)tile * A.PK * TILE_ROWS + tid;
+          float dx[3];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) dx[c] = dpe[c * TILE_ROWS + (tid ^ c)];
+          for (int f = 0; f < A.F; ++f) {
+            const float fr = (float)(1 << f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              const int ns = 3 + 6 * f + c, nc = ns + 3;
+              const float sn = pe[ns * TILE_ROWS], cs = pe[nc * TILE_ROWS];
+              dx[c] += fr * (cs * dpe[ns * TILE_ROWS + (tid ^ (ns & 31))] - sn * dpe[nc * TILE_ROWS + (tid ^ (nc & 31))]);
+            }
+          }
+          float* o = A.d_points + (size_t)row * 3;
+          o[0] = dx[0]; o[1] = dx[1]; o[2] = dx[2];
+        }
+        if (!first) __syncthreads();   // dr (aliased) is rewritten by the next tile
+      }
     }
   }
 
@@ -590,7 +464,7 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
 }
 
 void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)(ACT_FLOATS + 4 * TILE_ROWS) * sizeof(float);
+  const size_t lds = (size_t)(ACT_FLOATS + (a.d_points ? a.PK : 4) * TILE_ROWS) * sizeof(float);
   (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(256), lds, stream, a);
 }
@@ -603,7 +477,8 @@ __global__ void pack_weights_kernel(const PackDesc* __restrict__ descs, const fl
   const PackDesc d = descs[blockIdx.y];
   const float* __restrict__ src = params + d.src_off;
   float* __restrict__ dst = ws + d.dst_off;
-  const int total = d.K * (d.ncb == 2 ? 256 : 128);
+  const int ncols_wave = d.ncb == 2 ? 64 : 32;
+  const int total = d.K * ncols_wave * d.nwaves;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int e = idx & 3, lane = (idx >> 2) & 63;
     const int per_it = 256;                       // floats per (wave, it)
@@ -613,7 +488,8 @@ __global__ void pack_weights_kernel(const PackDesc* __restrict__ descs, const fl
     if (d.ncb == 2) { k = 4 * it + 2 * (e >> 1) + (lane >> 5); n = 64 * w + 32 * (e & 1) + (lane & 31); }
     else            { k = 8 * it + 2 * e + (lane >> 5);        n = 32 * w + (lane & 31); }
     float v = 0.f;
-    if (k < d.kvalid) v = d.transposed ? src[(size_t)n * d.src_ld + k] : src[(size_t)(d.src_row0 + k) * d.src_ld + n];
+    if (k < d.kvalid && n < d.nvalid)
+      v = d.transposed ? src[(size_t)(d.src_row0 + n) * d.src_ld + k] : src[(size_t)(d.src_row0 + k) * d.src_ld + n];
     dst[idx] = v;
   }
 }

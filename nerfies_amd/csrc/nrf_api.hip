@@ -35,6 +35,9 @@ struct LevelWs {   // float offsets from the workspace base, per level (0 = coar
   size_t wpk, z, out4, rgb, depth, med, acc, weights, condterm;
   size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
+  // SE3 warp field (per level: the field is evaluated on the coarse and on the fine samples)
+  size_t wpoints, points_raw, d_points;
+  size_t w_st_win, w_st_h, w_st_wv, w_bits, w_dy, w_dw4, w_dv4, w_small_part;
 };
 
 struct WsPlan {
@@ -47,6 +50,8 @@ struct WsPlan {
   std::vector<int> seg_begin;
   int wgrad_nwg = 0;
   size_t cond, mse, zero_rgb, slabs;
+  size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
+  int nreduce_first = 0;   // reduce descriptors [0, nreduce_first) overwrite, the rest accumulate (2nd launch)
   LevelWs L[2];
   size_t total_floats;
   std::vector<PackDesc> pack;
@@ -100,8 +105,12 @@ struct nrf_handle_s {
   int64_t nparams = 0;
   MlpParamOffsets po[2];
   PackOffsets pk;
-  int64_t app_off = -1, cam_off = -1, warp_embed_off = -1;
+  int64_t app_off = -1, cam_off = -1;
   int P, PK, R, V, app_in_cond, nlevels;
+  bool warp = false;
+  WarpParamOffsets wpo;
+  WarpPackOffsets wpk;
+  int Fw = 0, G = 0, Win = 0, PKw = 0;
   int num_cus = 256;
   bool cu_queried = false;
   WsPlan plan;
@@ -111,6 +120,7 @@ struct nrf_handle_s {
   uint32_t uploaded_flags = 0;
   void* stashed_ws = nullptr;
   int stashed_B = -1;
+  bool stashed_warp = false;
 };
 
 namespace {
@@ -149,6 +159,20 @@ void build_layout(nrf_handle h) {
     add_leaf(h, base + "/MLP_2/logit/kernel", W, 1, &po.alpha_k);
     add_leaf(h, base + "/MLP_2/logit/bias", 1, 1, &po.alpha_b);
   }
+  if (h->warp) {   // warping.SE3Field (warping.py:202-320); flax names per SURVEY.md A.2
+    WarpParamOffsets& w = h->wpo;
+    add_leaf(h, "warp_field/metadata_encoder/embed/embedding", d.num_warp_embeddings, d.num_warp_features, &w.embed);
+    for (int i = 0; i < WARP_DEPTH; ++i) {
+      int fin = i == 0 ? h->Win : WARP_W;
+      if (i == WARP_SKIP) fin += h->Win;
+      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", fin, WARP_W, &w.trunk_k[i]);
+      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/bias", 1, WARP_W, &w.trunk_b[i]);
+    }
+    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k);
+    add_leaf(h, "warp_field/branches_w/logit/bias", 1, 3, &w.w_b);
+    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k);
+    add_leaf(h, "warp_field/branches_v/logit/bias", 1, 3, &w.v_b);
+  }
   if (d.use_appearance_metadata)
     add_leaf(h, "appearance_encoder/embed/embedding", d.num_appearance_embeddings, d.num_appearance_features, &h->app_off);
   if (d.use_camera_metadata)
@@ -168,7 +192,20 @@ void build_pack_offsets(nrf_handle h) {
   pk.bwd_bnT = take(256 * 256);
   pk.bwd_LT[0] = 0;
   for (int l = 1; l < TRUNK_DEPTH; ++l) pk.bwd_LT[l] = take(256 * 256);
+  pk.bwd_L0T = pk.bwd_L4bT = 0;
+  if (h->warp) { pk.bwd_L0T = take(256 * 64); pk.bwd_L4bT = take(256 * 64); }
   pk.total = o + 2048;   // slack: the K loop prefetches one pair past a layer's last weights
+  if (h->warp) {
+    WarpPackOffsets& w = h->wpk;
+    int ow = 0;
+    auto takew = [&](int n) { int r = ow; ow += n; return r; };
+    w.fwd_L[0] = takew(h->PKw * WARP_W);
+    for (int l = 1; l < WARP_DEPTH; ++l) w.fwd_L[l] = takew(WARP_W * WARP_W);
+    w.fwd_L4b = takew(h->PKw * WARP_W);
+    w.bwd_LT[0] = 0;
+    for (int l = 1; l < WARP_DEPTH; ++l) w.bwd_LT[l] = takew(WARP_W * WARP_W);
+    w.total = ow + 2048;
+  }
 }
 
 // Lays out the workspace for B rays and (re)builds the descriptor tables.
@@ -190,7 +227,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
 
   // ---- wgrad groups (training) ----
   struct GroupSpec { int lv; int xk; size_t* xoff; int xstride; int kvalid; int Kb; int yk; size_t* yoff; int ystride; int Nb;
-                     int vec; int64_t dst; int dst_ld; int rows; int cols; int units; size_t xadd, yadd; };
+                     int vec; int64_t dst; int dst_ld; int rows; int cols; int units; size_t xadd, yadd;
+                     size_t* vecoff = nullptr; int accumulate = 0; };
   std::vector<GroupSpec> specs;
   const int Kb_pe = (h->PK + 31) / 32;
   if (train) {
@@ -219,6 +257,32 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
                        po.alpha_k, 1, 256, 1, 12, (size_t)7 * layer, 0});
       specs.push_back({lv, SRC_FRAG128, &L.st_rgbh, FRAG_TILE_128, 128, 4, 0, nullptr, 0, 0, 3,
                        po.logit_k, 3, 128, 3, 6, 0, 0});
+      if (h->warp) {   // SE3 trunk + heads; the field is shared by both passes: level 1 accumulates
+        const WarpParamOffsets& w = h->wpo;
+        const size_t wl = (size_t)p.ntiles[lv] * FRAG_TILE_128;
+        const int Kb_in = (h->PKw + 31) / 32;
+        const int accu = lv > 0 ? 1 : 0;
+        auto push = [&](GroupSpec g) { g.accumulate = accu; specs.push_back(g); };
+        for (int l = 0; l < WARP_DEPTH; ++l) {
+          if (l == 0) {
+            push({lv, SRC_PLAIN, &L.w_st_win, h->PKw * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+                  w.trunk_k[0], WARP_W, h->Win, WARP_W, Kb_in * 4, 0, 0});
+          } else {
+            push({lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+                  w.trunk_k[l], WARP_W, WARP_W, WARP_W, 16, (size_t)(l - 1) * wl, (size_t)l * wl});
+            if (l == WARP_SKIP)
+              push({lv, SRC_PLAIN, &L.w_st_win, h->PKw * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+                    w.trunk_k[l] + (int64_t)WARP_W * WARP_W, WARP_W, h->Win, WARP_W, Kb_in * 4, 0, (size_t)l * wl});
+          }
+        }
+        GroupSpec gw = {lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, 0, nullptr, 0, 0, 3,
+                        w.w_k, 3, WARP_W, 3, 6, (size_t)(WARP_DEPTH - 1) * wl, 0};
+        gw.vecoff = &L.w_dw4;
+        push(gw);
+        GroupSpec gv = gw;
+        gv.dst = w.v_k; gv.vecoff = &L.w_dv4;
+        push(gv);
+      }
     }
   }
 
@@ -272,8 +336,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
     p.wgrad_nwg = nwg;
   }
   p.ntasks = (int)p.segs.size();
-  const int npack = 2 * 21;
-  const int nreduce_max = 2 * 40;
+  const int npack = 64;
+  const int nreduce_max = 160;
   // tables region (bytes -> floats)
   p.pack_off_b = 0;
   p.groups_off_b = align_up(npack * sizeof(PackDesc), 256);
@@ -313,17 +377,34 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       L.small_part = take((size_t)G * SMALL_PART);
       L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
     }
+    if (h->warp) {
+      L.wpoints = take(nt * TILE_ROWS * 3);
+      L.points_raw = take(nt * TILE_ROWS * 3);
+      if (train) {
+        L.d_points = take(nt * TILE_ROWS * 3);
+        L.w_st_win = take(nt * h->PKw * TILE_ROWS);
+        L.w_st_h = take(nt * FRAG_TILE_128 * WARP_DEPTH);
+        L.w_st_wv = take(nt * TILE_ROWS * 8);
+        L.w_bits = take(nt * 4 * 128 * WARP_DEPTH);
+        L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
+        L.w_dw4 = take(nt * TILE_ROWS * 4);
+        L.w_dv4 = take(nt * TILE_ROWS * 4);
+        L.w_small_part = take((size_t)G * WARP_SMALL_PART);
+      }
+    }
   }
+  if (h->warp) p.warp_wpk = take(h->wpk.total);
 
   // ---- pack descriptors (both levels, forward and transposed streams) ----
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const MlpParamOffsets& po = h->po[lv];
     const int64_t base = (int64_t)p.L[lv].wpk;
     const PackOffsets& pk = h->pk;
-    auto add = [&](int64_t src, int dst, int ld, int row0, int kvalid, int K, int ncb, int tr) {
+    auto add = [&](int64_t src, int dst, int ld, int row0, int kvalid, int K, int ncb, int tr, int nwaves = 4,
+                   int nvalid = 1 << 30) {
       PackDesc q;
       q.src_off = src; q.dst_off = base + dst; q.src_ld = ld; q.src_row0 = row0; q.kvalid = kvalid; q.K = K; q.ncb = ncb;
-      q.transposed = tr;
+      q.transposed = tr; q.nwaves = nwaves; q.nvalid = nvalid;
       p.pack.push_back(q);
     };
     add(po.trunk_k[0], pk.fwd_L[0], 256, 0, h->P, h->PK, 2, 0);
@@ -334,9 +415,29 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
     add(po.rgbh_k, pk.bwd_rgbhT, 128, 0, 128, 128, 2, 1);
     add(po.bn_k, pk.bwd_bnT, 256, 0, 256, 256, 2, 1);
     for (int l = 1; l < TRUNK_DEPTH; ++l) add(po.trunk_k[l], pk.bwd_LT[l], 256, 0, 256, 256, 2, 1);
+    if (h->warp) {   // d posenc streams: B[k][n] = W[row0 + n][k], n < P, one 64-column group
+      add(po.trunk_k[0], pk.bwd_L0T, 256, 0, 256, 256, 2, 1, 1, h->P);
+      add(po.trunk_k[d.nerf_skip_layer], pk.bwd_L4bT, 256, 256, 256, 256, 2, 1, 1, h->P);
+    }
+  }
+  if (h->warp) {
+    const WarpParamOffsets& w = h->wpo;
+    const WarpPackOffsets& wk = h->wpk;
+    const int64_t base = (int64_t)p.warp_wpk;
+    auto addw = [&](int64_t src, int dst, int row0, int kvalid, int K, int tr) {
+      PackDesc q;
+      q.src_off = src; q.dst_off = base + dst; q.src_ld = WARP_W; q.src_row0 = row0; q.kvalid = kvalid; q.K = K; q.ncb = 1;
+      q.transposed = tr; q.nwaves = 4; q.nvalid = 1 << 30;
+      p.pack.push_back(q);
+    };
+    addw(w.trunk_k[0], wk.fwd_L[0], 0, h->Win, h->PKw, 0);
+    for (int l = 1; l < WARP_DEPTH; ++l) addw(w.trunk_k[l], wk.fwd_L[l], 0, WARP_W, WARP_W, 0);
+    addw(w.trunk_k[WARP_SKIP], wk.fwd_L4b, WARP_W, h->Win, h->PKw, 0);
+    for (int l = 1; l < WARP_DEPTH; ++l) addw(w.trunk_k[l], wk.bwd_LT[l], 0, WARP_W, WARP_W, 1);
   }
 
   // ---- wgrad groups + slabs + reduce descriptors ----
+  std::vector<ReduceDesc> reduce2;   // accumulating descriptors (second launch)
   if (train) {
     int first = 0;
     for (size_t i = 0; i < specs.size(); ++i) {
@@ -354,9 +455,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       first += g.nsplit;
       ReduceDesc r;
       memset(&r, 0, sizeof(r));
-      r.dst_off = s.dst; r.dst_ld = s.dst_ld; r.rows = s.rows; r.cols = s.cols;
+      r.dst_off = s.dst; r.dst_ld = s.dst_ld; r.rows = s.rows; r.cols = s.cols; r.accumulate = s.accumulate;
       if (s.vec) {
-        g.vec_off = (int64_t)p.L[s.lv].d_raw4;
+        g.vec_off = (int64_t)(s.vecoff ? *s.vecoff : p.L[s.lv].d_raw4);
         g.vslab_off = (int64_t)take((size_t)g.nsplit * 2 * g.Kb * 32 * 4);
         g.slab_off = 0;
         r.src_off = g.vslab_off + (s.vec == 1 ? 3 : 0);
@@ -367,7 +468,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
         r.src_off = g.slab_off; r.src_ld = g.Nb * 32; r.part_stride = (int64_t)g.Kb * 32 * g.Nb * 32; r.nparts = g.nsplit;
       }
       p.groups.push_back(g);
-      p.reduce.push_back(r);
+      (r.accumulate ? reduce2 : p.reduce).push_back(r);
     }
     // bias gradients and per-ray condition rows
     for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -393,8 +494,23 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
         r.src_off = (int64_t)L.cond_grad; r.src_ld = 128; r.part_stride = 0; r.nparts = 1;
         p.reduce.push_back(r);
       }
+      if (h->warp) {
+        const WarpParamOffsets& w = h->wpo;
+        auto wsmall = [&](int64_t dst, int cols, int sp_off) {
+          ReduceDesc r;
+          memset(&r, 0, sizeof(r));
+          r.dst_off = dst; r.dst_ld = cols; r.rows = 1; r.cols = cols; r.accumulate = lv > 0 ? 1 : 0;
+          r.src_off = (int64_t)L.w_small_part + sp_off; r.src_ld = cols; r.part_stride = WARP_SMALL_PART; r.nparts = grid;
+          (r.accumulate ? reduce2 : p.reduce).push_back(r);
+        };
+        for (int l = 0; l < WARP_DEPTH; ++l) wsmall(w.trunk_b[l], WARP_W, l * WARP_W);
+        wsmall(w.w_b, 3, 768);
+        wsmall(w.v_b, 3, 771);
+      }
     }
   }
+  p.nreduce_first = (int)p.reduce.size();
+  p.reduce.insert(p.reduce.end(), reduce2.begin(), reduce2.end());
   p.total_floats = o;
 }
 
@@ -453,6 +569,7 @@ int validate_rays(nrf_handle h, const nrf_rays* rays) {
   if (rays->num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
   if (h->d.use_camera_metadata && !rays->camera_ids) return fail(NRF_E_NULL, "camera_ids required (use_camera_metadata)");
   if (h->app_in_cond && !rays->appearance_ids) return fail(NRF_E_NULL, "appearance_ids required");
+  if (h->warp && !rays->warp_ids) return fail(NRF_E_NULL, "warp_ids required (use_warp)");
   return NRF_OK;
 }
 
@@ -485,14 +602,40 @@ double fwd_flops_row(nrf_handle h) {
   const double P = h->P, R = h->R;
   return 2.0 * (P * 256 + 6 * 65536.0 + (256 + P) * 256 + 65536.0 + 256 + (256 + R) * 128 + 128 * 3);
 }
-double dgrad_flops_row() { return 2.0 * (128 * 3 + 256 * 128 + 65536.0 + 256 + 7 * 65536.0); }
+double dgrad_flops_row(nrf_handle h, bool warp_on) {
+  const double base = 2.0 * (128 * 3 + 256 * 128 + 65536.0 + 256 + 7 * 65536.0);
+  return warp_on ? base + 2.0 * (2.0 * 256 * h->P) : base;   // + d posenc through layer 0 and the skip rows
+}
+// SE3 field per row: trunk + heads
+double warp_fwd_flops_row(nrf_handle h) {
+  const double Wi = h->Win;
+  return 2.0 * (Wi * 128 + 3 * 16384.0 + (128 + Wi) * 128 + 16384.0 + 128 * 6);
+}
+double warp_dgrad_flops_row(nrf_handle h) { return 2.0 * (128 * 6 + 5 * 16384.0 + 2.0 * h->G * 128); }
 double wgrad_flops_row(nrf_handle h) {
   const double P = h->P, R = h->R;
   return 2.0 * (2 * P * 256 + 7 * 65536.0 + 65536.0 + (256 + R) * 128 + 256 + 128 * 3);
 }
 
-int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_rand* rnd, const nrf_outputs* out,
-                 uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream) {
+WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float alpha, float* ws, bool train) {
+  const WsPlan& p = h->plan;
+  const LevelWs& L = p.L[lv];
+  WarpFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params; a.po = h->wpo; a.wpk = ws + p.warp_wpk; a.pk = h->wpk;
+  a.zvals = ws + L.z; a.origins = rays->origins; a.directions = rays->directions; a.warp_ids = rays->warp_ids;
+  a.points_out = ws + L.wpoints; a.points_raw = ws + L.points_raw;
+  a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
+  a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = alpha;
+  if (train) {
+    a.st_win = ws + L.w_st_win; a.st_h = ws + L.w_st_h; a.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
+    a.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
+  }
+  return a;
+}
+
+int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
+                 const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream) {
   CK(validate_rays(h, rays));
   if (!params || !ws) return fail(NRF_E_NULL, "params / workspace is null");
   query_device(h);
@@ -502,6 +645,9 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
   if (ws_bytes < p.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (see nrf_workspace_bytes)");
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
+  const bool warp_on = h->warp && !(flags & NRF_FLAG_NO_WARP);   // models.py:296 use_warp argument
+  if (warp_on && !scalars) return fail(NRF_E_NULL, "nrf_step_scalars (warp_alpha) required with the warp field");
+  if (h->warp && !warp_on && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
@@ -529,6 +675,12 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
     }
     ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train);
     const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    if (warp_on) {
+      pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * p.rows[lv], stream);
+      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train), train, grid, stream);
+      pf.end(stream);
+      a.points = ws + L.wpoints;
+    }
     pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
     launch_chain_fwd(a, train, grid, stream);
     pf.end(stream);
@@ -545,11 +697,17 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
       CK(copy_out(lo.acc, ws + L.acc, B, stream));
       CK(copy_out(lo.weights, ws + L.weights, (size_t)p.rows[lv], stream));
       CK(copy_out(lo.z_vals, ws + L.z, (size_t)p.rows[lv], stream));
+      if (lo.points || lo.warped_points) {
+        if (!warp_on) return fail(NRF_E_UNSUPPORTED, "points / warped_points outputs need the warp field");
+        CK(copy_out(lo.points, ws + L.points_raw, (size_t)p.rows[lv] * 3, stream));
+        CK(copy_out(lo.warped_points, ws + L.wpoints, (size_t)p.rows[lv] * 3, stream));
+      }
     }
   }
   CK(check_launch("nrf_forward"));
   h->stashed_ws = train ? (void*)ws : nullptr;
   h->stashed_B = train ? B : -1;
+  h->stashed_warp = warp_on;
   return NRF_OK;
 }
 
@@ -559,6 +717,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
   WsPlan& p = h->plan;
   const nrf_model_desc& d = h->d;
   const int B = p.B;
+  const bool warp_on = h->stashed_warp;
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
   hipError_t e = hipMemsetAsync(grad, 0, (size_t)h->nparams * sizeof(float), stream);
   if (e != hipSuccess) return fail_hip(e, "zero grad");
@@ -584,23 +743,47 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     a.bits_rgbh = reinterpret_cast<const uint32_t*>(ws + L.bits_rgbh);
     a.dy_trunk = ws + L.dy_trunk; a.dy_bn = ws + L.dy_bn; a.dy_rgbh = ws + L.dy_rgbh; a.dray = ws + L.dray;
     a.small_part = ws + L.small_part;
+    if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
+    a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
     const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
-    h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row() * p.rows[lv], stream);
+    h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
     launch_chain_bwd(a, grid, stream);
     h->prof.end(stream);
+    if (warp_on) {
+      WarpBwdArgs wa;
+      memset(&wa, 0, sizeof(wa));
+      wa.params = params; wa.po = h->wpo; wa.wpk = ws + p.warp_wpk; wa.pk = h->wpk;
+      wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
+      wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+      wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
+      wa.warp_ids = rays->warp_ids;
+      wa.S = p.S[lv]; wa.B = B; wa.rows = p.rows[lv]; wa.ntiles = p.ntiles[lv];
+      wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
+      wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
+      wa.grad_embed = grad + h->wpo.embed; wa.small_part = ws + L.w_small_part;
+      h->prof.begin(lv == 0 ? "warp_dgrad_coarse" : "warp_dgrad_fine", warp_dgrad_flops_row(h) * p.rows[lv], stream);
+      launch_warp_bwd(wa, grid, stream);
+      h->prof.end(stream);
+    }
     h->prof.begin("cond_wgrad", 0, stream);
     launch_cond_wgrad(ws + p.cond, ws + L.dray, B, h->R, ws + L.cond_grad, stream);
+    launch_cond_embed_grad(params, ws + L.dray, rays->appearance_ids, rays->camera_ids, B, h->V,
+                           h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
+                           d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->po[lv].rgbh_k, grad, stream);
     h->prof.end(stream);
   }
   double wg_rows = 0;
   for (int lv = 0; lv < h->nlevels; ++lv) wg_rows += p.rows[lv];
-  h->prof.begin("wgrad", wgrad_flops_row(h) * wg_rows, stream);
+  h->prof.begin("wgrad", (wgrad_flops_row(h) + (warp_on ? warp_fwd_flops_row(h) : 0.0)) * wg_rows, stream);
   launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b),
                reinterpret_cast<const WgradSegment*>(tables + p.segs_off_b),
                reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws, stream);
   h->prof.end(stream);
   h->prof.begin("grad_reduce", 0, stream);
-  launch_reduce(reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b), (int)p.reduce.size(), ws, grad, stream);
+  const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
+  launch_reduce(rd, p.nreduce_first, ws, grad, stream);
+  if ((int)p.reduce.size() > p.nreduce_first)   // second pass of leaves shared by both levels (SE3 field): dst +=
+    launch_reduce(rd + p.nreduce_first, (int)p.reduce.size() - p.nreduce_first, ws, grad, stream);
   if (stats) launch_finish_stats(ws + p.mse, B, stats, stream);
   h->prof.end(stream);
   return check_launch("nrf_backward");
@@ -621,7 +804,11 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width != RGB_W)
     return fail(NRF_E_UNSUPPORTED, "rgb branch must be 1 x 128");
   if (d.use_alpha_condition) return fail(NRF_E_UNSUPPORTED, "use_alpha_condition (alpha-branch conditioning) not built yet");
-  if (d.use_warp) return fail(NRF_E_UNSUPPORTED, "SE3 warp field not built yet in this round");
+  if (d.use_warp) {
+    if (d.num_warp_freqs < 0 || d.num_warp_freqs > 8) return fail(NRF_E_SHAPE, "num_warp_freqs must be in [0,8]");
+    if (d.num_warp_features < 1 || d.num_warp_features > 8) return fail(NRF_E_SHAPE, "num_warp_features must be in [1,8]");
+    if (d.num_warp_embeddings < 1) return fail(NRF_E_SHAPE, "num_warp_embeddings must be positive");
+  }
   if (!d.use_viewdirs && !d.use_camera_metadata) return fail(NRF_E_UNSUPPORTED, "rgb branch needs at least one condition");
   if (d.num_coarse_samples < 3 || d.num_coarse_samples > 256) return fail(NRF_E_SHAPE, "num_coarse_samples must be in [3,256]");
   if (d.num_fine_samples < 0 || d.num_coarse_samples + d.num_fine_samples > 512)
@@ -636,6 +823,12 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   h->PK = (h->P + 3) / 4 * 4;
   h->V = d.use_viewdirs ? 3 + 6 * d.num_nerf_viewdir_freqs : 0;
   h->app_in_cond = (d.use_appearance_metadata && d.use_alpha_condition) ? 1 : 0;   // models.py:206
+  h->warp = d.use_warp != 0;
+  if (h->warp) {
+    h->Fw = d.num_warp_freqs; h->G = d.num_warp_features;
+    h->Win = 3 + 6 * h->Fw + h->G;                 // [annealed posenc, GLO code] (warping.py:326-327)
+    h->PKw = (h->Win + 7) / 8 * 8;
+  }
   h->R = h->V + (h->app_in_cond ? d.num_appearance_features : 0) + (d.use_camera_metadata ? d.num_camera_features : 0);
   if (h->R > 64) { delete h; return fail(NRF_E_SHAPE, "rgb condition wider than 64"); }
   build_layout(h);
@@ -677,9 +870,8 @@ int nrf_workspace_bytes(nrf_handle h, int32_t num_rays, uint32_t flags, size_t* 
 int nrf_forward(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_step_scalars* scalars,
                 const nrf_rand* rnd, const nrf_outputs* out, uint32_t flags, void* workspace, size_t workspace_bytes,
                 void* stream) {
-  (void)scalars;
   if (!h) return fail(NRF_E_NULL, "handle is null");
-  return forward_impl(h, params, rays, rnd, out, flags, (float*)workspace, workspace_bytes, (hipStream_t)stream);
+  return forward_impl(h, params, rays, scalars, rnd, out, flags, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int nrf_backward(nrf_handle h, const float* params, const nrf_rays* rays, const float* d_rgb_coarse,
@@ -702,9 +894,9 @@ int nrf_backward(nrf_handle h, const float* params, const nrf_rays* rays, const 
 int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
                              const nrf_step_scalars* scalars, const nrf_rand* rnd, float* grad_params, float* stats,
                              void* workspace, size_t workspace_bytes, void* stream) {
-  (void)scalars;
   if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
-  CK(forward_impl(h, params, rays, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes, (hipStream_t)stream));
+  CK(forward_impl(h, params, rays, scalars, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes,
+                  (hipStream_t)stream));
   const float* dr[2] = {nullptr, nullptr};
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream);
 }

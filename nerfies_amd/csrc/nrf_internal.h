@@ -16,6 +16,14 @@ constexpr int FRAG_TILE_256 = TRUNK_W * TILE_ROWS;     // floats per stash tile,
 constexpr int FRAG_TILE_128 = RGB_W * TILE_ROWS;
 constexpr int SMALL_PART = 3080;  // per-workgroup small-gradient partials (see mlp_chain.hip)
 
+// SE3 warp field trunk (warping.py:224-231 defaults): 6 x 128, skip at 4
+constexpr int WARP_W = 128;
+constexpr int WARP_DEPTH = 6;
+constexpr int WARP_SKIP = 4;
+constexpr int WACT_FLOATS = WARP_W * TILE_ROWS;
+constexpr int WARP_SMALL_PART = 784;   // db_trunk[6][128] | db_w[3] | db_v[3] | pad
+constexpr int WARP_MAX_IN = 64;        // padded trunk input width (3 + 6 F_w + G <= 64)
+
 // Offsets (in floats) of one NeRF MLP's leaves inside the flat parameter buffer
 // (canonical flax layout: kernel [in,out] row-major, then bias).
 struct MlpParamOffsets {
@@ -34,6 +42,22 @@ struct PackOffsets {
   int fwd_bn, fwd_rgbh;
   int bwd_rgbhT, bwd_bnT;
   int bwd_LT[TRUNK_DEPTH]; // [1..7] used (dX of layer l), [0] unused unless warp
+  int bwd_L0T, bwd_L4bT;   // warp on: W0^T and the skip layer's posenc rows^T, 256 -> PK (64-column stream)
+  int total;
+};
+
+// SE3 field leaves inside the flat parameter buffer
+struct WarpParamOffsets {
+  int64_t trunk_k[WARP_DEPTH];
+  int64_t trunk_b[WARP_DEPTH];
+  int64_t w_k, w_b, v_k, v_b;   // branches_w / branches_v logit: [128,3], [3]
+  int64_t embed;                // metadata_encoder embedding [num_embeddings, G]
+};
+
+struct WarpPackOffsets {
+  int fwd_L[WARP_DEPTH];   // L0: K=PKw ; others K=128 (one 32-column block per wave)
+  int fwd_L4b;             // skip layer's input rows, K=PKw
+  int bwd_LT[WARP_DEPTH];  // [1..5]: transposed 128x128
   int total;
 };
 
@@ -75,6 +99,53 @@ struct ChainBwdArgs {
   float* dy_rgbh;            // [ntiles][128*128]
   float* dray;               // [B][128] += per-ray sums of dpre_rgbh (atomics)
   float* small_part;         // [gridDim.x][SMALL_PART]
+  // warp on: gradient w.r.t. the (warped) sample points through both posenc inputs of the trunk
+  float* d_points;           // [ntiles*128][3] or nullptr
+  const float* st_pe;        // [ntiles][PK][128] posenc stash of the forward pass
+  int F, P, PK;
+};
+
+// SE3Field forward (warping.py:322-353): x = o + z d (or explicit points) -> warped points.
+struct WarpFwdArgs {
+  const float* params;
+  WarpParamOffsets po;
+  const float* wpk;
+  WarpPackOffsets pk;
+  const float* zvals;        // [B*S]
+  const float* origins;      // [B][3]
+  const float* directions;   // [B][3]
+  const int32_t* warp_ids;   // [B]
+  const float* points_in;    // [rows][3] explicit points (then ids are per point) or nullptr
+  const int32_t* point_ids;  // [rows] with points_in
+  float* points_out;         // [ntiles*128][3] warped points
+  float* points_raw;         // optional [rows][3]: the unwarped sample points (return_points)
+  int S, B, rows, ntiles;
+  int F, G, Win, PKw;        // warp freqs, code width, 3+6F+G, Win rounded up to a multiple of 8
+  float alpha;               // warp_extra['alpha']
+  float* st_win;             // [ntiles][PKw][128] trunk input (training stash)
+  float* st_h;               // [6][ntiles][128*128] h1..h6, fragment-native
+  float4* st_wv;             // [ntiles*128][2] raw head outputs (w, v)
+  uint32_t* bits;            // [6][ntiles][4 waves][64 lanes] x 2 dwords
+};
+
+struct WarpBwdArgs {
+  const float* params;
+  WarpParamOffsets po;
+  const float* wpk;
+  WarpPackOffsets pk;
+  const float* d_points;     // [ntiles*128][3] dL/d warped point
+  const float* st_win;
+  const float4* st_wv;
+  const uint32_t* bits;
+  const int32_t* warp_ids;   // [B]
+  const int32_t* point_ids;  // [rows] or nullptr
+  int S, B, rows, ntiles;
+  int F, G, Win, PKw;
+  float* dy;                 // [6][ntiles][128*128] dpre_0..dpre_5
+  float4* d_w4;              // [ntiles*128] (dw, 0)
+  float4* d_v4;              // [ntiles*128] (dv, 0)
+  float* grad_embed;         // flat gradient + embedding offset (atomics)
+  float* small_part;         // [gridDim.x][WARP_SMALL_PART]
 };
 
 // One split-K slice of a weight-gradient GEMM  dW[k][n] = sum_rows X[row][k] dY[row][n].
@@ -106,7 +177,8 @@ struct ReduceDesc {
   int64_t dst_off;    // floats from the flat gradient buffer
   int64_t src_off;    // floats from the workspace base
   int64_t part_stride;
-  int dst_ld, rows, cols, src_ld, nparts, pad_;
+  int dst_ld, rows, cols, src_ld, nparts;
+  int accumulate;     // 1: dst += (a second level adding into leaves shared by both passes)
 };
 
 struct PackDesc {
@@ -116,14 +188,18 @@ struct PackDesc {
   int src_row0;       // first source row (forward) / unused (transposed)
   int kvalid;         // number of valid k
   int K;              // padded K (multiple of 4, or 8 when ncb==1)
-  int ncb;            // 2 -> N=256, 1 -> N=128
-  int transposed;     // B[k][n] = src[n][k]
+  int ncb;            // 2 -> 64 columns per wave, 1 -> 32 columns per wave
+  int transposed;     // B[k][n] = src[src_row0 + n][k]
+  int nwaves;         // column groups (4 -> N = 256 / 128; 1 -> N = 64 / 32)
+  int nvalid;         // valid n (columns beyond are zero)
 };
 
 // ---- launchers (all asynchronous on `stream`) ----
 void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
 void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
+void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream);
+void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream);
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   hipStream_t stream);
 void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
@@ -148,6 +224,9 @@ void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int N
                         hipStream_t stream);
 void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst /*[R][128]*/,
                        hipStream_t stream);
+void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
+                            int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
+                            float* grad, hipStream_t stream);
 void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
                  double b2, double eps, int64_t step, double gscale, hipStream_t stream);

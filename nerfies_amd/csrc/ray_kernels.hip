@@ -386,6 +386,37 @@ void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float
   if (R > 0) hipLaunchKernelGGL(cond_wgrad_kernel, dim3(R), dim3(1024), 0, stream, cond, dray, B, R, dst);
 }
 
+// dL/d(GLO code) of the rgb-branch conditions -> scatter-add into the embedding-table gradients
+// (transpose of the nn.Embed gathers of models.py:197-214).  One block per ray:
+// d cond[c] = sum_n dray[ray][n] * W_rgbh[256 + V + c][n].
+__global__ __launch_bounds__(128) void cond_embed_grad_kernel(
+    const float* __restrict__ params, const float* __restrict__ dray, const int32_t* __restrict__ app_ids,
+    const int32_t* __restrict__ cam_ids, int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
+    int64_t rgbh_k, float* __restrict__ grad) {
+  __shared__ float red[2];
+  const int ray = blockIdx.x, t = threadIdx.x;
+  const float d = dray[(size_t)ray * RGB_W + t];
+  for (int c = 0; c < app_feat + cam_feat; ++c) {
+    const float s = wave_sum(d * params[rgbh_k + (int64_t)(TRUNK_W + V + c) * RGB_W + t]);
+    if ((t & 63) == 0) red[t >> 6] = s;
+    __syncthreads();
+    if (t == 0) {
+      const float tot = red[0] + red[1];
+      if (c < app_feat) atomicAdd(grad + app_off + (int64_t)app_ids[ray] * app_feat + c, tot);
+      else atomicAdd(grad + cam_off + (int64_t)cam_ids[ray] * cam_feat + (c - app_feat), tot);
+    }
+    __syncthreads();
+  }
+}
+
+void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
+                            int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
+                            float* grad, hipStream_t stream) {
+  if (app_feat + cam_feat > 0)
+    hipLaunchKernelGGL(cond_embed_grad_kernel, dim3(B), dim3(128), 0, stream, params, dray, app_ids, cam_ids, V, app_feat,
+                       app_off, cam_feat, cam_off, rgbh_k, grad);
+}
+
 __global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, float* __restrict__ stats) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float mc = mse_sums[0] / (3.f * B), mf = mse_sums[1] / (3.f * B);

@@ -130,14 +130,16 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int 
 
   if (nchunks > 0) { fetch(0); commit(0); }
   __syncthreads();
+  const bool active = kb0 < T.Kb;   // narrow K (Kb < number of k wave groups): surplus waves only stage
   for (int ci = 0; ci < nchunks; ++ci) {
     const bool more = ci + 1 < nchunks;
     if (more) fetch(ci + 1);
     const float* Xs = smem + (ci & 1) * WG_STAGE;
-    wgrad_compute<NRB>(acc, Xs, Xs + WG_OPER, kb0, nb0, lane);
+    if (active) wgrad_compute<NRB>(acc, Xs, Xs + WG_OPER, kb0, nb0, lane);
     if (more) commit((ci + 1) & 1);
     __syncthreads();
   }
+  if (!active) return;
 
   const int j = lane & 31, h = lane >> 5;
   const int ld = T.Nb * 32;
@@ -247,7 +249,8 @@ __global__ void reduce_kernel(const ReduceDesc* __restrict__ descs, const float*
     const float* s = ws + d.src_off + (size_t)r * d.src_ld + c;
     float acc = 0.f;
     for (int q = 0; q < d.nparts; ++q) acc += s[(size_t)q * d.part_stride];
-    grad[d.dst_off + (size_t)r * d.dst_ld + c] = acc;
+    float* o = grad + d.dst_off + (size_t)r * d.dst_ld + c;
+    *o = d.accumulate ? *o + acc : acc;
   }
 }
 

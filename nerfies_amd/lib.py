@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, '_lib', 'libnerfies_amd.so')
 
 NRF_FLAG_TRAIN = 1
+NRF_FLAG_NO_WARP = 2
 ACT = {'relu': 0, 'softplus': 1}
 
 
@@ -51,7 +52,7 @@ class Rand(C.Structure):
 
 class LevelOut(C.Structure):
   _fields_ = [('rgb', C.c_void_p), ('depth', C.c_void_p), ('med_depth', C.c_void_p), ('acc', C.c_void_p),
-              ('weights', C.c_void_p), ('z_vals', C.c_void_p)]
+              ('weights', C.c_void_p), ('z_vals', C.c_void_p), ('points', C.c_void_p), ('warped_points', C.c_void_p)]
 
 
 class Outputs(C.Structure):

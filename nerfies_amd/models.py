@@ -145,6 +145,10 @@ class NerfModel:
     d.use_alpha_condition = int(self.use_alpha_condition)
     d.use_rgb_condition = int(self.use_rgb_condition)
     d.use_trunk_condition = int(self.use_trunk_condition)
+    if self.use_warp and self.warp_field_type != 'se3':
+      raise L.NrfError("only warp_field_type='se3' is built (every shipped preset uses it, warp_defaults.gin)")
+    if self.use_warp and self.warp_metadata_encoder_type != 'glo':
+      raise L.NrfError("only the 'glo' warp metadata encoder is built")
     d.use_warp = int(self.use_warp)
     d.num_warp_freqs = self.num_warp_freqs
     d.num_warp_embeddings = self.num_warp_embeddings if self.use_warp else 0
@@ -238,8 +242,11 @@ class NerfModel:
     del deterministic   # accepted and unused, as in the reference (models.py:298)
     if metadata_encoded:
       raise L.NrfError('metadata_encoded=True is not built yet')
-    if return_points or return_warp_jacobian:
-      raise L.NrfError('return_points / return_warp_jacobian need the warp field (not built yet)')
+    if return_warp_jacobian or self.use_warp_jacobian:
+      raise L.NrfError('warp Jacobian (elastic regulariser, SURVEY 8f rank 1) is not built yet')
+    warp_on = bool(self.use_warp and use_warp)
+    if return_points and not warp_on:
+      raise L.NrfError('return_points is only built together with the warp field')
     device = torch.as_tensor(rays_dict['origins']).device
     if device.type != 'cuda':
       raise L.NrfError('rays must live on the GPU: the hot path has no CPU fallback')
@@ -259,14 +266,18 @@ class NerfModel:
         d['weights'] = torch.empty(B, s, device=device)
       if return_z_vals:   # extra (not in the reference dict): the sample depths of this level
         d['z_vals'] = torch.empty(B, s, device=device)
+      if return_points:   # models.py:250-251, 266-267
+        d['points'] = torch.empty(B, s, 3, device=device)
+        d['warped_points'] = torch.empty(B, s, 3, device=device)
       for k, t in d.items():
         setattr(lo, k, _ptr(t))
       ret[name] = d
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
     ws = self.workspace(B, train, device)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0)
     L.check(self.lib.nrf_forward(self.handle, _ptr(fp.flat), C.byref(rays), C.byref(scal), C.byref(rnd), C.byref(out),
-                                 L.NRF_FLAG_TRAIN if train else 0, _ptr(ws), ws.numel() * 4, stream), self.lib)
+                                 flags, _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2
     return ret
 

@@ -82,13 +82,15 @@ class FlatParams:
 
 def init_flat(layout: ParamLayout, seed: int, device) -> torch.Tensor:
   """Reference initialisation: glorot-uniform kernels, zero biases (modules.py:107-108, 127-140),
-  embeddings U[0, 0.05) (glo.py:33)."""
+  embeddings U[0, 0.05) (glo.py:33); SE3 trunk xavier-uniform (= glorot, warping.py:237), heads U[0,1e-4)."""
   g = torch.Generator(device='cpu')
   g.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
   flat = torch.zeros(layout.total, dtype=torch.float32)
   for name, off, shape in layout.entries:
     n = math.prod(shape)
-    if name.endswith('/kernel'):
+    if name.startswith('warp_field/branches_') and name.endswith('/kernel'):
+      flat[off:off + n] = torch.rand(n, generator=g) * 1e-4   # initializers.uniform(scale=1e-4), one-sided (warping.py:238-239)
+    elif name.endswith('/kernel'):
       lim = math.sqrt(6.0 / (shape[0] + shape[1]))
       flat[off:off + n] = (torch.rand(n, generator=g) * 2 - 1) * lim
     elif name.endswith('/embedding'):

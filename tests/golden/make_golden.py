@@ -77,6 +77,17 @@ def compute(name):
     out[f'{lv}/psnr'] = np.array(stats[lv]['metric/psnr'].item())
   for path, g in O.tree_leaves_with_path(grads):
     out['grad/' + path] = leaf_digest(g)
+  # The same gradients from the fp32 oracle.  A pre-activation within fp32 rounding of zero takes
+  # the other ReLU branch in fp32 than in fp64; with few rays one such flip moves a whole layer's
+  # gradient (and every layer below it) by percents.  An fp32 implementation is therefore held to
+  # the fp32 oracle where the two oracles disagree (tests/test_golden.py).
+  f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+  p32 = O.tree_map(f32, params)
+  b32 = {k: (O.tree_map(f32, v) if isinstance(v, dict) else f32(v)) for k, v in batch.items()}
+  _, _, grads32, _ = O.loss_and_grad(p32, spec, b32, warp_alpha=alpha, t_rand=f32(t_rand) if t_rand is not None else None,
+                                     u=f32(u) if u is not None else None)
+  for path, g in O.tree_leaves_with_path(grads32):
+    out['grad32/' + path] = leaf_digest(g.double())
   for k in ('origins', 'directions', 'rgb'):
     out['in/' + k] = batch[k].numpy()
   for k, v in batch['metadata'].items():

@@ -293,3 +293,113 @@ def test_errors_are_reported_not_fatal():
   with pytest.raises(L.NrfError):   # backward without a stashed forward on that workspace
     model.apply({'params': fp}, gb, {}, train=False)
     model.backward({'params': fp}, gb, gb['rgb'], gb['rgb'])
+
+
+# ---------------------------------------------------------------------------------------------
+# SE3 warp field (warping.py:202-389) -- SURVEY.md 8a rows 3-6
+# ---------------------------------------------------------------------------------------------
+def _make_warp(B, seed=0, alpha=3.5, **kw):
+  import helpers as H
+  skw = dict(num_coarse_samples=32, num_fine_samples=32, num_nerf_point_freqs=8, use_stratified_sampling=False,
+             use_warp=True, num_warp_freqs=8, num_warp_features=8, num_warp_embeddings=4)
+  skw.update(kw)
+  spec = O.ModelSpec(**skw)
+  oparams = O.init_params(spec, seed=seed, trained_like=True, dtype=torch.float64)
+  batch = O.synthetic_batch(B, seed=seed + 1, dtype=torch.float64)
+  model, fp = H.gpu_model(spec, oparams, B)
+  return spec, model, fp, H.gpu_batch(batch), oparams, batch, alpha
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(num_warp_freqs=6, num_warp_features=3), dict(num_warp_freqs=4)])
+def test_warp_forward_parity(kw):
+  spec, model, fp, gb, p64, b64, alpha = _make_warp(7, **kw)
+  out = model.apply({'params': fp}, gb, {'alpha': alpha}, return_points=True, return_weights=True)
+  ref = O.nerf_model_apply(p64, spec, b64, alpha, return_points=True)
+  for lv in ('coarse', 'fine'):
+    np.testing.assert_allclose(out[lv]['points'].cpu().numpy(), ref[lv]['points'].numpy(), atol=2e-6)
+    np.testing.assert_allclose(out[lv]['warped_points'].cpu().numpy(), ref[lv]['warped_points'].numpy(), atol=2e-5)
+    for k in ('rgb', 'depth', 'acc', 'weights'):
+      np.testing.assert_allclose(out[lv][k].cpu().numpy(), ref[lv][k].detach().numpy(), atol=2e-4, err_msg=f'{lv}/{k}')
+
+
+def test_warp_reference_init_is_near_identity_and_finite():
+  """With the reference initialisation (heads U[0,1e-4), warping.py:238-239) theta ~ 1e-4: the fp32
+  reference form loses 1-cos(theta) entirely; the series form must stay finite and ~identity."""
+  import helpers as H
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, use_warp=True)
+  oparams = O.init_params(spec, seed=5, trained_like=False, dtype=torch.float64)
+  batch = O.synthetic_batch(4, seed=6, dtype=torch.float64)
+  model, fp = H.gpu_model(spec, oparams, 4)
+  out = model.apply({'params': fp}, H.gpu_batch(batch), {'alpha': 8.0}, return_points=True)
+  ref = O.nerf_model_apply(oparams, spec, batch, 8.0, return_points=True)
+  for lv in ('coarse', 'fine'):
+    wp = out[lv]['warped_points']
+    assert torch.isfinite(wp).all()
+    np.testing.assert_allclose(wp.cpu().numpy(), ref[lv]['warped_points'].numpy(), atol=2e-6)
+    assert (wp - out[lv]['points']).abs().max().item() < 1e-2
+
+
+def test_warp_can_be_disabled_per_call():
+  spec, model, fp, gb, p64, b64, alpha = _make_warp(5)
+  out = model.apply({'params': fp}, gb, {'alpha': alpha}, use_warp=False)
+  ref = O.nerf_model_apply(p64, spec, b64, alpha, use_warp=False)
+  np.testing.assert_allclose(out['fine']['rgb'].cpu().numpy(), ref['fine']['rgb'].detach().numpy(), atol=2e-4)
+
+
+@pytest.mark.parametrize('kw,alpha', [(dict(num_nerf_point_freqs=3), 3.5),
+                                       (dict(num_nerf_point_freqs=2, num_warp_freqs=6, use_camera_metadata=True), 6.0),
+                                       (dict(num_nerf_point_freqs=3, num_warp_features=3, use_stratified_sampling=True), 1.25),
+                                       (dict(num_nerf_point_freqs=2, num_coarse_samples=48, num_fine_samples=80), 8.0)])
+def test_warp_loss_and_grad_parity(kw, alpha):
+  """Gradients of every leaf (NeRF MLPs, SE3 trunk + heads, GLO tables) with the warp on.  Low NeRF
+  posenc frequencies keep the fp32 rounding of the warped points from being amplified into ReLU
+  branch flips (see tests/test_golden.py), so the comparison is tight."""
+  import helpers as H
+  from nerfies_amd import params as P
+  spec, model, fp, gb, p64, b64, _ = _make_warp(9, seed=3, **kw)
+  rngs, t_rand, u = None, None, None
+  if spec.use_stratified_sampling:
+    g = torch.Generator().manual_seed(0)
+    t_rand = torch.rand(9, spec.num_coarse_samples, generator=g)
+    u = torch.rand(9, spec.num_fine_samples, generator=g)
+    rngs = {'coarse': t_rand.to(DEV), 'fine': u.to(DEV)}
+    t_rand, u = t_rand.double(), u.double()
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha}, rngs=rngs)
+  torch.cuda.synchronize()
+  loss, ostats, ograds, _ = O.loss_and_grad(p64, spec, b64, warp_alpha=alpha, t_rand=t_rand, u=u)
+  assert abs(stats[4].item() - loss.item()) < 2e-5
+  # fp32 oracle as second witness: a pre-activation within fp32 rounding of 0 takes the other ReLU
+  # branch in fp32 than in fp64, which moves that layer's (and all lower layers') gradient by
+  # percents at 9 rays.  The fp32 HIP path must agree with one of the two to 2e-3 on every leaf.
+  f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+  p32 = O.tree_map(f32, p64)
+  b32 = {k: (O.tree_map(f32, v) if isinstance(v, dict) else f32(v)) for k, v in b64.items()}
+  _, _, ograds32, _ = O.loss_and_grad(p32, spec, b32, warp_alpha=alpha, t_rand=f32(t_rand) if t_rand is not None else None,
+                                      u=f32(u) if u is not None else None)
+  got = P.tree_from_flat(grad.cpu(), model.layout)
+  n64 = 0
+  for (path, og), (_, og32) in zip(O.tree_leaves_with_path(ograds), O.tree_leaves_with_path(ograds32)):
+    node = got
+    for k in path.split('/'):
+      node = node[k]
+    scale = max(og.abs().max().item(), 1e-7)
+    err64 = (node.double() - og).abs().max().item() / scale
+    err32 = (node.double() - og32.double()).abs().max().item() / scale
+    n64 += err64 < 2e-3
+    assert min(err64, err32) < 2e-3, (path, err64, err32, scale)
+  assert n64 > 0   # heads above the first flipped layer agree with fp64 directly
+  # the warp leaves must actually carry gradient (both passes feed the shared field)
+  assert got['warp_field']['trunk']['hidden_0']['kernel'].abs().max().item() > 0
+  assert got['warp_field']['metadata_encoder']['embed']['embedding'].abs().max().item() > 0
+
+
+def test_warp_train_step_runs_and_reduces_loss():
+  from nerfies_amd import training
+  spec, model, fp, gb, p64, b64, alpha = _make_warp(64, seed=1)
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=alpha)
+  sp = training.ScalarParams(learning_rate=1e-3)
+  key, losses = 0, []
+  for _ in range(25):
+    state, stats, key = training.train_step(model, key, state, gb, sp)
+    losses.append(stats['fine']['loss/rgb'].item())
+  assert np.isfinite(losses).all() and losses[-1] < losses[0]

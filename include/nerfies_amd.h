@@ -203,6 +203,11 @@ int nrf_profile_enable(nrf_handle h, int32_t on);
 /* Waits for the recorded events, returns and resets the accumulators.  out may be NULL to query *n. */
 int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n);
 
+/* Calibration aid for the wgrad stream-K partition: for each segment of the last
+ * nrf_backward / nrf_train_step_loss_grad on `workspace`, 6 doubles {workgroup, group, Kb, Nb,
+ * tiles, wall-clock ticks (100 MHz)}.  Synchronous (hipMemcpy); out may be NULL to query *n. */
+int nrf_debug_wgrad_segments(nrf_handle h, const void* workspace, double* out, int32_t* n);
+
 /* ---- individual operators (same device code the fused path runs), exposed so
  * parity tests can check each reference function in isolation. ---- */
 

@@ -51,6 +51,7 @@ struct WsPlan {
   int wgrad_nwg = 0;
   size_t cond, mse, zero_rgb, slabs;
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
+  size_t seg_clock;     // [nsegs] uint64 wall-clock ticks per wgrad segment (cost-model calibration)
   int nreduce_first = 0;   // reduce descriptors [0, nreduce_first) overwrite, the rest accumulate (2nd launch)
   LevelWs L[2];
   size_t total_floats;
@@ -394,6 +395,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
     }
   }
   if (h->warp) p.warp_wpk = take(h->wpk.total);
+  p.seg_clock = take(2 * (p.segs.size() + 1));
 
   // ---- pack descriptors (both levels, forward and transposed streams) ----
   for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -777,7 +779,8 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
   h->prof.begin("wgrad", (wgrad_flops_row(h) + (warp_on ? warp_fwd_flops_row(h) : 0.0)) * wg_rows, stream);
   launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b),
                reinterpret_cast<const WgradSegment*>(tables + p.segs_off_b),
-               reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws, stream);
+               reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws,
+               reinterpret_cast<unsigned long long*>(ws + p.seg_clock), stream);
   h->prof.end(stream);
   h->prof.begin("grad_reduce", 0, stream);
   const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
@@ -921,6 +924,27 @@ int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n) {
       out[i].ms = h->prof.acc[i].ms; out[i].launches = h->prof.acc[i].launches; out[i].flops_per_launch = h->prof.acc[i].flops;
     }
     h->prof.acc.clear();
+  }
+  *n = cnt;
+  return NRF_OK;
+}
+
+int nrf_debug_wgrad_segments(nrf_handle h, const void* workspace, double* out, int32_t* n) {
+  if (!h || !n) return fail(NRF_E_NULL, "null");
+  const WsPlan& p = h->plan;
+  const int32_t cnt = (int32_t)p.segs.size();
+  if (out) {
+    if (*n < cnt || !workspace) return fail(NRF_E_SHAPE, "segment array too small / workspace null");
+    std::vector<unsigned long long> clk(cnt);
+    hipError_t e = hipMemcpy(clk.data(), (const float*)workspace + p.seg_clock, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) return fail_hip(e, "read segment clocks");
+    int wg = 0;
+    for (int32_t i = 0; i < cnt; ++i) {
+      while (wg + 1 < (int)p.seg_begin.size() && p.seg_begin[wg + 1] <= i) ++wg;
+      const WgradGroup& g = p.groups[p.segs[i].group];
+      out[6 * i + 0] = wg; out[6 * i + 1] = p.segs[i].group; out[6 * i + 2] = g.Kb; out[6 * i + 3] = g.Nb;
+      out[6 * i + 4] = p.segs[i].tile_end - p.segs[i].tile_begin; out[6 * i + 5] = (double)clk[i];
+    }
   }
   *n = cnt;
   return NRF_OK;

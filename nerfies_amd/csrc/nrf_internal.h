@@ -201,7 +201,7 @@ void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
 void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream);
 void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream);
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
-                  hipStream_t stream);
+                  unsigned long long* seg_clock, hipStream_t stream);
 void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
 
 void launch_ray_prep(const float* params, const float* viewdirs, const int32_t* app_ids,

@@ -213,10 +213,12 @@ __device__ __forceinline__ void wgrad_run_task(const WgradTask& T, float* smem) 
 // workgroup, so there is exactly one round and no tail), flushing a partial slab per segment.
 __global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict__ groups,
                                                     const WgradSegment* __restrict__ segs,
-                                                    const int* __restrict__ seg_begin, float* __restrict__ ws) {
+                                                    const int* __restrict__ seg_begin, float* __restrict__ ws,
+                                                    unsigned long long* __restrict__ seg_clock) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int s0 = seg_begin[blockIdx.x], s1 = seg_begin[blockIdx.x + 1];
   for (int si = s0; si < s1; ++si) {
+    const unsigned long long t0 = wall_clock64();
     const WgradSegment sg = segs[si];
     const WgradGroup G = groups[sg.group];
     WgradTask T;
@@ -229,14 +231,15 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict
     T.vslab = ws + G.vslab_off + (size_t)sg.slab_idx * 2 * (G.Kb * 32) * 4;
     wgrad_run_task(T, smem);
     __syncthreads();   // the next segment restages LDS
+    if (seg_clock && threadIdx.x == 0) seg_clock[si] = wall_clock64() - t0;   // 100 MHz ticks (cost-model calibration)
   }
 }
 
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
-                  hipStream_t stream) {
+                  unsigned long long* seg_clock, hipStream_t stream) {
   const size_t lds = (size_t)(2 * WG_STAGE + 256) * sizeof(float);
   (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws, seg_clock);
 }
 
 // dst[r][c] = sum_parts src[part][r][c]

@@ -68,6 +68,7 @@ EXPORTS = [
     'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',
     'nrf_workspace_bytes', 'nrf_forward', 'nrf_backward', 'nrf_train_step_loss_grad', 'nrf_adam_step',
     'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf', 'nrf_profile_enable', 'nrf_profile_read',
+    'nrf_debug_wgrad_segments',
 ]
 
 _lib = None
@@ -78,7 +79,7 @@ def load_library(path=None):
   global _lib
   if _lib is not None and path is None:
     return _lib
-  path = path or LIB_PATH
+  path = path or os.environ.get('NRF_LIB_PATH') or LIB_PATH   # NRF_LIB_PATH: experiment builds of the same ABI
   if not os.path.exists(path):
     raise NrfError(
         f'HIP extension not built: {path} is missing. Run `python -c "import __graft_entry__ as g; g.build()"` '
@@ -104,13 +105,13 @@ def load_library(path=None):
       'nrf_sample_pdf': [vp, vp, i32, i32, i32, i32, vp, u64, u64, vp, vp],
       'nrf_profile_enable': [vp, i32],
       'nrf_profile_read': [vp, C.POINTER(ProfileEntry), C.POINTER(i32)],
+      'nrf_debug_wgrad_segments': [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)],
   }
   for name, argtypes in sigs.items():
     fn = getattr(lib, name)
     fn.argtypes = argtypes
     fn.restype = C.c_int
-  if path == LIB_PATH:
-    _lib = lib
+  _lib = lib
   return lib
 
 

@@ -208,6 +208,12 @@ int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n);
  * tiles, wall-clock ticks (100 MHz)}.  Synchronous (hipMemcpy); out may be NULL to query *n. */
 int nrf_debug_wgrad_segments(nrf_handle h, const void* workspace, double* out, int32_t* n);
 
+/* Test aid: float offset inside the workspace of an internal buffer of `level` (0 coarse, 1 fine) for the
+ * last planned (num_rays, flags): "st_pe", "st_h", "st_bn", "st_rgbh", "dy_trunk", "dy_bn", "dy_rgbh",
+ * "d_raw4", "z", "out4", "wpoints", "d_points", "w_st_win", "w_st_h", "w_st_wv", "w_dy", "w_dw4", "w_dv4".
+ * Stash tiles are [features][64 rows] in fragment order (csrc/chain_common.h frag_index). */
+int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* float_offset);
+
 /* ---- individual operators (same device code the fused path runs), exposed so
  * parity tests can check each reference function in isolation. ---- */
 

@@ -1,194 +1,233 @@
 // Device-side building blocks shared by the fused MLP chain kernels (mlp_chain.hip: 8x256 NeRF MLP;
 // warp_chain.hip: 6x128 SE3 warp trunk).  gfx950 only.
+//
+// Tile = 64 rows (ray samples) per workgroup of 4 waves; TWO workgroups are resident per CU
+// (2 x 80 KiB LDS, <= 256 VGPRs per wave), so one workgroup's layer epilogue / prologue / heads
+// run under the other's MFMA stream.  A wave owns 64 rows x 64 (NCB=2) or 32 (NCB=1) columns =
+// 2 MFMA row blocks x NCB column blocks of v_mfma_f32_32x32x2_f32; MFMA row block rb holds tile
+// rows p = 2*i + rb (i = 0..31), so one ds_read_b64 feeds the A operand of both row blocks.
 #pragma once
 #include "nrf_internal.h"
 
 namespace nrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// Stash stores go through a wave-uniform buffer descriptor: the per-register offset rides in the
-// scalar offset, so one voffset VGPR (lane*16) serves every store (no per-store 64-bit address).
+// Stash stores go through a wave-uniform buffer descriptor (one 32-bit voffset per store instead
+// of a 64-bit address).  The scalar-offset field is deliberately left at 0 and the whole offset is
+// carried in the VGPR: with an SGPR soffset hipcc (ROCm 7.2) applies no "wide store data" hazard
+// and schedules a VALU write of the store's data registers directly behind the
+// buffer_store_dwordx4, and on gfx950 that store then picked up the NEW register contents for
+// some lanes (observed: SE3 dgrad stash corrupted in exactly the component overwritten by the
+// following v_pk_add_f32).  With soffset = 0 the compiler keeps the required wait state.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
-__device__ __forceinline__ void buf_store4(const float4& v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+__device__ __forceinline__ void buf_store4(const float4& v, __amdgpu_buffer_rsrc_t r, int voff, int off) {
   u32x4 d;
   d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff + off, 0, 0);
 }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// LDS address (in floats) of granule (k, i): 4 consecutive tile rows 4i..4i+3 of feature k.
-__device__ __forceinline__ int act_addr(int k, int i) { return k * TILE_ROWS + 4 * (i ^ (k & 7)); }
+// LDS address (in floats) of granule (k, g): 4 consecutive tile rows 4g..4g+3 of feature k.  The
+// 16 granules of a feature row are XOR-swizzled with k & 15, which makes the epilogue's
+// ds_write_b128 (lanes = 32 consecutive features, one granule) bank-conflict free; the A-operand
+// ds_read_b64 (lanes = the 32 row pairs of one feature) covers a whole 256-byte row either way.
+__device__ __forceinline__ int act_addr(int k, int g) { return k * TILE_ROWS + 4 * (g ^ (k & 15)); }
+// element (feature k, tile row p)
+__device__ __forceinline__ int act_elem(int k, int p) { return act_addr(k, p >> 2) + (p & 3); }
 
-// acc[rb][cb] += A[128 x K] * B[K x 64(32)] for this wave.
-//   lds_in : feature-major tile, pitch 128 floats; SWZ selects the swizzled act layout.
-//   wp     : this wave's packed weights, [it][lane] float4.
-//   NCB=2  : it covers 4 k  (float4 = {ks0 cb0, ks0 cb1, ks1 cb0, ks1 cb1}), nit = K/4
-//   NCB=1  : it covers 8 k  (float4 = ks0..ks3),                               nit = K/8
-template <int NCB, int KS>
-__device__ __forceinline__ void mfma_block(f32x16 (&acc)[4][NCB], const float4 (&a)[KS], const float4& b) {
-  const float bv[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-  for (int s = 0; s < KS; ++s) {
-    const float av[4] = {a[s].x, a[s].y, a[s].z, a[s].w};
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        acc[rb][cb] = mfma32(av[rb], bv[(NCB == 2) ? (2 * s + cb) : s], acc[rb][cb]);
-      }
-    }
-  }
+// "Fragment" order of a [features][64 rows] tile in HBM (activation / gradient stash).  A float4
+// piece = 4 consecutive rows of one feature; pieces are laid out so that (a) the epilogue of the
+// chain kernels stores its accumulator registers as they lie (1 KiB coalesced per wave store) and
+// (b) the wgrad kernel copies 1 KiB runs verbatim into LDS (global_load_lds) and reads them as MFMA
+// operands: float4 index = ((blk*8 + q)*64 + lane), blk = feature/32, lane = feature%32 + 32*kk,
+// rows 4g..4g+3 with g = (q&1) + 2*kk + 4*(q>>1).
+__device__ __forceinline__ int frag_index(int k, int p) {   // float index of element (feature k, row p)
+  const int g = p >> 2, q = 2 * (g >> 2) + (g & 1), kk = (g >> 1) & 1;
+  return (((k >> 5) * 8 + q) * 64 + (k & 31) + 32 * kk) * 4 + (p & 3);
 }
 
-// First weight pair of a layer.  Issued BEFORE the previous layer's epilogue so that these loads sit
-// ahead of the epilogue's stash stores in the in-order vmcnt queue (gfx9 counts stores in vmcnt).
-struct WPair { float4 b0, b1; };
-__device__ __forceinline__ WPair prefetch_pair(const float4* __restrict__ wp, int nit, int lane) {
-  WPair w;
-  w.b0 = wp[lane];
-  w.b1 = wp[(nit > 1 ? 1 : 0) * 64 + lane];
+// ---------------------------------------------------------------------------------------------
+// K loop:  acc[rb][cb] += A[64 x K] * B[K x 32*NCB]  for this wave.
+//   lds_in : feature-major tile, pitch 64 floats; SWZ selects the swizzled act layout.
+//   wp     : this wave's packed weights, [it][lane] float4.
+//   NCB=2  : it covers 4 k  (float4 = {ks0 cb0, ks0 cb1, ks1 cb0, ks1 cb1})
+//   NCB=1  : it covers 8 k  (float4 = ks0..ks3)
+// The swizzle repeats every 16 k, so the loop is organised in "quads" of 16 k = 8 k-steps
+// (NB = 4 / 2 weight float4s, 8 A reads, 32 / 16 MFMAs): the per-lane LDS offsets are loop
+// invariant.  K must be a multiple of 16.
+// ---------------------------------------------------------------------------------------------
+template <int NCB> struct WQuad { float4 b[NCB == 2 ? 4 : 2]; };
+
+template <int NCB>
+__device__ __forceinline__ WQuad<NCB> prefetch_quad(const float4* __restrict__ wp, int lane) {
+  WQuad<NCB> w;
+#pragma unroll
+  for (int q = 0; q < (NCB == 2 ? 4 : 2); ++q) w.b[q] = wp[q * 64 + lane];
   return w;
 }
 
-// Software-pipelined K loop.  One "pair" = two iterations = 32 MFMAs (2048 cycles) against
-// 2 weight loads (issued a full pair ahead; L2 latency under load is ~1-2k cycles) and 2*KS LDS
-// A-operand reads (issued >= 16 MFMAs ahead).  The swizzle pattern repeats every 8 k, i.e. every
-// pair, so the per-lane LDS offsets are loop invariant and the loop body carries no address VALU;
-// sched_group_barrier spreads the loads between the MFMAs so the matrix pipe never drains.
-// Weight loads run up to one pair past the end of the layer (the pack buffer is padded for it).
-template <int NCB, bool SWZ>
-__device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[4][NCB], const float* lds_in, int nit,
-                                            const float4* __restrict__ wp, int lane, const WPair& first) {
-  const int i = lane & 31, kk = lane >> 5;
-  constexpr int KS = (NCB == 2) ? 2 : 4;              // k-steps (of 2 k) per iteration
-  constexpr int PAIR_FLOATS = 2 * (2 * KS) * TILE_ROWS;   // LDS floats covered by one pair
-  int off[2 * KS];                                     // per-lane float offsets of the pair's reads
+// MFMAs of k-steps [S0, S0+4) of a quad: a[s] = float2 (row blocks 0/1) of k-step S0+s.
+template <int NCB, int S0>
+__device__ __forceinline__ void mfma_half(f32x16 (&acc)[2][NCB], const float2 (&a)[4], const WQuad<NCB>& w) {
 #pragma unroll
-  for (int t = 0; t < 2 * KS; ++t) {
+  for (int s = 0; s < 4; ++s) {
+    const int ks = S0 + s;   // k-step within the quad, 0..7
+    float bv[NCB];
+    if constexpr (NCB == 2) {
+      const float4 b = w.b[ks >> 1];
+      bv[0] = (ks & 1) ? b.z : b.x;
+      bv[1] = (ks & 1) ? b.w : b.y;
+    } else {
+      const float4 b = w.b[ks >> 2];
+      bv[0] = (ks & 3) == 0 ? b.x : (ks & 3) == 1 ? b.y : (ks & 3) == 2 ? b.z : b.w;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      acc[0][cb] = mfma32(a[s].x, bv[cb], acc[0][cb]);
+      acc[1][cb] = mfma32(a[s].y, bv[cb], acc[1][cb]);
+    }
+  }
+}
+
+template <int NCB, bool SWZ>
+__device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* lds_in, int nquads,
+                                            const float4* __restrict__ wp, int lane, const WQuad<NCB>& first) {
+  constexpr int NB = NCB == 2 ? 4 : 2;
+  constexpr int QUAD_FLOATS = 16 * TILE_ROWS;
+  const int i = lane & 31, kk = lane >> 5;
+  int off[8];   // per-lane float offsets of the quad's 8 A reads (k = 2t + kk)
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
     const int k = 2 * t + kk;
-    off[t] = SWZ ? act_addr(k, i) : (k * TILE_ROWS + 4 * i);
+    off[t] = SWZ ? (act_addr(k, i >> 1) + 2 * (i & 1)) : (k * TILE_ROWS + 2 * i);
   }
   const float* ap = lds_in;
   const float4* bp = wp + lane;
-  float4 bc0 = first.b0, bc1 = first.b1;
-  float4 a0[KS], a1[KS];
+  WQuad<NCB> bc = first;
+  float2 a0[4], a1[4];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) a0[s] = *reinterpret_cast<const float4*>(ap + off[s]);
-  const int npairs = nit >> 1;
+  for (int s = 0; s < 4; ++s) a0[s] = *reinterpret_cast<const float2*>(ap + off[s]);
 #pragma unroll 2
-  for (int pr = 0; pr < npairs; ++pr) {
-    const float4 bn0 = bp[128];
-    const float4 bn1 = bp[192];
+  for (int q = 0; q < nquads; ++q) {
+    WQuad<NCB> bn;   // weights run up to one quad past the end of the layer (the pack buffer is padded)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a1[s] = *reinterpret_cast<const float4*>(ap + off[KS + s]);
-    mfma_block<NCB, KS>(acc, a0, bc0);
+    for (int t = 0; t < NB; ++t) bn.b[t] = bp[(NB + t) * 64];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) a0[s] = *reinterpret_cast<const float4*>(ap + PAIR_FLOATS + off[s]);
-    mfma_block<NCB, KS>(acc, a1, bc1);
-    // order: 2 weight loads, KS A reads, then MFMAs with the next-pair A reads threaded through
-    __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);          // VMEM read x2
-    __builtin_amdgcn_sched_group_barrier(0x100, KS, 0);         // DS read xKS (odd iteration)
-    __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);          // MFMA x8
+    for (int s = 0; s < 4; ++s) a1[s] = *reinterpret_cast<const float2*>(ap + off[4 + s]);
+    mfma_half<NCB, 0>(acc, a0, bc);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);        // DS read (next even iteration)
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);        // MFMA x4
+    for (int s = 0; s < 4; ++s) a0[s] = *reinterpret_cast<const float2*>(ap + QUAD_FLOATS + off[s]);
+    mfma_half<NCB, 4>(acc, a1, bc);
+    // order: weight loads, second-half A reads, first-half MFMAs with the next quad's A reads threaded in
+    __builtin_amdgcn_sched_group_barrier(0x020, NB, 0);            // VMEM read
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);             // DS read x4
+    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCB, 0);       // MFMA
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // DS read (next quad)
+      __builtin_amdgcn_sched_group_barrier(0x008, 2 * NCB, 0);     // MFMA
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, 32 - 8 - 4 * KS, 0);
-    bc0 = bn0; bc1 = bn1;
-    ap += PAIR_FLOATS;
-    bp += 128;
+    __builtin_amdgcn_sched_group_barrier(0x008, 16 * NCB - 4 * NCB - 8 * NCB, 0);
+    bc = bn;
+    ap += QUAD_FLOATS;
+    bp += NB * 64;
   }
-  if (nit & 1) mfma_block<NCB, KS>(acc, a0, bc0);   // odd tail (K = 52: 13 iterations)
+}
+
+// Two workgroups share a CU.  Started together they run in lockstep (same work per tile): their
+// epilogues coincide and the matrix pipe idles through both.  The phase difference between the
+// two is preserved from layer to layer (whoever is alone in its K loop runs at full MFMA rate), so a
+// one-off delay of the later-dispatched half of the grid keeps one workgroup's epilogue under
+// the other's K loop for the whole kernel.  Placement is not architecturally guaranteed
+// (blocks >= grid/2 normally take the second slot of each CU); a wrong guess only loses the gain.
+__device__ __forceinline__ void dephase_second_half(int cfg) {
+  const int sleeps = cfg & 0xff, mode = cfg >> 8;
+  const int b = blockIdx.x;
+  bool late;
+  if (mode == 0) late = b >= (gridDim.x + 1) / 2;
+  else if (mode == 1) late = b & 1;
+  else if (mode == 2) late = (b >> 3) & 1;
+  else if (mode == 3) late = (b >> 4) & 1;
+  else late = (b >> 5) & 1;
+  if (late)
+    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 clocks each
 }
 
 // acc = bias[n] broadcast down the rows: the bias add rides in the MFMA accumulator for free.
 template <int NCB>
-__device__ __forceinline__ void bias_acc(f32x16 (&acc)[4][NCB], const float* __restrict__ bias, int ncol0, int lane) {
+__device__ __forceinline__ void bias_acc(f32x16 (&acc)[2][NCB], const float* __restrict__ bias, int ncol0, int lane) {
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const float bv = bias[ncol0 + 32 * cb + (lane & 31)];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb)
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = bv;
   }
 }
 
 template <int NCB>
-__device__ __forceinline__ void zero_acc(f32x16 (&acc)[4][NCB]) {
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][NCB]) {
 #pragma unroll
-  for (int rb = 0; rb < 4; ++rb)
+  for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
 }
 
-// row-in-block index of accumulator register `reg` for lane half h (C/D layout of 32x32 MFMA)
+// row-in-block index of accumulator register `reg` for lane half h (C/D layout of the 32x32 MFMA)
 __device__ __forceinline__ int c_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
-
-// Epilogue-side form of act_addr(n, c_row(reg, h)): the swizzle only touches the low 3 bits of the
-// granule index, so 4 per-lane offsets (one per reg&3) plus an immediate cover all 16 registers.
-struct EpiAddr {
-  int sw[4];
-  __device__ __forceinline__ EpiAddr(int lane) {
-    const int jx = lane & 7, h = lane >> 5;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) sw[q] = 4 * ((q + 4 * h) ^ jx);
-  }
-  __device__ __forceinline__ int operator()(int n, int reg) const { return n * TILE_ROWS + sw[reg & 3] + 32 * (reg >> 2); }
-};
+// Accumulator registers (2q, 2q+1) x row blocks (0, 1) of one lane are 4 consecutive tile rows:
+// granule g = (q&1) + 2h + 4(q>>1), q = 0..7.
+__device__ __forceinline__ int q_granule(int q, int h) { return (q & 1) + 2 * h + 4 * (q >> 1); }
+template <int NCB>
+__device__ __forceinline__ float4 acc_piece(const f32x16 (&acc)[2][NCB], int cb, int q) {
+  return make_float4(acc[0][cb][2 * q], acc[1][cb][2 * q], acc[0][cb][2 * q + 1], acc[1][cb][2 * q + 1]);
+}
 
 __device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
 
-// sign bits of one float4 (4 row blocks of one accumulator register) -> 4-bit nibble
+// sign bits of one float4 (4 consecutive rows) -> 4-bit nibble
 __device__ __forceinline__ uint32_t sign_nibble(const float4& v) {
   return (v.x > 0.f ? 1u : 0u) | (v.y > 0.f ? 2u : 0u) | (v.z > 0.f ? 4u : 0u) | (v.w > 0.f ? 8u : 0u);
 }
+__device__ __forceinline__ float4 mask4(const float4& v, uint32_t nib) {
+  return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
+}
 
-// bits_wave: this (layer, tile, wave)'s mask words, [lane][2*NCB] dwords; dword = cb*2 + reg/8,
-// nibble = reg%8, bit = row block.
+// Layer epilogue: [ReLU,] write the wave's 64 x 32*NCB outputs to the LDS activation tile and, in
+// training, to the fragment-order stash (+ 1 sign bit per element: bits_wave[lane*NCB + cb], nibble q).
 template <int NCB, bool RELU, bool STASH>
-__device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[4][NCB],
-                                             int ncol0, float* act, __amdgpu_buffer_rsrc_t stash, int stash_soff,
-                                             uint32_t* bits_wave, int lane) {
-  const int j = lane & 31;
-  const EpiAddr ea(lane);
+__device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[2][NCB], int ncol0, float* act,
+                                             __amdgpu_buffer_rsrc_t stash, int stash_soff, uint32_t* bits_wave,
+                                             int lane) {
+  const int j = lane & 31, h = lane >> 5;
   __syncthreads();   // every wave has finished reading the previous activations
-  uint32_t mb[2 * NCB];
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = ncol0 + 32 * cb + j;
-    mb[2 * cb] = mb[2 * cb + 1] = 0u;
+    uint32_t mb = 0u;
 #pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
+    for (int q = 0; q < 8; ++q) {
+      float4 v = acc_piece<NCB>(acc, cb, q);
       if (RELU) {
-        if (STASH) mb[2 * cb + (reg >> 3)] |= sign_nibble(v) << (4 * (reg & 7));
+        if (STASH) mb |= sign_nibble(v) << (4 * q);
         v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w);
       }
-      *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
-      if (STASH) buf_store4(v, stash, lane * 16, stash_soff + (cb * 16 + reg) * 1024);
+      *reinterpret_cast<float4*>(act + act_addr(n, q_granule(q, h))) = v;
+      if (STASH) buf_store4(v, stash, lane * 16, stash_soff + (cb * 8 + q) * 1024);
     }
-  }
-  if (STASH && RELU) {
-#pragma unroll
-    for (int q = 0; q < 2 * NCB; ++q) bits_wave[lane * (2 * NCB) + q] = mb[q];
+    if (STASH && RELU) bits_wave[lane * NCB + cb] = mb;
   }
   __syncthreads();
-}
-
-__device__ __forceinline__ float4 mask4(const float4& v, uint32_t nib) {
-  return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
 }
 
 }  // namespace nrf

@@ -6,29 +6,31 @@
 //   modules.MLP / NerfMLP       modules.py:26-62, 65-169
 //   nn.sigmoid / sigma_activation  models.py:276-277
 //
-// Design (one workgroup = 4 waves = one 128-row tile, persistent over tiles):
-//   * activations of the tile live in LDS, feature-major  act[k][128 rows]
-//     (XOR-swizzled 16-byte granules so the MFMA epilogue's ds_write_b128 and
-//     the A-operand ds_read_b128 are both bank-conflict free at pitch 128);
-//   * every layer is  acc[128 x 64 per wave] += A(LDS) x B(weights), with
+// Design (one workgroup = 4 waves = one 64-row tile, persistent over tiles, TWO
+// workgroups resident per CU so one's epilogues hide under the other's MFMAs):
+//   * activations of the tile live in LDS, feature-major  act[k][64 rows]
+//     (XOR-swizzled 16-byte granules so the MFMA epilogue's ds_write_b128 is
+//     bank-conflict free; the A-operand ds_read_b64 covers a whole row);
+//   * every layer is  acc[64 x 64 per wave] += A(LDS) x B(weights), with
 //     v_mfma_f32_32x32x2_f32 (exact fp32 == an fmaf chain).  Rows are
-//     interleaved so that MFMA row-block rb holds tile rows p = 4*i + rb: one
-//     ds_read_b128 then feeds the A operand of all four row blocks;
+//     interleaved so that MFMA row-block rb holds tile rows p = 2*i + rb: one
+//     ds_read_b64 then feeds the A operand of both row blocks;
 //   * weights are pre-packed per layer in B-fragment order, so each lane
 //     streams its B operands with one coalesced global_load_dwordx4 per 16
 //     MFMAs straight from L2 -- no LDS traffic for weights;
 //   * the training stash is written straight from the accumulator registers in
 //     "fragment-native" order (coalesced 1 KiB per wave store); the dgrad pass
 //     and the wgrad GEMM read it back in the same order.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "chain_common.h"
 
 namespace nrf {
 
-
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-
 __device__ __forceinline__ float sigma_activation(float x, int kind) {
   if (kind == 1) {  // softplus, computed as jax.nn.softplus = logaddexp(x, 0)
     return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
@@ -37,20 +39,31 @@ __device__ __forceinline__ float sigma_activation(float x, int kind) {
 }
 
 template <bool STASH>
-__global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A) {
+__global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* act = smem;                 // [256][128] swizzled
-  float* pe = smem + ACT_FLOATS;     // [PK][128]; reused as scratch after the skip layer
+  float* act = smem;                 // [256][64] swizzled
+  float* pe = smem + ACT_FLOATS;     // [PK][64]; reused as scratch after the skip layer
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int p = tid & 127;
-  const int half = wave >> 1;
+  const int p = lane;                // tile row handled in the per-row (VALU) phases
+  const int part = wave;             // ... by 4 threads, one per wave
   const float* __restrict__ prm = A.params;
   const int PK = A.PK;
+  const int PKS = (PK + 31) / 32 * 32;   // features per posenc stash tile (whole 32-feature blocks)
+  const int nq_pe = PK / 16;
+  dephase_second_half(A.dephase);
+  int stamp_i = 0;
+  auto STAMP = [&]() {
+    if (A.timeline && blockIdx.x == 0 && lane == 0 && stamp_i < 64) A.timeline[wave * 64 + stamp_i] = clock64();
+    ++stamp_i;
+  };
 
+  unsigned long long wg_t0 = 0;
+  if (A.timeline && tid == 0) wg_t0 = clock64();
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    STAMP();   // tile start
     // ---- prologue: sample point + SinusoidalEncoder (modules.py:213-228) ----
     {
       int r = tile * TILE_ROWS + p;
@@ -65,19 +78,20 @@ __global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A)
         for (int c = 0; c < 3; ++c)   // origins + z_vals * directions  (model_utils.py:72-73)
           x[c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
       }
-      float* stp = STASH ? A.st_pe + (size_t)tile * PK * TILE_ROWS + p : nullptr;
+      float* stp = STASH ? A.st_pe + (size_t)tile * PKS * TILE_ROWS : nullptr;
       auto put = [&](int k, float v) {
         pe[k * TILE_ROWS + p] = v;
-        if (STASH) stp[k * TILE_ROWS] = v;
+        if (STASH) stp[frag_index(k, p)] = v;
       };
-      if (half == 0) {
+      if (part == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) put(c, x[c]);
-      } else {
+      } else if (part == 1) {
         for (int k = A.P; k < PK; ++k) put(k, 0.f);
+        if (STASH) for (int k = PK; k < PKS; ++k) stp[frag_index(k, p)] = 0.f;
       }
       const float half_pi = 1.57079632679489661923f;   // fp32(pi/2), modules.py:222
-      for (int f = half; f < A.F; f += 2) {
+      for (int f = part; f < A.F; f += 4) {
         const float fr = (float)(1 << f);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
@@ -89,33 +103,36 @@ __global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A)
     }
     __syncthreads();
 
-    f32x16 acc[4][2];
+    STAMP();   // prologue done
+    f32x16 acc[2][2];
     const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
     const size_t st_h_layer = (size_t)A.ntiles * FRAG_TILE_256;       // floats
-    const int wv_soff = wave * 2 * 16 * 1024;                          // bytes: this wave's slice of a tile
+    const int wv_soff = wave * 2 * 8 * 1024;                           // bytes: this wave's slice of a tile
 
     // ---- trunk: 8 x Dense(256)+ReLU, skip concat [h, posenc] at layer 4 (modules.py:41-50) ----
     const float4* wL0 = wpk4 + (A.pk.fwd_L[0] / 4) + wave * (PK / 4) * 64;
-    WPair wnext = prefetch_pair(wL0, PK / 4, lane);
+    WQuad<2> wnext = prefetch_quad<2>(wL0, lane);
 #pragma unroll 1
     for (int l = 0; l < TRUNK_DEPTH; ++l) {
       bias_acc<2>(acc, prm + A.po.trunk_b[l], wave * 64, lane);
       if (l == 0) {
-        mfma_k_loop<2, false>(acc, pe, PK / 4, wL0, lane, wnext);
+        mfma_k_loop<2, false>(acc, pe, nq_pe, wL0, lane, wnext);
       } else {
-        mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane, wnext);
+        mfma_k_loop<2, true>(acc, act, 16, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane, wnext);
         if (l == SKIP_LAYER) {
           const float4* w4b = wpk4 + (A.pk.fwd_L4b / 4) + wave * (PK / 4) * 64;
-          mfma_k_loop<2, false>(acc, pe, PK / 4, w4b, lane, prefetch_pair(w4b, PK / 4, lane));
+          mfma_k_loop<2, false>(acc, pe, nq_pe, w4b, lane, prefetch_quad<2>(w4b, lane));
         }
       }
       // the next layer's first weights go out before this layer's stash stores
-      wnext = prefetch_pair(wpk4 + ((l + 1 < TRUNK_DEPTH ? A.pk.fwd_L[l + 1] : A.pk.fwd_bn) / 4) + wave * 64 * 64, 64, lane);
+      wnext = prefetch_quad<2>(wpk4 + ((l + 1 < TRUNK_DEPTH ? A.pk.fwd_L[l + 1] : A.pk.fwd_bn) / 4) + wave * 64 * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
+      STAMP();   // k loop of layer l issued
       fwd_epilogue<2, true, STASH>(
           acc, wave * 64, act,
           make_rsrc(STASH ? A.st_h + l * st_h_layer + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff,
-          STASH ? A.bits_trunk + (((size_t)l * A.ntiles + tile) * 4 + wave) * 256 : nullptr, lane);
+          STASH ? A.bits_trunk + (((size_t)l * A.ntiles + tile) * 4 + wave) * 128 : nullptr, lane);
+      STAMP();   // epilogue of layer l done
     }
 
     // ---- alpha head: Dense(256->1) on the trunk output (modules.py:152-157) ----
@@ -123,89 +140,107 @@ __global__ __launch_bounds__(256) void nerf_mlp_fwd_kernel(const ChainFwdArgs A)
     {
       const float* __restrict__ wa = prm + A.po.alpha_k;
       float s = 0.f;
-      const int k0 = half * 128;
-      const int g = p >> 2, e = p & 3;
-      for (int k = k0; k < k0 + 128; ++k) s = fmaf(act[k * TILE_ROWS + 4 * (g ^ (k & 7)) + e], wa[k], s);
-      pe[half * TILE_ROWS + p] = s;   // scratch (posenc no longer needed for this tile)
+      const int k0 = part * 64;
+      for (int k = k0; k < k0 + 64; ++k) s = fmaf(act[act_elem(k, p)], wa[k], s);
+      pe[part * TILE_ROWS + p] = s;   // scratch (posenc no longer needed for this tile)
       __syncthreads();
-      if (half == 0) sigma_raw = pe[p] + pe[TILE_ROWS + p] + prm[A.po.alpha_b];
+      if (part == 0)
+        sigma_raw = (pe[p] + pe[TILE_ROWS + p]) + (pe[2 * TILE_ROWS + p] + pe[3 * TILE_ROWS + p]) + prm[A.po.alpha_b];
     }
 
+    STAMP();   // alpha head done
     // ---- bottleneck: Dense(256), no activation (modules.py:149-150) ----
     bias_acc<2>(acc, prm + A.po.bn_b, wave * 64, lane);
-    mfma_k_loop<2, true>(acc, act, 64, wpk4 + (A.pk.fwd_bn / 4) + wave * 64 * 64, lane, wnext);
+    mfma_k_loop<2, true>(acc, act, 16, wpk4 + (A.pk.fwd_bn / 4) + wave * 64 * 64, lane, wnext);
     const float4* wrgb = wpk4 + (A.pk.fwd_rgbh / 4) + wave * 32 * 64;
-    wnext = prefetch_pair(wrgb, 32, lane);
+    const WQuad<1> wrgb0 = prefetch_quad<1>(wrgb, lane);
     __builtin_amdgcn_sched_barrier(0);
     fwd_epilogue<2, false, STASH>(
         acc, wave * 64, act,
         make_rsrc(STASH ? A.st_bn + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff, nullptr, lane);
 
+    STAMP();   // bottleneck done
     // ---- rgb branch hidden: Dense(256+R -> 128)+ReLU; the R per-ray condition columns are
     //      folded into condterm[ray][n] (= cond . W[256:] + bias) by ray_prep ----
     {
-      f32x16 acc1[4][1];
+      f32x16 acc1[2][1];
       zero_acc<1>(acc1);
-      mfma_k_loop<1, true>(acc1, act, 32, wrgb, lane, wnext);
+      mfma_k_loop<1, true>(acc1, act, 16, wrgb, lane, wrgb0);
       const int n = wave * 32 + j;
       const __amdgpu_buffer_rsrc_t st = make_rsrc(STASH ? A.st_rgbh + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4);
-      const EpiAddr ea(lane);
       __syncthreads();
-      uint32_t mb[2] = {0u, 0u};
-      // rows visited by this lane increase with (reg, rb): walk the ray boundaries instead of dividing
+      uint32_t mb = 0u;
+      // rows visited by this lane increase with q: walk the ray boundaries instead of dividing
       int ray = (tile * TILE_ROWS) / A.S;
       int nextb = (ray + 1) * A.S - tile * TILE_ROWS;   // first tile row of the next ray
       float ct = A.condterm[(size_t)min(ray, A.B - 1) * RGB_W + n];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int i = c_row(reg, h);
+      for (int q = 0; q < 8; ++q) {
+        const int g = q_granule(q, h);
+        const float4 a4 = acc_piece<1>(acc1, 0, q);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w};
         float v[4];
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const int pr = 4 * i + rb;
+        for (int e = 0; e < 4; ++e) {
+          const int pr = 4 * g + e;
           while (pr >= nextb) { ++ray; nextb += A.S; ct = A.condterm[(size_t)min(ray, A.B - 1) * RGB_W + n]; }
-          v[rb] = acc1[rb][0][reg] + ct;
+          v[e] = av[e] + ct;
         }
         float4 v4 = make_float4(v[0], v[1], v[2], v[3]);
-        if (STASH) mb[reg >> 3] |= sign_nibble(v4) << (4 * (reg & 7));
+        if (STASH) mb |= sign_nibble(v4) << (4 * q);
         v4.x = relu(v4.x); v4.y = relu(v4.y); v4.z = relu(v4.z); v4.w = relu(v4.w);
-        *reinterpret_cast<float4*>(act + ea(n, reg)) = v4;
-        if (STASH) buf_store4(v4, st, lane * 16, (wave * 16 + reg) * 1024);
+        *reinterpret_cast<float4*>(act + act_addr(n, g)) = v4;
+        if (STASH) buf_store4(v4, st, lane * 16, (wave * 8 + q) * 1024);
       }
-      if (STASH) {
-        uint32_t* bw = A.bits_rgbh + ((size_t)tile * 4 + wave) * 128;
-        bw[lane * 2] = mb[0]; bw[lane * 2 + 1] = mb[1];
-      }
+      if (STASH) A.bits_rgbh[((size_t)tile * 4 + wave) * 64 + lane] = mb;
       __syncthreads();
     }
 
+    STAMP();   // rgb hidden done
     // ---- rgb logits Dense(128->3), sigmoid; sigma activation (models.py:276-277) ----
     {
       const float* __restrict__ wl = prm + A.po.logit_k;   // [128][3]
       float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-      const int k0 = half * 64;
-      const int g = p >> 2, e = p & 3;
-      for (int k = k0; k < k0 + 64; ++k) {
-        const float a = act[k * TILE_ROWS + 4 * (g ^ (k & 7)) + e];
+      const int k0 = part * 32;
+      for (int k = k0; k < k0 + 32; ++k) {
+        const float a = act[act_elem(k, p)];
         s0 = fmaf(a, wl[3 * k], s0); s1 = fmaf(a, wl[3 * k + 1], s1); s2 = fmaf(a, wl[3 * k + 2], s2);
       }
-      if (half == 1) { pe[p] = s0; pe[TILE_ROWS + p] = s1; pe[2 * TILE_ROWS + p] = s2; }
+      pe[(3 * part) * TILE_ROWS + p] = s0; pe[(3 * part + 1) * TILE_ROWS + p] = s1; pe[(3 * part + 2) * TILE_ROWS + p] = s2;
       __syncthreads();
-      if (half == 0) {
-        s0 += pe[p] + prm[A.po.logit_b]; s1 += pe[TILE_ROWS + p] + prm[A.po.logit_b + 1];
-        s2 += pe[2 * TILE_ROWS + p] + prm[A.po.logit_b + 2];
+      if (part == 0) {
+        float t[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          t[c] = (pe[c * TILE_ROWS + p] + pe[(3 + c) * TILE_ROWS + p]) + (pe[(6 + c) * TILE_ROWS + p] + pe[(9 + c) * TILE_ROWS + p]) +
+                 prm[A.po.logit_b + c];
         float4 o;
-        o.x = 1.f / (1.f + expf(-s0)); o.y = 1.f / (1.f + expf(-s1)); o.z = 1.f / (1.f + expf(-s2));
+        o.x = 1.f / (1.f + expf(-t[0])); o.y = 1.f / (1.f + expf(-t[1])); o.z = 1.f / (1.f + expf(-t[2]));
         o.w = sigma_activation(sigma_raw, A.sigma_act);
         A.out4[(size_t)tile * TILE_ROWS + p] = o;
       }
       __syncthreads();   // scratch (aliases pe) is free again for the next tile's prologue
     }
   }
+  if (A.timeline && tid == 0) {   // per-workgroup residency record: start, end (shader clock), HW_ID, XCC_ID
+    unsigned long long* rec = A.timeline + 1024 + 4 * (size_t)blockIdx.x;
+    rec[0] = wg_t0; rec[1] = clock64();
+    rec[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
+    rec[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+  }
 }
 
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream) {
   const size_t lds = (size_t)(ACT_FLOATS + a.PK * TILE_ROWS) * sizeof(float);
+  if (getenv("NRF_DEBUG_OCC")) {
+    int nb = -1;
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nerf_mlp_fwd_kernel<true>, 256, lds);
+    hipFuncAttributes fa;
+    (void)hipFuncGetAttributes(&fa, (const void*)nerf_mlp_fwd_kernel<true>);
+    fprintf(stderr, "[nrf] fwd<true>: lds %zu B, occupancy %d blocks/CU (err %d), regs %d, static lds %zu, scratch %zu\n", lds, nb, (int)e,
+            fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes);
+  }
   if (stash) {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(nerf_mlp_fwd_kernel<true>, dim3(grid), dim3(256), lds, stream, a);
@@ -221,10 +256,10 @@ void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t s
 // small_part layout (floats): db_trunk[8][256] | db_bn[256] | db_rgbh[128] | db_logit[3] | db_alpha
 constexpr int SP_DB_TRUNK = 0, SP_DB_BN = 2048, SP_DB_RGBH = 2304, SP_DB_LOGIT = 2432, SP_DB_ALPHA = 2435;
 
-__global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A) {
+__global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* act = smem;                 // [256][128] swizzled: current dpre tile
-  float* dr = smem + ACT_FLOATS;     // [4][128]: d raw rgb (3) and d raw sigma of the tile rows
+  float* act = smem;                 // [256][64] swizzled: current dpre tile
+  float* dr = smem + ACT_FLOATS;     // [4][64]: d raw rgb (3) and d raw sigma of the tile rows
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,11 +273,11 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
   for (int l = 0; l < TRUNK_DEPTH; ++l) db_trunk[l][0] = db_trunk[l][1] = 0.f;
   float db_bn[2] = {0.f, 0.f};
   float db_rgbh = 0.f;
-  float dsum[4] = {0.f, 0.f, 0.f, 0.f};   // threads < 128: column sums of d_raw (logit / alpha bias grads)
+  float dsum[4] = {0.f, 0.f, 0.f, 0.f};   // threads < 64: column sums of d_raw (logit / alpha bias grads)
 
   const size_t layer_fl = (size_t)A.ntiles * FRAG_TILE_256;   // floats per trunk layer
-  const int wv = wave * 2 * 16 * 1024;                          // bytes: this wave's slice of a tile
-  const EpiAddr ea(lane);
+  const int wv = wave * 2 * 8 * 1024;                           // bytes: this wave's slice of a tile
+  dephase_second_half(A.dephase);
 
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
@@ -257,36 +292,35 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
     {
       const int n = wave * 32 + j;
       const float w0 = prm[A.po.logit_k + 3 * n], w1 = prm[A.po.logit_k + 3 * n + 1], w2 = prm[A.po.logit_k + 3 * n + 2];
-      const uint32_t* bw = A.bits_rgbh + ((size_t)tile * 4 + wave) * 128;
-      const uint32_t mb[2] = {bw[lane * 2], bw[lane * 2 + 1]};
+      const uint32_t mb = A.bits_rgbh[((size_t)tile * 4 + wave) * 64 + lane];
       const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy_rgbh + (size_t)tile * FRAG_TILE_128, FRAG_TILE_128 * 4);
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const int i = c_row(reg, h);
-        const float4 d0 = *reinterpret_cast<const float4*>(dr + 4 * i);
-        const float4 d1 = *reinterpret_cast<const float4*>(dr + TILE_ROWS + 4 * i);
-        const float4 d2 = *reinterpret_cast<const float4*>(dr + 2 * TILE_ROWS + 4 * i);
+      for (int q = 0; q < 8; ++q) {
+        const int g = q_granule(q, h);
+        const float4 d0 = *reinterpret_cast<const float4*>(dr + 4 * g);
+        const float4 d1 = *reinterpret_cast<const float4*>(dr + TILE_ROWS + 4 * g);
+        const float4 d2 = *reinterpret_cast<const float4*>(dr + 2 * TILE_ROWS + 4 * g);
         float4 v4 = make_float4(d0.x * w0 + d1.x * w1 + d2.x * w2, d0.y * w0 + d1.y * w1 + d2.y * w2,
                                 d0.z * w0 + d1.z * w1 + d2.z * w2, d0.w * w0 + d1.w * w1 + d2.w * w2);
-        v4 = mask4(v4, (mb[reg >> 3] >> (4 * (reg & 7))) & 15u);
+        v4 = mask4(v4, (mb >> (4 * q)) & 15u);
         db_rgbh += (v4.x + v4.y) + (v4.z + v4.w);
-        *reinterpret_cast<float4*>(act + ea(n, reg)) = v4;
-        buf_store4(v4, dy, lane * 16, (wave * 16 + reg) * 1024);
+        *reinterpret_cast<float4*>(act + act_addr(n, g)) = v4;
+        buf_store4(v4, dy, lane * 16, (wave * 8 + q) * 1024);
       }
     }
     __syncthreads();
     // ---- per-ray sums of dpre_rgbh (gradient of the per-ray condition columns of the rgb branch):
-    //      thread (n, half) walks 64 tile rows of feature n in LDS and flushes at ray boundaries ----
+    //      thread (n, half) walks 32 tile rows of feature n in LDS and flushes at ray boundaries ----
     {
       const int n = tid & 127, hf = tid >> 7;
-      const int row0 = 64 * hf;
+      const int row0 = 32 * hf;
       const int grow0 = tile * TILE_ROWS + row0;
       int ray = grow0 / A.S;
       int nextb = (ray + 1) * A.S - tile * TILE_ROWS;   // first tile row of the next ray
       const int nvalid = A.rows - tile * TILE_ROWS;      // tile rows >= nvalid are padding
       float ray_sum = 0.f;
 #pragma unroll 1
-      for (int g = row0 / 4; g < row0 / 4 + 16; ++g) {
+      for (int g = row0 / 4; g < row0 / 4 + 8; ++g) {
         const float4 v4 = *reinterpret_cast<const float4*>(act + act_addr(n, g));
         const float v[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -302,14 +336,14 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
       if (ray < A.B && ray_sum != 0.f) atomicAdd(A.dray + (size_t)ray * RGB_W + n, ray_sum);
     }
 
-    f32x16 acc[4][2];
+    f32x16 acc[2][2];
     // ---- d bottleneck = dpre_rgbh . W_rgbh[0:256]^T   (K=128 -> N=256), linear ----
     zero_acc<2>(acc);
     {
       const float4* w0 = wpk4 + (A.pk.bwd_rgbhT / 4) + wave * 32 * 64;
-      mfma_k_loop<2, true>(acc, act, 32, w0, lane, prefetch_pair(w0, 32, lane));
+      mfma_k_loop<2, true>(acc, act, 8, w0, lane, prefetch_quad<2>(w0, lane));
     }
-    WPair wnext = prefetch_pair(wpk4 + (A.pk.bwd_bnT / 4) + wave * 64 * 64, 64, lane);
+    WQuad<2> wnext = prefetch_quad<2>(wpk4 + (A.pk.bwd_bnT / 4) + wave * 64 * 64, lane);
     __builtin_amdgcn_sched_barrier(0);
     {
       const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy_bn + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
@@ -319,11 +353,11 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
         const int n = wave * 64 + 32 * cb + j;
         float bsum = 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
+        for (int q = 0; q < 8; ++q) {
+          const float4 v = acc_piece<2>(acc, cb, q);
           bsum += (v.x + v.y) + (v.z + v.w);
-          *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
-          buf_store4(v, dy, lane * 16, wv + (cb * 16 + reg) * 1024);
+          *reinterpret_cast<float4*>(act + act_addr(n, q_granule(q, h))) = v;
+          buf_store4(v, dy, lane * 16, wv + (cb * 8 + q) * 1024);
         }
         db_bn[cb] += bsum;
       }
@@ -335,12 +369,12 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
 #pragma unroll 1
     for (int l = TRUNK_DEPTH; l >= 1; --l) {
       // the output of this step is dpre_{l-1}; its mask is sign(pre_{l-1}) = bits_trunk[l-1]
-      const uint4 mq = *reinterpret_cast<const uint4*>(A.bits_trunk + (((size_t)(l - 1) * A.ntiles + tile) * 4 + wave) * 256 + lane * 4);
-      const uint32_t mb[4] = {mq.x, mq.y, mq.z, mq.w};
+      const uint2 mq = *reinterpret_cast<const uint2*>(A.bits_trunk + (((size_t)(l - 1) * A.ntiles + tile) * 4 + wave) * 128 + lane * 2);
+      const uint32_t mb[2] = {mq.x, mq.y};
       zero_acc<2>(acc);
       const int woff = (l == TRUNK_DEPTH) ? A.pk.bwd_bnT : A.pk.bwd_LT[l];
-      mfma_k_loop<2, true>(acc, act, 64, wpk4 + (woff / 4) + wave * 64 * 64, lane, wnext);
-      wnext = prefetch_pair(wpk4 + (A.pk.bwd_LT[l > 1 ? l - 1 : 1] / 4) + wave * 64 * 64, 64, lane);
+      mfma_k_loop<2, true>(acc, act, 16, wpk4 + (woff / 4) + wave * 64 * 64, lane, wnext);
+      wnext = prefetch_quad<2>(wpk4 + (A.pk.bwd_LT[l > 1 ? l - 1 : 1] / 4) + wave * 64 * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
       const __amdgpu_buffer_rsrc_t dy =
           make_rsrc(A.dy_trunk + (size_t)(l - 1) * layer_fl + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
@@ -352,17 +386,17 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
         const float wa = (l == TRUNK_DEPTH) ? prm[A.po.alpha_k + n] : 0.f;
         float bsum = 0.f;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int i = c_row(reg, h);
-          float4 v = make_float4(acc[0][cb][reg], acc[1][cb][reg], acc[2][cb][reg], acc[3][cb][reg]);
+        for (int q = 0; q < 8; ++q) {
+          const int g = q_granule(q, h);
+          float4 v = acc_piece<2>(acc, cb, q);
           if (l == TRUNK_DEPTH) {
-            const float4 ds = *reinterpret_cast<const float4*>(dr + 3 * TILE_ROWS + 4 * i);
+            const float4 ds = *reinterpret_cast<const float4*>(dr + 3 * TILE_ROWS + 4 * g);
             v.x = fmaf(ds.x, wa, v.x); v.y = fmaf(ds.y, wa, v.y); v.z = fmaf(ds.z, wa, v.z); v.w = fmaf(ds.w, wa, v.w);
           }
-          v = mask4(v, (mb[2 * cb + (reg >> 3)] >> (4 * (reg & 7))) & 15u);
+          v = mask4(v, (mb[cb] >> (4 * q)) & 15u);
           bsum += (v.x + v.y) + (v.z + v.w);
-          *reinterpret_cast<float4*>(act + ea(n, reg)) = v;
-          buf_store4(v, dy, lane * 16, wv + (cb * 16 + reg) * 1024);
+          *reinterpret_cast<float4*>(act + act_addr(n, g)) = v;
+          buf_store4(v, dy, lane * 16, wv + (cb * 8 + q) * 1024);
         }
         bs[cb] = bsum;
       }
@@ -373,37 +407,34 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
       __syncthreads();
 
       // ---- warp on: d posenc = dpre_4 . W4[256:]^T + dpre_0 . W0^T  (256 -> PK columns).  Wave w owns
-      //      MFMA row block w (tile rows 4i + w) for all 64 columns; the result goes to the dpe tile in
-      //      LDS (aliases dr, dead since the l = 8 step), element (n, row) at n*128 + (row ^ (n & 31)). ----
+      //      MFMA row block w&1 (tile rows 2i + rb) x column block w>>1; the result goes to the dpe tile
+      //      in LDS (aliases dr, dead since the l = 8 step), element (n, row) at n*64 + (row ^ (n & 31)). ----
       if (A.d_points && (l - 1 == SKIP_LAYER || l == 1)) {
         float* dpe = dr;
         const bool first = (l - 1 == SKIP_LAYER);
         const float4* wq = wpk4 + ((first ? A.pk.bwd_L4bT : A.pk.bwd_L0T) / 4) + lane;
-        f32x16 a2[2];
+        const int rb = wave & 1, cb = wave >> 1;
+        f32x16 a2;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { a2[0][r] = 0.f; a2[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) a2[r] = 0.f;
         const int i = lane & 31, kk = lane >> 5;
+        const int aoff = 2 * (i & 1) + rb;
 #pragma unroll 4
         for (int it = 0; it < 64; ++it) {
           const float4 b = wq[it * 64];
           const int k0 = 4 * it + kk;
-          const float4 q0 = *reinterpret_cast<const float4*>(act + act_addr(k0, i));
-          const float4 q1 = *reinterpret_cast<const float4*>(act + act_addr(k0 + 2, i));
-          const float a0 = wave == 0 ? q0.x : wave == 1 ? q0.y : wave == 2 ? q0.z : q0.w;
-          const float a1 = wave == 0 ? q1.x : wave == 1 ? q1.y : wave == 2 ? q1.z : q1.w;
-          a2[0] = mfma32(a0, b.x, a2[0]); a2[1] = mfma32(a0, b.y, a2[1]);
-          a2[0] = mfma32(a1, b.z, a2[0]); a2[1] = mfma32(a1, b.w, a2[1]);
+          const float a0 = act[act_addr(k0, i >> 1) + aoff];
+          const float a1 = act[act_addr(k0 + 2, i >> 1) + aoff];
+          a2 = mfma32(a0, cb ? b.y : b.x, a2);
+          a2 = mfma32(a1, cb ? b.w : b.z, a2);
         }
+        const int n = 32 * cb + j;
+        if (n < A.PK) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          const int n = 32 * cb + j;
-          if (n < A.PK) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-              const int row = 4 * c_row(reg, h) + wave;
-              float* o = dpe + n * TILE_ROWS + (row ^ (n & 31));
-              *o = first ? a2[cb][reg] : *o + a2[cb][reg];
-            }
+          for (int reg = 0; reg < 16; ++reg) {
+            const int row = 2 * c_row(reg, h) + rb;
+            float* o = dpe + n * TILE_ROWS + (row ^ (n & 31));
+            *o = first ? a2[reg] : *o + a2[reg];
           }
         }
         __syncthreads();
@@ -411,7 +442,8 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
           // chain rule through SinusoidalEncoder: d sin(f x) = f cos(f x), d sin(f x + pi/2) = -f sin(f x),
           // with sin / cos taken from the forward posenc stash.
           const int row = tile * TILE_ROWS + tid;
-          const float* pe = A.st_pe + (size_t)tile * A.PK * TILE_ROWS + tid;
+          const int PKS = (A.PK + 31) / 32 * 32;
+          const float* pe = A.st_pe + (size_t)tile * PKS * TILE_ROWS;
           float dx[3];
 #pragma unroll
           for (int c = 0; c < 3; ++c) dx[c] = dpe[c * TILE_ROWS + (tid ^ c)];
@@ -420,7 +452,7 @@ __global__ __launch_bounds__(256) void nerf_mlp_bwd_kernel(const ChainBwdArgs A)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
               const int ns = 3 + 6 * f + c, nc = ns + 3;
-              const float sn = pe[ns * TILE_ROWS], cs = pe[nc * TILE_ROWS];
+              const float sn = pe[frag_index(ns, tid)], cs = pe[frag_index(nc, tid)];
               dx[c] += fr * (cs * dpe[ns * TILE_ROWS + (tid ^ (ns & 31))] - sn * dpe[nc * TILE_ROWS + (tid ^ (nc & 31))]);
             }
           }

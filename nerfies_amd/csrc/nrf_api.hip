@@ -51,6 +51,7 @@ struct WsPlan {
   int wgrad_nwg = 0;
   size_t cond, mse, zero_rgb, slabs;
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
+  size_t timeline;      // [2 levels][4 waves][64] uint64 debug stamps of workgroup 0 of the forward chain kernel
   size_t seg_clock;     // [nsegs] uint64 wall-clock ticks per wgrad segment (cost-model calibration)
   int nreduce_first = 0;   // reduce descriptors [0, nreduce_first) overwrite, the rest accumulate (2nd launch)
   LevelWs L[2];
@@ -231,7 +232,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
                      int vec; int64_t dst; int dst_ld; int rows; int cols; int units; size_t xadd, yadd;
                      size_t* vecoff = nullptr; int accumulate = 0; };
   std::vector<GroupSpec> specs;
-  const int Kb_pe = (h->PK + 31) / 32;
+  const int Kb_pe = (h->PK + 31) / 32;          // posenc stash tiles hold whole 32-feature blocks
+  const int PKS = Kb_pe * 32;
   if (train) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
       LevelWs& L = p.L[lv];
@@ -239,13 +241,13 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       const size_t layer = (size_t)p.ntiles[lv] * FRAG_TILE_256;
       for (int l = 0; l < TRUNK_DEPTH; ++l) {
         if (l == 0) {
-          specs.push_back({lv, SRC_PLAIN, &L.st_pe, h->PK * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
+          specs.push_back({lv, SRC_PLAIN, &L.st_pe, PKS * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
                            po.trunk_k[0], 256, h->P, 256, Kb_pe * 8, 0, 0});
         } else {
           specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
                            po.trunk_k[l], 256, 256, 256, 64, (size_t)(l - 1) * layer, (size_t)l * layer});
           if (l == d.nerf_skip_layer)
-            specs.push_back({lv, SRC_PLAIN, &L.st_pe, h->PK * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
+            specs.push_back({lv, SRC_PLAIN, &L.st_pe, PKS * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
                              po.trunk_k[l] + 256 * 256, 256, h->P, 256, Kb_pe * 8, 0, (size_t)l * layer});
         }
       }
@@ -266,13 +268,13 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
         auto push = [&](GroupSpec g) { g.accumulate = accu; specs.push_back(g); };
         for (int l = 0; l < WARP_DEPTH; ++l) {
           if (l == 0) {
-            push({lv, SRC_PLAIN, &L.w_st_win, h->PKw * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+            push({lv, SRC_PLAIN, &L.w_st_win, Kb_in * 32 * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
                   w.trunk_k[0], WARP_W, h->Win, WARP_W, Kb_in * 4, 0, 0});
           } else {
             push({lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
                   w.trunk_k[l], WARP_W, WARP_W, WARP_W, 16, (size_t)(l - 1) * wl, (size_t)l * wl});
             if (l == WARP_SKIP)
-              push({lv, SRC_PLAIN, &L.w_st_win, h->PKw * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+              push({lv, SRC_PLAIN, &L.w_st_win, Kb_in * 32 * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
                     w.trunk_k[l] + (int64_t)WARP_W * WARP_W, WARP_W, h->Win, WARP_W, Kb_in * 4, 0, (size_t)l * wl});
           }
         }
@@ -364,18 +366,18 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
     L.weights = take((size_t)p.rows[lv]);
     L.condterm = take((size_t)B * RGB_W);
     if (train) {
-      L.st_pe = take(nt * h->PK * TILE_ROWS);
+      L.st_pe = take(nt * PKS * TILE_ROWS);
       L.st_h = take(nt * FRAG_TILE_256 * TRUNK_DEPTH);
       L.st_bn = take(nt * FRAG_TILE_256);
       L.st_rgbh = take(nt * FRAG_TILE_128);
-      L.bits_trunk = take(nt * 4 * 256 * TRUNK_DEPTH);
-      L.bits_rgbh = take(nt * 4 * 128);
+      L.bits_trunk = take(nt * 4 * 128 * TRUNK_DEPTH);
+      L.bits_rgbh = take(nt * 4 * 64);
       L.d_raw4 = take(nt * TILE_ROWS * 4);
       L.dy_trunk = take(nt * FRAG_TILE_256 * TRUNK_DEPTH);
       L.dy_bn = take(nt * FRAG_TILE_256);
       L.dy_rgbh = take(nt * FRAG_TILE_128);
       L.dray = take((size_t)B * RGB_W);
-      L.small_part = take((size_t)G * SMALL_PART);
+      L.small_part = take((size_t)2 * G * SMALL_PART);
       L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
     }
     if (h->warp) {
@@ -383,19 +385,20 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       L.points_raw = take(nt * TILE_ROWS * 3);
       if (train) {
         L.d_points = take(nt * TILE_ROWS * 3);
-        L.w_st_win = take(nt * h->PKw * TILE_ROWS);
+        L.w_st_win = take(nt * ((h->PKw + 31) / 32 * 32) * TILE_ROWS);
         L.w_st_h = take(nt * FRAG_TILE_128 * WARP_DEPTH);
         L.w_st_wv = take(nt * TILE_ROWS * 8);
-        L.w_bits = take(nt * 4 * 128 * WARP_DEPTH);
+        L.w_bits = take(nt * 4 * 64 * WARP_DEPTH);
         L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
         L.w_dw4 = take(nt * TILE_ROWS * 4);
         L.w_dv4 = take(nt * TILE_ROWS * 4);
-        L.w_small_part = take((size_t)G * WARP_SMALL_PART);
+        L.w_small_part = take((size_t)2 * G * WARP_SMALL_PART);
       }
     }
   }
   if (h->warp) p.warp_wpk = take(h->wpk.total);
   p.seg_clock = take(2 * (p.segs.size() + 1));
+  p.timeline = take(2 * (2 * 4 * 64 + 1024 + 4 * 4096));
 
   // ---- pack descriptors (both levels, forward and transposed streams) ----
   for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -476,7 +479,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
       const LevelWs& L = p.L[lv];
-      const int grid = p.ntiles[lv] < G ? p.ntiles[lv] : G;
+      const int grid = p.ntiles[lv] < 2 * G ? p.ntiles[lv] : 2 * G;   // chain kernels: two workgroups per CU
       auto small = [&](int64_t dst, int cols, int sp_off) {
         ReduceDesc r;
         memset(&r, 0, sizeof(r));
@@ -585,6 +588,8 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
   a.points = nullptr; a.out4 = reinterpret_cast<float4*>(ws + L.out4);
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
   a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation;
+  a.dephase = getenv("NRF_DEPHASE") ? atoi(getenv("NRF_DEPHASE")) : 3;
+  a.timeline = getenv("NRF_TIMELINE") ? reinterpret_cast<unsigned long long*>(ws + p.timeline) + lv * (256 + 512 + 4 * 2048) : nullptr;
   if (train) {
     a.st_pe = ws + L.st_pe; a.st_h = ws + L.st_h; a.st_bn = ws + L.st_bn; a.st_rgbh = ws + L.st_rgbh;
     a.bits_trunk = reinterpret_cast<uint32_t*>(ws + L.bits_trunk);
@@ -676,7 +681,8 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
       pf.end(stream);
     }
     ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train);
-    const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    const int gmul = getenv("NRF_GRID_MUL") ? atoi(getenv("NRF_GRID_MUL")) : 2;
+    const int grid = p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus;   // two workgroups per CU
     if (warp_on) {
       pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * p.rows[lv], stream);
       launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train), train, grid, stream);
@@ -747,7 +753,8 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     a.small_part = ws + L.small_part;
     if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
     a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
-    const int grid = p.ntiles[lv] < h->num_cus ? p.ntiles[lv] : h->num_cus;
+    a.dephase = getenv("NRF_DEPHASE") ? atoi(getenv("NRF_DEPHASE")) : 3;
+    const int grid = p.ntiles[lv] < 2 * h->num_cus ? p.ntiles[lv] : 2 * h->num_cus;   // two workgroups per CU
     h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
     launch_chain_bwd(a, grid, stream);
     h->prof.end(stream);
@@ -823,14 +830,14 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   h->d = d;
   h->nlevels = d.num_fine_samples > 0 ? 2 : 1;
   h->P = 3 + 6 * d.num_nerf_point_freqs;
-  h->PK = (h->P + 3) / 4 * 4;
+  h->PK = (h->P + 15) / 16 * 16;                  // K of the posenc GEMMs: whole 16-k quads of the MFMA loop
   h->V = d.use_viewdirs ? 3 + 6 * d.num_nerf_viewdir_freqs : 0;
   h->app_in_cond = (d.use_appearance_metadata && d.use_alpha_condition) ? 1 : 0;   // models.py:206
   h->warp = d.use_warp != 0;
   if (h->warp) {
     h->Fw = d.num_warp_freqs; h->G = d.num_warp_features;
     h->Win = 3 + 6 * h->Fw + h->G;                 // [annealed posenc, GLO code] (warping.py:326-327)
-    h->PKw = (h->Win + 7) / 8 * 8;
+    h->PKw = (h->Win + 15) / 16 * 16;
   }
   h->R = h->V + (h->app_in_cond ? d.num_appearance_features : 0) + (d.use_camera_metadata ? d.num_camera_features : 0);
   if (h->R > 64) { delete h; return fail(NRF_E_SHAPE, "rgb condition wider than 64"); }
@@ -927,6 +934,22 @@ int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n) {
   }
   *n = cnt;
   return NRF_OK;
+}
+
+int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* float_offset) {
+  if (!h || !name || !float_offset) return fail(NRF_E_NULL, "null");
+  if (level < 0 || level > 1 || h->plan.B < 0) return fail(NRF_E_STATE, "no workspace plan yet / bad level");
+  const LevelWs& L = h->plan.L[level];
+  const struct { const char* n; size_t v; } tab[] = {
+      {"st_pe", L.st_pe}, {"st_h", L.st_h}, {"st_bn", L.st_bn}, {"st_rgbh", L.st_rgbh}, {"dy_trunk", L.dy_trunk},
+      {"dy_bn", L.dy_bn}, {"dy_rgbh", L.dy_rgbh}, {"d_raw4", L.d_raw4}, {"z", L.z}, {"out4", L.out4},
+      {"wpoints", L.wpoints}, {"d_points", L.d_points}, {"w_st_win", L.w_st_win}, {"w_st_h", L.w_st_h},
+      {"w_st_wv", L.w_st_wv}, {"w_dy", L.w_dy}, {"w_dw4", L.w_dw4}, {"w_dv4", L.w_dv4},
+      {"w_bits", L.w_bits}, {"bits_trunk", L.bits_trunk}, {"bits_rgbh", L.bits_rgbh},
+      {"timeline", h->plan.timeline + (size_t)level * 2 * (256 + 512 + 4 * 2048)}};
+  for (const auto& t : tab)
+    if (!strcmp(t.n, name)) { *float_offset = (int64_t)t.v; return NRF_OK; }
+  return fail(NRF_E_SHAPE, "unknown workspace buffer name");
 }
 
 int nrf_debug_wgrad_segments(nrf_handle h, const void* workspace, double* out, int32_t* n) {

@@ -6,7 +6,7 @@
 
 namespace nrf {
 
-constexpr int TILE_ROWS = 128;   // rows (ray samples) per workgroup tile
+constexpr int TILE_ROWS = 64;    // rows (ray samples) per workgroup tile; two workgroups per CU
 constexpr int TRUNK_W = 256;     // NeRF trunk width the MFMA chain is built for
 constexpr int RGB_W = 128;       // rgb branch width
 constexpr int TRUNK_DEPTH = 8;
@@ -73,8 +73,10 @@ struct ChainFwdArgs {
   const float* points;       // [rows][3] warped points, or nullptr -> o + z d
   float4* out4;              // [ntiles*128] (r,g,b,sigma) post-activation
   int S, B, rows, ntiles;
-  int F, P, PK;              // point freqs, 3+6F, P rounded up to a multiple of 4
+  int F, P, PK;              // point freqs, 3+6F, P rounded up to a multiple of 16
   int sigma_act;
+  int dephase;               // s_sleep(127) count for the second half of the grid (chain_common.h)
+  unsigned long long* timeline;   // debug: [4 waves][64] shader-clock stamps of workgroup 0 (or nullptr)
   // activation stash (training only)
   float* st_pe;              // [ntiles][PK][128]
   float* st_h;               // [8][ntiles][256*128]  h1..h8, fragment-native
@@ -101,8 +103,9 @@ struct ChainBwdArgs {
   float* small_part;         // [gridDim.x][SMALL_PART]
   // warp on: gradient w.r.t. the (warped) sample points through both posenc inputs of the trunk
   float* d_points;           // [ntiles*128][3] or nullptr
-  const float* st_pe;        // [ntiles][PK][128] posenc stash of the forward pass
+  const float* st_pe;        // posenc stash of the forward pass
   int F, P, PK;
+  int dephase;
 };
 
 // SE3Field forward (warping.py:322-353): x = o + z d (or explicit points) -> warped points.

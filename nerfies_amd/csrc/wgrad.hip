@@ -1,70 +1,70 @@
 // Weight-gradient GEMMs  dW[k][n] = sum_rows X[row][k] * dY[row][n]  for every dense layer
-// of the NeRF MLPs (the transpose jax.grad builds for modules.MLP, modules.py:41-58).
+// of the NeRF MLPs and of the SE3 trunk (the transpose jax.grad builds for modules.MLP,
+// modules.py:41-58).
 //
 // The reduction runs over rows (ray samples): 65k-196k per MLP, output only 256x256.  Each
-// workgroup owns one split-K slice (a range of 128-row tiles) of one layer and produces a
-// full [Kb*32][Nb*32] partial in registers: 8 waves x (<=4 x 2) 32x32 fp32 MFMA blocks, so X
-// and dY stream from HBM exactly once.  Operands are staged through LDS in 32-row chunks
-// (double buffered, one barrier per chunk); both are read feature-major so one ds_read_b128
-// yields the operand of 4 MFMA k-steps.  Partials go to slabs, summed by reduce_kernel.
+// workgroup walks a stream-K share of the (layer, 64-row tile) work list and, per segment, holds
+// a full [Kb*32][Nb*32] partial in registers: 8 waves x (<=4 x 2) 32x32 fp32 MFMA blocks, so X
+// and dY stream from HBM exactly once.  Both operands live in HBM in "fragment" order
+// (chain_common.h): a 32-row chunk of 32 features is a run of 4 KiB that is copied VERBATIM into
+// LDS with global_load_lds (1 KiB per wave instruction, no staging registers, no ds_write, no
+// swizzle) and read back as MFMA operands with conflict-free ds_read_b128: the float4 a lane
+// receives is 4 consecutive rows = the k of 4 MFMA steps, identical for X and dY.
+// Double buffered, one barrier per chunk.  Partials go to slabs, summed by reduce_kernel.
 #include "nrf_internal.h"
 
 namespace nrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_LDP = 36;                    // LDS pitch (32 rows + 4 pad) -> conflict-free b128
-constexpr int WG_OPER = 256 * WG_LDP;         // floats per operand per stage
+constexpr int WG_OPER = 256 * 32;             // floats per operand per stage (256 features x 32 rows)
 constexpr int WG_STAGE = 2 * WG_OPER;
 constexpr int WG_VEC = 2 * WG_STAGE;          // float offset of the [2 stages][32 rows] float4 vec staging
+constexpr int WG_VSTRIDE = 256;               // floats per vec stage (one 1 KiB global_load_lds)
+constexpr int WG_LDS_FLOATS = WG_VEC + 2 * WG_VSTRIDE;
 
-struct Granule { float4 v; int lds; };
+typedef __attribute__((address_space(3))) void lds_void;
 
-// granule `gid` of 32-row chunk `c` of a tile: 4 consecutive rows of one feature.
-__device__ __forceinline__ bool granule_src(const float* __restrict__ base, int kind, int kvalid, int nblocks,
-                                            int c, int gid, const float4*& src, int& lds) {
-  if (kind == SRC_FRAG256) {
-    const int ln = gid & 63, q = (gid >> 6) & 3, blk = gid >> 8;   // blk = w*2+cb
-    if (blk >= nblocks) return false;
-    src = reinterpret_cast<const float4*>(base) + (blk * 16 + 4 * c + q) * 64 + ln;
-    lds = (32 * blk + (ln & 31)) * WG_LDP + 4 * (q + 4 * (ln >> 5));
-    return true;
-  } else if (kind == SRC_FRAG128) {
-    const int ln = gid & 63, q = (gid >> 6) & 3, blk = gid >> 8;   // blk = w
-    if (blk >= nblocks) return false;
-    src = reinterpret_cast<const float4*>(base) + (blk * 16 + 4 * c + q) * 64 + ln;
-    lds = (32 * blk + (ln & 31)) * WG_LDP + 4 * (q + 4 * (ln >> 5));
-    return true;
-  } else {  // SRC_PLAIN: [k][128 rows]
-    const int g = gid & 7, k = gid >> 3;
-    if (k >= nblocks * 32) return false;
-    lds = k * WG_LDP + 4 * g;
-    src = (k < kvalid) ? reinterpret_cast<const float4*>(base + k * TILE_ROWS + 32 * c + 4 * g) : nullptr;
-    return true;
+// Issues this wave's share of the global->LDS copies of chunk `c` (32 rows) of one operand tile:
+// pieces (blk, qq), blk < nblocks, qq < 4; piece id = blk*4 + qq is dealt round-robin to the 8 waves.
+__device__ __forceinline__ void stage_operand(const float* __restrict__ tile_base, int nblocks, int c, float* lds_oper,
+                                              int wave, int lane) {
+  const int npieces = nblocks * 4;
+  for (int pid = wave; pid < npieces; pid += 8) {
+    const int blk = pid >> 2, qq = pid & 3;
+    const float* src = tile_base + ((size_t)(blk * 8 + 4 * c + qq) * 64 + lane) * 4;
+    float* dst = lds_oper + pid * 256;   // wave-uniform base; the hardware adds lane * 16 bytes
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, 0);
   }
 }
 
 template <int NRB>
 __device__ __forceinline__ void wgrad_compute(f32x16 (&acc)[NRB][2], const float* Xs, const float* Ys,
                                               int kb0, int nb0, int lane) {
-  const int i = lane & 31, kk = lane >> 5;
-#pragma unroll
-  for (int g4 = 0; g4 < 4; ++g4) {
-    float4 a[NRB], b[2];
+  float4 a[2][NRB], b[2][2];
+  auto load = [&](int qq, int buf) {
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb)
-      a[rb] = *reinterpret_cast<const float4*>(Xs + (32 * (kb0 + rb) + i) * WG_LDP + 8 * g4 + 4 * kk);
+      a[buf][rb] = *reinterpret_cast<const float4*>(Xs + (((kb0 + rb) * 4 + qq) * 64 + lane) * 4);
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb)
-      b[cb] = *reinterpret_cast<const float4*>(Ys + (32 * (nb0 + cb) + i) * WG_LDP + 8 * g4 + 4 * kk);
+      b[buf][cb] = *reinterpret_cast<const float4*>(Ys + (((nb0 + cb) * 4 + qq) * 64 + lane) * 4);
+  };
+  load(0, 0);
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) {
+    const int cur = qq & 1;
+    if (qq + 1 < 4) load(qq + 1, cur ^ 1);
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int rb = 0; rb < NRB; ++rb) {
-        const float av = s == 0 ? a[rb].x : s == 1 ? a[rb].y : s == 2 ? a[rb].z : a[rb].w;
+        const float4 av4 = a[cur][rb];
+        const float av = s == 0 ? av4.x : s == 1 ? av4.y : s == 2 ? av4.z : av4.w;
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-          const float bv = s == 0 ? b[cb].x : s == 1 ? b[cb].y : s == 2 ? b[cb].z : b[cb].w;
+          const float4 bv4 = b[cur][cb];
+          const float bv = s == 0 ? bv4.x : s == 1 ? bv4.y : s == 2 ? bv4.z : bv4.w;
           acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[rb][cb], 0, 0, 0);
         }
       }
@@ -72,26 +72,10 @@ __device__ __forceinline__ void wgrad_compute(f32x16 (&acc)[NRB][2], const float
   }
 }
 
-// narrow dY columns on the VALU: va[c] += sum_rows X[row][k] * vec[row][c] for this thread's k and 16 rows
-__device__ __forceinline__ void vec_accumulate(float (&va)[4], const float* Xs, const float* vs, int kmax) {
-  const int k = threadIdx.x & 255, hf = threadIdx.x >> 8;
-  if (k >= kmax) return;
-#pragma unroll
-  for (int g = 0; g < 4; ++g) {
-    const float4 xv = *reinterpret_cast<const float4*>(Xs + k * WG_LDP + 16 * hf + 4 * g);
-    const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float4 dv = *reinterpret_cast<const float4*>(vs + 4 * (16 * hf + 4 * g + e));
-      va[0] = fmaf(xe[e], dv.x, va[0]); va[1] = fmaf(xe[e], dv.y, va[1]);
-      va[2] = fmaf(xe[e], dv.z, va[2]); va[3] = fmaf(xe[e], dv.w, va[3]);
-    }
-  }
-}
-
 template <int NRB>
 __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int kb0, int nb0) {
   const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   f32x16 acc[NRB][2];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
@@ -100,43 +84,23 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
 
-  const int nchunks = (T.tile_end - T.tile_begin) * 4;
-  float4 rx[4], ry[4];
-  int lx[4], ly[4];
-  bool vx[4], vy[4];
-
-  auto fetch = [&](int ci) {
-    const int tile = T.tile_begin + (ci >> 2), c = ci & 3;
-    const float* xb = T.X + (size_t)tile * T.x_tile_stride;
-    const float* yb = T.dY + (size_t)tile * T.dy_tile_stride;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float4* s;
-      vx[m] = granule_src(xb, T.x_kind, T.x_kvalid, T.Kb, c, tid + 512 * m, s, lx[m]);
-      rx[m] = (vx[m] && s) ? *s : make_float4(0.f, 0.f, 0.f, 0.f);
-      vy[m] = granule_src(yb, T.dy_kind, 1 << 30, T.Nb, c, tid + 512 * m, s, ly[m]);
-      ry[m] = (vy[m] && s) ? *s : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+  const int nchunks = (T.tile_end - T.tile_begin) * 2;
+  auto stage = [&](int ci) {
+    const int tile = T.tile_begin + (ci >> 1), c = ci & 1;
+    float* Xs = smem + (ci & 1) * WG_STAGE;
+    stage_operand(T.X + (size_t)tile * T.x_tile_stride, T.Kb, c, Xs, wave, lane);
+    stage_operand(T.dY + (size_t)tile * T.dy_tile_stride, T.Nb, c, Xs + WG_OPER, wave, lane);
   };
-  auto commit = [&](int stage) {
-    float* Xs = smem + stage * WG_STAGE;
-    float* Ys = Xs + WG_OPER;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      if (vx[m]) *reinterpret_cast<float4*>(Xs + lx[m]) = rx[m];
-      if (vy[m]) *reinterpret_cast<float4*>(Ys + ly[m]) = ry[m];
-    }
-  };
-
-  if (nchunks > 0) { fetch(0); commit(0); }
-  __syncthreads();
   const bool active = kb0 < T.Kb;   // narrow K (Kb < number of k wave groups): surplus waves only stage
+
+  if (nchunks > 0) stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   for (int ci = 0; ci < nchunks; ++ci) {
-    const bool more = ci + 1 < nchunks;
-    if (more) fetch(ci + 1);
+    if (ci + 1 < nchunks) stage(ci + 1);
     const float* Xs = smem + (ci & 1) * WG_STAGE;
     if (active) wgrad_compute<NRB>(acc, Xs, Xs + WG_OPER, kb0, nb0, lane);
-    if (more) commit((ci + 1) & 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's copies of the next chunk have landed
     __syncthreads();
   }
   if (!active) return;
@@ -154,45 +118,51 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int 
       }
 }
 
-// Vector-column task (Nb == 0): vslab[hf][k][c] = sum_rows X[row][k] * vec[row][c] -- the weight
-// gradients of the two narrow heads (alpha: X = h8, vec.w ; rgb logits: X = rgb hidden, vec.xyz).
+// Vector-column task (Nb == 0): vslab[kk][k][c] = sum_rows X[row][k] * vec[row][c] -- the weight
+// gradients of the narrow heads (alpha: X = h8, vec.w ; rgb logits: X = rgb hidden, vec.xyz ;
+// SE3 w / v heads).  Thread (k = feature, kk): its float4s of a staged chunk are rows
+// 4g..4g+3 with g = (qq&1) + 2 kk + 4 (qq>>1) of the chunk.
 __device__ __forceinline__ void wgrad_vec_body(const WgradTask& T, float* smem) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float va[4] = {0.f, 0.f, 0.f, 0.f};
-  const int nchunks = (T.tile_end - T.tile_begin) * 4;
-  float4 rx[4], rvec = make_float4(0.f, 0.f, 0.f, 0.f);
-  int lx[4];
-  bool vx[4];
-  auto fetch = [&](int ci) {
-    const int tile = T.tile_begin + (ci >> 2), c = ci & 3;
-    const float* xb = T.X + (size_t)tile * T.x_tile_stride;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-      const float4* s;
-      vx[m] = granule_src(xb, T.x_kind, T.x_kvalid, T.Kb, c, tid + 512 * m, s, lx[m]);
-      rx[m] = (vx[m] && s) ? *s : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int nchunks = (T.tile_end - T.tile_begin) * 2;
+  const int k = tid & 255, kk = tid >> 8;
+  auto stage = [&](int ci) {
+    const int tile = T.tile_begin + (ci >> 1), c = ci & 1;
+    stage_operand(T.X + (size_t)tile * T.x_tile_stride, T.Kb, c, smem + (ci & 1) * WG_STAGE, wave, lane);
+    if (wave == 0) {   // 32 rows x float4, plain row order (lanes 32..63 copy 512 B of slack that is never read)
+      float* dst = smem + WG_VEC + (ci & 1) * WG_VSTRIDE;
+      const int r = lane & 31;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(T.vec + (size_t)tile * TILE_ROWS + 32 * c + r), (lds_void*)dst, 16, 0, 0);
     }
-    if (tid < 32) rvec = T.vec[(size_t)tile * TILE_ROWS + 32 * c + tid];
   };
-  auto commit = [&](int stage) {
-    float* Xs = smem + stage * WG_STAGE;
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-      if (vx[m]) *reinterpret_cast<float4*>(Xs + lx[m]) = rx[m];
-    if (tid < 32) *reinterpret_cast<float4*>(smem + WG_VEC + stage * 128 + 4 * tid) = rvec;
-  };
-  if (nchunks > 0) { fetch(0); commit(0); }
+  if (nchunks > 0) stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int ci = 0; ci < nchunks; ++ci) {
-    const bool more = ci + 1 < nchunks;
-    if (more) fetch(ci + 1);
-    vec_accumulate(va, smem + (ci & 1) * WG_STAGE, smem + WG_VEC + (ci & 1) * 128, T.Kb * 32);
-    if (more) commit((ci + 1) & 1);
+    if (ci + 1 < nchunks) stage(ci + 1);
+    if (k < T.Kb * 32) {
+      const float* Xs = smem + (ci & 1) * WG_STAGE;
+      const float* vs = smem + WG_VEC + (ci & 1) * WG_VSTRIDE;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const float4 xv = *reinterpret_cast<const float4*>(Xs + ((((k >> 5) * 4 + qq) * 64) + (k & 31) + 32 * kk) * 4);
+        const float xe[4] = {xv.x, xv.y, xv.z, xv.w};
+        const int g = (qq & 1) + 2 * kk + 4 * (qq >> 1);   // granule within the 32-row chunk
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float4 dv = *reinterpret_cast<const float4*>(vs + 4 * (4 * g + e));
+          va[0] = fmaf(xe[e], dv.x, va[0]); va[1] = fmaf(xe[e], dv.y, va[1]);
+          va[2] = fmaf(xe[e], dv.z, va[2]); va[3] = fmaf(xe[e], dv.w, va[3]);
+        }
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
-  const int k = tid & 255, hf = tid >> 8;
   if (k < T.Kb * 32)
-    *reinterpret_cast<float4*>(T.vslab + ((size_t)hf * T.Kb * 32 + k) * 4) = make_float4(va[0], va[1], va[2], va[3]);
+    *reinterpret_cast<float4*>(T.vslab + ((size_t)kk * T.Kb * 32 + k) * 4) = make_float4(va[0], va[1], va[2], va[3]);
 }
 
 __device__ __forceinline__ void wgrad_run_task(const WgradTask& T, float* smem) {
@@ -237,7 +207,7 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict
 
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   unsigned long long* seg_clock, hipStream_t stream) {
-  const size_t lds = (size_t)(2 * WG_STAGE + 256) * sizeof(float);
+  const size_t lds = (size_t)WG_LDS_FLOATS * sizeof(float);
   (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws, seg_clock);
 }

@@ -68,7 +68,7 @@ EXPORTS = [
     'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',
     'nrf_workspace_bytes', 'nrf_forward', 'nrf_backward', 'nrf_train_step_loss_grad', 'nrf_adam_step',
     'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf', 'nrf_profile_enable', 'nrf_profile_read',
-    'nrf_debug_wgrad_segments',
+    'nrf_debug_wgrad_segments', 'nrf_debug_ws_offset',
 ]
 
 _lib = None
@@ -106,6 +106,7 @@ def load_library(path=None):
       'nrf_profile_enable': [vp, i32],
       'nrf_profile_read': [vp, C.POINTER(ProfileEntry), C.POINTER(i32)],
       'nrf_debug_wgrad_segments': [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)],
+      'nrf_debug_ws_offset': [vp, C.c_char_p, i32, C.POINTER(i64)],
   }
   for name, argtypes in sigs.items():
     fn = getattr(lib, name)

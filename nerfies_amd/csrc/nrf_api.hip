@@ -196,7 +196,7 @@ void build_pack_offsets(nrf_handle h) {
   for (int l = 1; l < TRUNK_DEPTH; ++l) pk.bwd_LT[l] = take(256 * 256);
   pk.bwd_L0T = pk.bwd_L4bT = 0;
   if (h->warp) { pk.bwd_L0T = take(256 * 64); pk.bwd_L4bT = take(256 * 64); }
-  pk.total = o + 2048;   // slack: the K loop prefetches one pair past a layer's last weights
+  pk.total = o + 4096;   // slack: the K loop prefetches two quads past a layer's last weights
   if (h->warp) {
     WarpPackOffsets& w = h->wpk;
     int ow = 0;
@@ -206,7 +206,7 @@ void build_pack_offsets(nrf_handle h) {
     w.fwd_L4b = takew(h->PKw * WARP_W);
     w.bwd_LT[0] = 0;
     for (int l = 1; l < WARP_DEPTH; ++l) w.bwd_LT[l] = takew(WARP_W * WARP_W);
-    w.total = ow + 2048;
+    w.total = ow + 4096;
   }
 }
 
@@ -293,14 +293,16 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
   size_t o = 0;
   auto take = [&](size_t n) { size_t r = o; o = align_up(o + n, ALIGN_F); return r; };
   // ---- stream-K partition of the wgrad work: equal cost per workgroup, one workgroup per CU ----
-  // cost of one 128-row tile of a group, in units of a full 256x256 layer tile; the narrow groups
+  // cost of one 64-row tile of a group, in units of a full 256x256 layer tile; the narrow groups
   // are staging/latency bound, so they are charged more than their MFMA share.
   auto env_cost = [](const char* name, double dflt) {
     const char* e = getenv(name);
     return e ? atof(e) : dflt;
   };
-  const double c_vec256 = env_cost("NRF_COST_VEC256", 0.35), c_vec128 = env_cost("NRF_COST_VEC128", 0.20),
-               c_pe = env_cost("NRF_COST_PE", 0.45), c_rgbh = env_cost("NRF_COST_RGBH", 0.65);
+  // measured with scripts/wgrad_calib.py (per-segment wall clocks, least squares), relative to a 256x256 tile
+  const double c_vec256 = env_cost("NRF_COST_VEC256", 0.157), c_vec128 = env_cost("NRF_COST_VEC128", 0.121),
+               c_pe = env_cost("NRF_COST_PE", 0.335), c_rgbh = env_cost("NRF_COST_RGBH", 0.571),
+               c_seg = env_cost("NRF_COST_SEG", 0.5);   // fixed cost of opening a segment (pipeline fill + slab flush), in tiles
   auto tile_cost = [&](const GroupSpec& sp) -> double {
     if (sp.Nb == 0) return sp.Kb == 8 ? c_vec256 : c_vec128;   // vector columns only (VALU + HBM stream)
     const double mm = (double)sp.Kb * sp.Nb / 64.0;
@@ -311,6 +313,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
     double total = 0;
     for (auto& sp : specs) total += tile_cost(sp) * p.ntiles[sp.lv];
     const int nwg = G;
+    total += c_seg * (nwg + (double)specs.size());   // every workgroup and every group boundary opens a segment
     const double quota = total / nwg;
     p.seg_begin.assign(1, 0);
     int w = 0;
@@ -320,7 +323,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       int t0 = 0;
       const int nt = p.ntiles[specs[gi].lv];
       while (t0 < nt) {
-        int take_n = (int)floor(room / c + 1e-9);
+        int take_n = (int)floor((room - c_seg) / c + 1e-9);
         if (take_n <= 0 && w < nwg - 1) {            // this workgroup is full: move on
           p.seg_begin.push_back((int)p.segs.size());
           ++w; room += quota;
@@ -332,7 +335,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
         p.segs.push_back({(int)gi, t0, t0 + take_n, nsplit[gi]});
         nsplit[gi] += 1;
         t0 += take_n;
-        room -= take_n * c;
+        room -= c_seg + take_n * c;
       }
     }
     while ((int)p.seg_begin.size() < nwg + 1) p.seg_begin.push_back((int)p.segs.size());

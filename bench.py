@@ -27,6 +27,19 @@ import torch.distributed as dist
 RAYS_PER_GPU = 1024
 N_COARSE, N_FINE, POINT_FREQS = 64, 128, 8
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# profile name -> kernel symbol in profiles/hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 run)
+TRAFFIC_KERNEL = {'wgrad': 'nrf::wgrad_kernel'}
+
+
+def hbm_traffic(profile_name):
+  """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/hbm_traffic.json:
+  FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), or None when that kernel has no unambiguous entry."""
+  path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
+  sym = TRAFFIC_KERNEL.get(profile_name)
+  if sym is None or not os.path.exists(path):
+    return None
+  k = json.load(open(path)).get('kernels', {}).get(sym)
+  return None if k is None else k['fetch_bytes'] + k['write_bytes']
 
 
 class Cfg:
@@ -175,7 +188,7 @@ def main():
                                'stratified, fwd+MSE+bwd+grad all-reduce+Adam', 'rays_per_gpu': RAYS_PER_GPU,
                    'global_batch': world * RAYS_PER_GPU, 'parallelism': f'ray-shard dp{world}'},
         'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': hbm_traffic(dom['name']),
                      'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']},
         'step_tflops': step_flops / (ms_per_step * 1e-3) / 1e12,
         'step_frac_of_fp32_mfma_peak': step_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),

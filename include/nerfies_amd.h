@@ -180,6 +180,36 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
                              const nrf_rand* rnd, float* grad_params, float* stats,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Background-point regulariser of training.compute_background_loss (training.py:117-135, 248-259).  The
+ * caller draws the warp id per point (random.choice over model.warp_ids) and adds the N(0, noise_std)
+ * noise; the library warps the points with the shared SE3 field (create_warp_field(num_batch_dims=1),
+ * models.py:165-184), evaluates  weight * mean(general_loss_with_squared_residual(|x'-x|^2, alpha, scale))
+ * (utils.py:264-331) and ADDS its parameter gradient to grad_params. */
+typedef struct nrf_background {
+  int32_t num_points;
+  const float* points;      /* (N,3) noised points */
+  const int32_t* warp_ids;  /* (N,) */
+  float loss_weight;        /* scalar_params.background_loss_weight */
+  float loss_alpha;         /* -2 (training.py:119) */
+  float loss_scale;         /* 0.001 */
+} nrf_background;
+
+/* nrf_train_step_loss_grad + the background regulariser (bg may be NULL).  stats[5] = mean background loss
+ * (unweighted, training.py:259), stats[4] includes weight * stats[5].  The workspace must come from
+ * nrf_workspace_bytes_ex with the same num_background_points. */
+int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
+                                const nrf_step_scalars* scalars, const nrf_rand* rnd, const nrf_background* bg,
+                                float* grad_params, float* stats, void* workspace, size_t workspace_bytes,
+                                void* stream);
+int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points,
+                           size_t* bytes);
+
+/* warping.SE3Field on arbitrary points with one warp id per point: model.create_warp_field(num_batch_dims=1)
+ * .apply(points, metadata, warp_extra, False, False) (models.py:165-184, warping.py:355-389). */
+int nrf_warp_points_workspace_bytes(nrf_handle h, int32_t num_points, size_t* bytes);
+int nrf_warp_points(nrf_handle h, const float* params, const float* points, const int32_t* warp_ids, int32_t num_points,
+                    const nrf_step_scalars* scalars, float* warped, void* workspace, size_t workspace_bytes, void* stream);
+
 /* flax.optim.Adam.apply_gradient (training.py:268-269; flax 0.3.4 optim/adam.py):
  * g = grad*grad_scale (grad_scale = 1/world_size folds lax.pmean, training.py:266),
  * m,v updated in place, step = number of updates already applied.  Hyper-parameters are doubles

@@ -43,7 +43,7 @@ struct LevelWs {   // float offsets from the workspace base, per level (0 = coar
 struct WsPlan {
   int B = -1;
   uint32_t flags = 0;
-  int S[2], rows[2], ntiles[2];
+  int S[3], rows[3], ntiles[3];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
   size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b;
   std::vector<WgradSegment> segs;
@@ -51,10 +51,13 @@ struct WsPlan {
   int wgrad_nwg = 0;
   size_t cond, mse, zero_rgb, slabs;
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
+  size_t bg_loss;       // [64] background-loss accumulator
   size_t timeline;      // [2 levels][4 waves][64] uint64 debug stamps of workgroup 0 of the forward chain kernel
   size_t seg_clock;     // [nsegs] uint64 wall-clock ticks per wgrad segment (cost-model calibration)
-  int nreduce_first = 0;   // reduce descriptors [0, nreduce_first) overwrite, the rest accumulate (2nd launch)
-  LevelWs L[2];
+  int nreduce_pass[3] = {0, 0, 0};   // reduce descriptors by pass: pass 0 overwrites, passes 1 (fine level) and 2
+                                     // (background batch) add into leaves shared with earlier passes, one launch each
+  LevelWs L[3];          // 0 coarse, 1 fine, 2 background points (SE3 field only, training.py:117-135)
+  int bgN = 0;           // number of background points the plan was built for
   size_t total_floats;
   std::vector<PackDesc> pack;
   std::vector<WgradGroup> groups;
@@ -120,9 +123,12 @@ struct nrf_handle_s {
   void* uploaded_ws = nullptr;
   int uploaded_B = -1;
   uint32_t uploaded_flags = 0;
+  int uploaded_bgN = 0;
   void* stashed_ws = nullptr;
   int stashed_B = -1;
   bool stashed_warp = false;
+  std::vector<PackDesc> wp_pack;   // pack table of nrf_warp_points (kept alive for the async upload)
+  int64_t wp_pack_base = -1;
 };
 
 namespace {
@@ -211,18 +217,22 @@ void build_pack_offsets(nrf_handle h) {
 }
 
 // Lays out the workspace for B rays and (re)builds the descriptor tables.
-void build_plan(nrf_handle h, int B, uint32_t flags) {
+constexpr int BG = 2;   // level index of the background-point batch
+
+void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
   WsPlan& p = h->plan;
-  if (p.B == B && p.flags == flags) return;
+  if (p.B == B && p.flags == flags && p.bgN == bgN) return;
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
   p = WsPlan();
   p.B = B;
   p.flags = flags;
+  p.bgN = bgN;
   p.S[0] = d.num_coarse_samples;
   p.S[1] = d.num_coarse_samples + d.num_fine_samples;
-  for (int lv = 0; lv < 2; ++lv) {
-    p.rows[lv] = B * p.S[lv];
+  p.S[BG] = 1;
+  for (int lv = 0; lv < 3; ++lv) {
+    p.rows[lv] = lv == BG ? bgN : B * p.S[lv];
     p.ntiles[lv] = (p.rows[lv] + TILE_ROWS - 1) / TILE_ROWS;
   }
   const int G = h->num_cus;
@@ -234,6 +244,33 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
   std::vector<GroupSpec> specs;
   const int Kb_pe = (h->PK + 31) / 32;          // posenc stash tiles hold whole 32-feature blocks
   const int PKS = Kb_pe * 32;
+  // SE3 trunk + heads of level `lv` (coarse / fine samples, or the background-point batch)
+  auto add_warp_groups = [&](int lv, int accu) {
+    LevelWs& L = p.L[lv];
+    const WarpParamOffsets& w = h->wpo;
+    const size_t wl = (size_t)p.ntiles[lv] * FRAG_TILE_128;
+    const int Kb_in = (h->PKw + 31) / 32;
+    auto push = [&](GroupSpec g) { g.accumulate = accu; specs.push_back(g); };
+    for (int l = 0; l < WARP_DEPTH; ++l) {
+      if (l == 0) {
+        push({lv, SRC_PLAIN, &L.w_st_win, Kb_in * 32 * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+              w.trunk_k[0], WARP_W, h->Win, WARP_W, Kb_in * 4, 0, 0});
+      } else {
+        push({lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+              w.trunk_k[l], WARP_W, WARP_W, WARP_W, 16, (size_t)(l - 1) * wl, (size_t)l * wl});
+        if (l == WARP_SKIP)
+          push({lv, SRC_PLAIN, &L.w_st_win, Kb_in * 32 * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
+                w.trunk_k[l] + (int64_t)WARP_W * WARP_W, WARP_W, h->Win, WARP_W, Kb_in * 4, 0, (size_t)l * wl});
+      }
+    }
+    GroupSpec gw = {lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, 0, nullptr, 0, 0, 3,
+                    w.w_k, 3, WARP_W, 3, 6, (size_t)(WARP_DEPTH - 1) * wl, 0};
+    gw.vecoff = &L.w_dw4;
+    push(gw);
+    GroupSpec gv = gw;
+    gv.dst = w.v_k; gv.vecoff = &L.w_dv4;
+    push(gv);
+  };
   if (train) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
       LevelWs& L = p.L[lv];
@@ -260,33 +297,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
                        po.alpha_k, 1, 256, 1, 12, (size_t)7 * layer, 0});
       specs.push_back({lv, SRC_FRAG128, &L.st_rgbh, FRAG_TILE_128, 128, 4, 0, nullptr, 0, 0, 3,
                        po.logit_k, 3, 128, 3, 6, 0, 0});
-      if (h->warp) {   // SE3 trunk + heads; the field is shared by both passes: level 1 accumulates
-        const WarpParamOffsets& w = h->wpo;
-        const size_t wl = (size_t)p.ntiles[lv] * FRAG_TILE_128;
-        const int Kb_in = (h->PKw + 31) / 32;
-        const int accu = lv > 0 ? 1 : 0;
-        auto push = [&](GroupSpec g) { g.accumulate = accu; specs.push_back(g); };
-        for (int l = 0; l < WARP_DEPTH; ++l) {
-          if (l == 0) {
-            push({lv, SRC_PLAIN, &L.w_st_win, Kb_in * 32 * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
-                  w.trunk_k[0], WARP_W, h->Win, WARP_W, Kb_in * 4, 0, 0});
-          } else {
-            push({lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
-                  w.trunk_k[l], WARP_W, WARP_W, WARP_W, 16, (size_t)(l - 1) * wl, (size_t)l * wl});
-            if (l == WARP_SKIP)
-              push({lv, SRC_PLAIN, &L.w_st_win, Kb_in * 32 * TILE_ROWS, h->Win, Kb_in, SRC_FRAG128, &L.w_dy, FRAG_TILE_128, 4, 0,
-                    w.trunk_k[l] + (int64_t)WARP_W * WARP_W, WARP_W, h->Win, WARP_W, Kb_in * 4, 0, (size_t)l * wl});
-          }
-        }
-        GroupSpec gw = {lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, 0, nullptr, 0, 0, 3,
-                        w.w_k, 3, WARP_W, 3, 6, (size_t)(WARP_DEPTH - 1) * wl, 0};
-        gw.vecoff = &L.w_dw4;
-        push(gw);
-        GroupSpec gv = gw;
-        gv.dst = w.v_k; gv.vecoff = &L.w_dv4;
-        push(gv);
-      }
+      if (h->warp) add_warp_groups(lv, lv > 0 ? 1 : 0);   // the field is shared by both passes: level 1 accumulates
     }
+    if (h->warp && bgN > 0) add_warp_groups(BG, 2);
   }
 
   // ---- float layout ----
@@ -353,6 +366,21 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
   const size_t table_bytes = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
   p.tables = take(table_bytes / 4);
 
+  auto alloc_warp = [&](LevelWs& L, size_t nt) {
+    L.wpoints = take(nt * TILE_ROWS * 3);
+    L.points_raw = take(nt * TILE_ROWS * 3);
+    if (train) {
+      L.d_points = take(nt * TILE_ROWS * 3);
+      L.w_st_win = take(nt * ((h->PKw + 31) / 32 * 32) * TILE_ROWS);
+      L.w_st_h = take(nt * FRAG_TILE_128 * WARP_DEPTH);
+      L.w_st_wv = take(nt * TILE_ROWS * 8);
+      L.w_bits = take(nt * 4 * 64 * WARP_DEPTH);
+      L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
+      L.w_dw4 = take(nt * TILE_ROWS * 4);
+      L.w_dv4 = take(nt * TILE_ROWS * 4);
+      L.w_small_part = take((size_t)2 * G * WARP_SMALL_PART);
+    }
+  };
   p.cond = take((size_t)B * (h->R > 0 ? h->R : 1));
   p.mse = take(64);
   p.zero_rgb = take((size_t)B * 3);
@@ -383,21 +411,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
       L.small_part = take((size_t)2 * G * SMALL_PART);
       L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
     }
-    if (h->warp) {
-      L.wpoints = take(nt * TILE_ROWS * 3);
-      L.points_raw = take(nt * TILE_ROWS * 3);
-      if (train) {
-        L.d_points = take(nt * TILE_ROWS * 3);
-        L.w_st_win = take(nt * ((h->PKw + 31) / 32 * 32) * TILE_ROWS);
-        L.w_st_h = take(nt * FRAG_TILE_128 * WARP_DEPTH);
-        L.w_st_wv = take(nt * TILE_ROWS * 8);
-        L.w_bits = take(nt * 4 * 64 * WARP_DEPTH);
-        L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
-        L.w_dw4 = take(nt * TILE_ROWS * 4);
-        L.w_dv4 = take(nt * TILE_ROWS * 4);
-        L.w_small_part = take((size_t)2 * G * WARP_SMALL_PART);
-      }
-    }
+    if (h->warp) alloc_warp(L, nt);
+  }
+  if (h->warp && bgN > 0) {
+    alloc_warp(p.L[BG], p.ntiles[BG]);
+    p.bg_loss = take(64);
   }
   if (h->warp) p.warp_wpk = take(h->wpk.total);
   p.seg_clock = take(2 * (p.segs.size() + 1));
@@ -445,7 +463,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
   }
 
   // ---- wgrad groups + slabs + reduce descriptors ----
-  std::vector<ReduceDesc> reduce2;   // accumulating descriptors (second launch)
+  std::vector<ReduceDesc> reduce2, reduce3;   // accumulating descriptors (second / third launch)
   if (train) {
     int first = 0;
     for (size_t i = 0; i < specs.size(); ++i) {
@@ -476,8 +494,22 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
         r.src_off = g.slab_off; r.src_ld = g.Nb * 32; r.part_stride = (int64_t)g.Kb * 32 * g.Nb * 32; r.nparts = g.nsplit;
       }
       p.groups.push_back(g);
-      (r.accumulate ? reduce2 : p.reduce).push_back(r);
+      (r.accumulate == 0 ? p.reduce : r.accumulate == 1 ? reduce2 : reduce3).push_back(r);
     }
+    auto warp_bias_descs = [&](int lv, int grid, int accu) {
+      const WarpParamOffsets& w = h->wpo;
+      const LevelWs& L = p.L[lv];
+      auto wsmall = [&](int64_t dst, int cols, int sp_off) {
+        ReduceDesc r;
+        memset(&r, 0, sizeof(r));
+        r.dst_off = dst; r.dst_ld = cols; r.rows = 1; r.cols = cols; r.accumulate = accu;
+        r.src_off = (int64_t)L.w_small_part + sp_off; r.src_ld = cols; r.part_stride = WARP_SMALL_PART; r.nparts = grid;
+        (r.accumulate == 0 ? p.reduce : r.accumulate == 1 ? reduce2 : reduce3).push_back(r);
+      };
+      for (int l = 0; l < WARP_DEPTH; ++l) wsmall(w.trunk_b[l], WARP_W, l * WARP_W);
+      wsmall(w.w_b, 3, 768);
+      wsmall(w.v_b, 3, 771);
+    };
     // bias gradients and per-ray condition rows
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
@@ -502,29 +534,21 @@ void build_plan(nrf_handle h, int B, uint32_t flags) {
         r.src_off = (int64_t)L.cond_grad; r.src_ld = 128; r.part_stride = 0; r.nparts = 1;
         p.reduce.push_back(r);
       }
-      if (h->warp) {
-        const WarpParamOffsets& w = h->wpo;
-        auto wsmall = [&](int64_t dst, int cols, int sp_off) {
-          ReduceDesc r;
-          memset(&r, 0, sizeof(r));
-          r.dst_off = dst; r.dst_ld = cols; r.rows = 1; r.cols = cols; r.accumulate = lv > 0 ? 1 : 0;
-          r.src_off = (int64_t)L.w_small_part + sp_off; r.src_ld = cols; r.part_stride = WARP_SMALL_PART; r.nparts = grid;
-          (r.accumulate ? reduce2 : p.reduce).push_back(r);
-        };
-        for (int l = 0; l < WARP_DEPTH; ++l) wsmall(w.trunk_b[l], WARP_W, l * WARP_W);
-        wsmall(w.w_b, 3, 768);
-        wsmall(w.v_b, 3, 771);
-      }
+      if (h->warp) warp_bias_descs(lv, grid, lv > 0 ? 1 : 0);
     }
+    if (h->warp && bgN > 0) warp_bias_descs(BG, p.ntiles[BG] < 2 * G ? p.ntiles[BG] : 2 * G, 2);
   }
-  p.nreduce_first = (int)p.reduce.size();
+  p.nreduce_pass[0] = (int)p.reduce.size();
+  p.nreduce_pass[1] = (int)reduce2.size();
+  p.nreduce_pass[2] = (int)reduce3.size();
   p.reduce.insert(p.reduce.end(), reduce2.begin(), reduce2.end());
+  p.reduce.insert(p.reduce.end(), reduce3.begin(), reduce3.end());
   p.total_floats = o;
 }
 
 int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
   WsPlan& p = h->plan;
-  if (h->uploaded_ws == (void*)ws && h->uploaded_B == p.B && h->uploaded_flags == p.flags) return NRF_OK;
+  if (h->uploaded_ws == (void*)ws && h->uploaded_B == p.B && h->uploaded_flags == p.flags && h->uploaded_bgN == p.bgN) return NRF_OK;
   char* base = reinterpret_cast<char*>(ws + p.tables);
   hipError_t e;
   if (!p.pack.empty()) {
@@ -548,6 +572,7 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
   h->uploaded_ws = ws;
   h->uploaded_B = p.B;
   h->uploaded_flags = p.flags;
+  h->uploaded_bgN = p.bgN;
   return NRF_OK;
 }
 
@@ -645,12 +670,12 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
 }
 
 int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
-                 const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream) {
+                 const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream, int bgN = 0) {
   CK(validate_rays(h, rays));
   if (!params || !ws) return fail(NRF_E_NULL, "params / workspace is null");
   query_device(h);
   const int B = rays->num_rays;
-  build_plan(h, B, flags & NRF_FLAG_TRAIN);
+  build_plan(h, B, flags & NRF_FLAG_TRAIN, bgN);
   WsPlan& p = h->plan;
   if (ws_bytes < p.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (see nrf_workspace_bytes)");
   const nrf_model_desc& d = h->d;
@@ -724,7 +749,8 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
 
 // d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
 int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
-                  float* grad, float* stats, float* ws, hipStream_t stream) {
+                  float* grad, float* stats, float* ws, hipStream_t stream, const nrf_background* bg = nullptr,
+                  const nrf_step_scalars* scalars = nullptr) {
   WsPlan& p = h->plan;
   const nrf_model_desc& d = h->d;
   const int B = p.B;
@@ -784,6 +810,42 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
                            d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->po[lv].rgbh_k, grad, stream);
     h->prof.end(stream);
   }
+  // ---- background regulariser (training.compute_background_loss, training.py:117-135): the SE3 field on the
+  //      (already noised) background points with one warp id per point; general loss of |x' - x|^2 ----
+  const bool bg_on = bg && p.bgN > 0;
+  if (bg_on) {
+    const LevelWs& L = p.L[BG];
+    const int grid = p.ntiles[BG] < 2 * h->num_cus ? p.ntiles[BG] : 2 * h->num_cus;
+    WarpFwdArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.params = params; fa.po = h->wpo; fa.wpk = ws + p.warp_wpk; fa.pk = h->wpk;
+    fa.points_in = bg->points; fa.point_ids = bg->warp_ids; fa.points_out = ws + L.wpoints;
+    fa.S = 1; fa.B = p.bgN; fa.rows = p.bgN; fa.ntiles = p.ntiles[BG];
+    fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = scalars->warp_alpha;
+    fa.st_win = ws + L.w_st_win; fa.st_h = ws + L.w_st_h; fa.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
+    fa.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
+    h->prof.begin("warp_fwd_bg", warp_fwd_flops_row(h) * p.bgN, stream);
+    launch_warp_fwd(fa, true, grid, stream);
+    h->prof.end(stream);
+    e = hipMemsetAsync(ws + p.bg_loss, 0, 64 * sizeof(float), stream);
+    if (e != hipSuccess) return fail_hip(e, "zero bg loss");
+    launch_background_loss(bg->points, ws + L.wpoints, p.bgN, p.ntiles[BG] * TILE_ROWS, bg->loss_alpha, bg->loss_scale,
+                           bg->loss_weight, ws + L.d_points, ws + p.bg_loss, stream);
+    WarpBwdArgs wa;
+    memset(&wa, 0, sizeof(wa));
+    wa.params = params; wa.po = h->wpo; wa.wpk = ws + p.warp_wpk; wa.pk = h->wpk;
+    wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
+    wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+    wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
+    wa.point_ids = bg->warp_ids;
+    wa.S = 1; wa.B = p.bgN; wa.rows = p.bgN; wa.ntiles = p.ntiles[BG];
+    wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
+    wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
+    wa.grad_embed = grad + h->wpo.embed; wa.small_part = ws + L.w_small_part;
+    h->prof.begin("warp_dgrad_bg", warp_dgrad_flops_row(h) * p.bgN, stream);
+    launch_warp_bwd(wa, grid, stream);
+    h->prof.end(stream);
+  }
   double wg_rows = 0;
   for (int lv = 0; lv < h->nlevels; ++lv) wg_rows += p.rows[lv];
   h->prof.begin("wgrad", (wgrad_flops_row(h) + (warp_on ? warp_fwd_flops_row(h) : 0.0)) * wg_rows, stream);
@@ -794,10 +856,10 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
   h->prof.end(stream);
   h->prof.begin("grad_reduce", 0, stream);
   const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
-  launch_reduce(rd, p.nreduce_first, ws, grad, stream);
-  if ((int)p.reduce.size() > p.nreduce_first)   // second pass of leaves shared by both levels (SE3 field): dst +=
-    launch_reduce(rd + p.nreduce_first, (int)p.reduce.size() - p.nreduce_first, ws, grad, stream);
-  if (stats) launch_finish_stats(ws + p.mse, B, stats, stream);
+  for (int pass = 0, at = 0; pass < 3; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
+    if (p.nreduce_pass[pass] > 0) launch_reduce(rd + at, p.nreduce_pass[pass], ws, grad, stream);
+  if (stats) launch_finish_stats(ws + p.mse, B, bg_on ? ws + p.bg_loss : nullptr, bg_on ? p.bgN : 0, bg_on ? bg->loss_weight : 0.f,
+                                 stats, stream);
   h->prof.end(stream);
   return check_launch("nrf_backward");
 }
@@ -912,6 +974,101 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
                   (hipStream_t)stream));
   const float* dr[2] = {nullptr, nullptr};
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream);
+}
+
+int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
+                                const nrf_step_scalars* scalars, const nrf_rand* rnd, const nrf_background* bg,
+                                float* grad_params, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
+  int bgN = 0;
+  if (bg && bg->num_points > 0) {
+    if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the background regulariser needs the warp field");
+    if (!bg->points || !bg->warp_ids) return fail(NRF_E_NULL, "background points / warp_ids is null");
+    if (!scalars) return fail(NRF_E_NULL, "nrf_step_scalars required");
+    bgN = bg->num_points;
+  }
+  CK(forward_impl(h, params, rays, scalars, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes,
+                  (hipStream_t)stream, bgN));
+  const float* dr[2] = {nullptr, nullptr};
+  return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream,
+                       bgN > 0 ? bg : nullptr, scalars);
+}
+
+int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points, size_t* bytes) {
+  if (!h || !bytes) return fail(NRF_E_NULL, "null");
+  if (num_rays <= 0 || num_background_points < 0) return fail(NRF_E_SHAPE, "bad sizes");
+  if (num_background_points > 0 && !h->warp) return fail(NRF_E_UNSUPPORTED, "the background regulariser needs the warp field");
+  query_device(h);
+  build_plan(h, num_rays, flags & NRF_FLAG_TRAIN, (flags & NRF_FLAG_TRAIN) ? num_background_points : 0);
+  *bytes = h->plan.total_floats * sizeof(float);
+  return NRF_OK;
+}
+
+// Stand-alone SE3 field on arbitrary points (create_warp_field(num_batch_dims=1), models.py:165-184; the
+// field training.compute_background_loss applies, training.py:127-130).  Mini workspace:
+// [pack descriptors | packed trunk weights | padded output].
+namespace {
+struct WarpPointsPlan { size_t desc_f, wpk_f, out_f, total_f; int ntiles; };
+WarpPointsPlan warp_points_plan(nrf_handle h, int n) {
+  WarpPointsPlan q;
+  q.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
+  size_t o = 0;
+  auto take = [&](size_t f) { size_t r = o; o = align_up(o + f, ALIGN_F); return r; };
+  q.desc_f = take(16 * sizeof(PackDesc) / 4);
+  q.wpk_f = take(h->wpk.total);
+  q.out_f = take((size_t)q.ntiles * TILE_ROWS * 3);
+  q.total_f = o;
+  return q;
+}
+}  // namespace
+
+int nrf_warp_points_workspace_bytes(nrf_handle h, int32_t num_points, size_t* bytes) {
+  if (!h || !bytes) return fail(NRF_E_NULL, "null");
+  if (!h->warp) return fail(NRF_E_UNSUPPORTED, "model has no warp field");
+  if (num_points <= 0) return fail(NRF_E_SHAPE, "num_points must be positive");
+  *bytes = warp_points_plan(h, num_points).total_f * sizeof(float);
+  return NRF_OK;
+}
+
+int nrf_warp_points(nrf_handle h, const float* params, const float* points, const int32_t* warp_ids, int32_t num_points,
+                    const nrf_step_scalars* scalars, float* warped, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !params || !points || !warp_ids || !scalars || !warped || !workspace) return fail(NRF_E_NULL, "null argument");
+  if (!h->warp) return fail(NRF_E_UNSUPPORTED, "model has no warp field");
+  if (num_points <= 0) return fail(NRF_E_SHAPE, "num_points must be positive");
+  query_device(h);
+  const WarpPointsPlan q = warp_points_plan(h, num_points);
+  if (workspace_bytes < q.total_f * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (nrf_warp_points_workspace_bytes)");
+  float* ws = (float*)workspace;
+  hipStream_t st = (hipStream_t)stream;
+  if (h->wp_pack.empty() || h->wp_pack_base != (int64_t)q.wpk_f) {
+    h->wp_pack.clear();
+    const WarpParamOffsets& w = h->wpo;
+    const WarpPackOffsets& wk = h->wpk;
+    auto addw = [&](int64_t src, int dst, int row0, int kvalid, int K) {
+      PackDesc d;
+      d.src_off = src; d.dst_off = (int64_t)q.wpk_f + dst; d.src_ld = WARP_W; d.src_row0 = row0; d.kvalid = kvalid; d.K = K;
+      d.ncb = 1; d.transposed = 0; d.nwaves = 4; d.nvalid = 1 << 30;
+      h->wp_pack.push_back(d);
+    };
+    addw(w.trunk_k[0], wk.fwd_L[0], 0, h->Win, h->PKw);
+    for (int l = 1; l < WARP_DEPTH; ++l) addw(w.trunk_k[l], wk.fwd_L[l], 0, WARP_W, WARP_W);
+    addw(w.trunk_k[WARP_SKIP], wk.fwd_L4b, WARP_W, h->Win, h->PKw);
+    h->wp_pack_base = (int64_t)q.wpk_f;
+  }
+  hipError_t e = hipMemcpyAsync(ws + q.desc_f, h->wp_pack.data(), h->wp_pack.size() * sizeof(PackDesc), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) return fail_hip(e, "upload warp pack table");
+  launch_pack(reinterpret_cast<const PackDesc*>(ws + q.desc_f), (int)h->wp_pack.size(), params, ws, st);
+  WarpFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.params = params; a.po = h->wpo; a.wpk = ws + q.wpk_f; a.pk = h->wpk;
+  a.points_in = points; a.point_ids = warp_ids; a.points_out = ws + q.out_f;
+  a.S = 1; a.B = num_points; a.rows = num_points; a.ntiles = q.ntiles;
+  a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha;
+  const int grid = q.ntiles < 2 * h->num_cus ? q.ntiles : 2 * h->num_cus;
+  launch_warp_fwd(a, false, grid, st);
+  e = hipMemcpyAsync(warped, ws + q.out_f, (size_t)num_points * 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
+  if (e != hipSuccess) return fail_hip(e, "copy warped points");
+  return check_launch("nrf_warp_points");
 }
 
 int nrf_profile_enable(nrf_handle h, int32_t on) {

@@ -181,7 +181,7 @@ struct ReduceDesc {
   int64_t src_off;    // floats from the workspace base
   int64_t part_stride;
   int dst_ld, rows, cols, src_ld, nparts;
-  int accumulate;     // 1: dst += (a second level adding into leaves shared by both passes)
+  int accumulate;     // > 0: dst += (pass index: a later level adding into leaves shared with earlier passes)
 };
 
 struct PackDesc {
@@ -230,7 +230,10 @@ void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float
 void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
                             int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
                             float* grad, hipStream_t stream);
-void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t stream);
+void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, float* stats,
+                         hipStream_t stream);
+void launch_background_loss(const float* points, const float* warped, int N, int rows_pad, float alpha, float scale,
+                            float weight, float* d_points, float* loss_sum, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
                  double b2, double eps, int64_t step, double gscale, hipStream_t stream);
 

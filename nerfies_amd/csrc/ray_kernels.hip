@@ -417,19 +417,59 @@ void launch_cond_embed_grad(const float* params, const float* dray, const int32_
                        app_off, cam_feat, cam_off, rgbh_k, grad);
 }
 
-__global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, float* __restrict__ stats) {
+__global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, const float* __restrict__ bg_sum, int bgN,
+                                    float bg_weight, float* __restrict__ stats) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float mc = mse_sums[0] / (3.f * B), mf = mse_sums[1] / (3.f * B);
+    const float bgl = bg_sum ? bg_sum[0] / (float)bgN : 0.f;
     stats[0] = mc; stats[1] = mf;
     stats[2] = -10.f * logf(mc) / logf(10.f);   // utils.compute_psnr (utils.py:94-103)
     stats[3] = -10.f * logf(mf) / logf(10.f);
-    stats[4] = mc + mf;                           // training.py:261
-    stats[5] = stats[6] = stats[7] = 0.f;
+    stats[4] = mc + mf + bg_weight * bgl;         // training.py:261 (+ :257-258)
+    stats[5] = bgl;                               // stats['background_loss'] (training.py:259)
+    stats[6] = stats[7] = 0.f;
   }
 }
 
-void launch_finish_stats(const float* mse_sums, int B, float* stats, hipStream_t stream) {
-  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, mse_sums, B, stats);
+void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, float* stats,
+                         hipStream_t stream) {
+  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, mse_sums, B, bg_sum, bgN, bg_weight, stats);
+}
+
+// ------------------------------------------------------------------ background regulariser
+// loss_i = general_loss_with_squared_residual(|x'_i - x_i|^2, alpha, scale) (utils.py:264-331, finite alpha not in
+// {0,2}):  rho(q) = scale * (beta/alpha) * ((q/(scale^2 beta) + 1)^(alpha/2) - 1),  beta = |alpha - 2|;
+// d rho/d x' = rho'(q) * 2 (x' - x),  rho'(q) = (1/(2 scale)) (q/(scale^2 beta) + 1)^(alpha/2 - 1).
+// d_points = weight/N * d rho/d x' (0 on the tile padding rows);  loss_sum += sum_i rho_i.
+__global__ __launch_bounds__(256) void background_loss_kernel(const float* __restrict__ pts, const float* __restrict__ warped,
+                                                              int N, int rows_pad, float alpha, float scale, float gscale,
+                                                              float* __restrict__ d_points, float* __restrict__ loss_sum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float rho = 0.f;
+  if (i < rows_pad) {
+    float g[3] = {0.f, 0.f, 0.f};
+    if (i < N) {
+      const float beta = fmaxf(1.1920929e-7f, fabsf(alpha - 2.f));
+      const float a_safe = (alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(alpha));
+      float r[3], q = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { r[c] = warped[3 * i + c] - pts[3 * i + c]; q += r[c] * r[c]; }
+      const float u = q / (scale * scale * beta) + 1.f;
+      rho = scale * (beta / a_safe) * (powf(u, 0.5f * alpha) - 1.f);
+      const float drho = (0.5f / scale) * powf(u, 0.5f * alpha - 1.f);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = gscale * drho * 2.f * r[c];
+    }
+    d_points[3 * i] = g[0]; d_points[3 * i + 1] = g[1]; d_points[3 * i + 2] = g[2];
+  }
+  rho = wave_sum(rho);
+  if ((threadIdx.x & 63) == 0 && rho != 0.f) atomicAdd(loss_sum, rho);
+}
+
+void launch_background_loss(const float* points, const float* warped, int N, int rows_pad, float alpha, float scale,
+                            float weight, float* d_points, float* loss_sum, hipStream_t stream) {
+  hipLaunchKernelGGL(background_loss_kernel, dim3((rows_pad + 255) / 256), dim3(256), 0, stream, points, warped, N, rows_pad,
+                     alpha, scale, weight / (float)N, d_points, loss_sum);
 }
 
 // ------------------------------------------------------------------ Adam

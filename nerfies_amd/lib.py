@@ -59,6 +59,11 @@ class Outputs(C.Structure):
   _fields_ = [('coarse', LevelOut), ('fine', LevelOut)]
 
 
+class Background(C.Structure):
+  _fields_ = [('num_points', C.c_int32), ('points', C.c_void_p), ('warp_ids', C.c_void_p), ('loss_weight', C.c_float),
+              ('loss_alpha', C.c_float), ('loss_scale', C.c_float)]
+
+
 class ProfileEntry(C.Structure):
   _fields_ = [('name', C.c_char * 32), ('ms', C.c_double), ('launches', C.c_int32), ('pad_', C.c_int32),
               ('flops_per_launch', C.c_double)]
@@ -68,7 +73,8 @@ EXPORTS = [
     'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',
     'nrf_workspace_bytes', 'nrf_forward', 'nrf_backward', 'nrf_train_step_loss_grad', 'nrf_adam_step',
     'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf', 'nrf_profile_enable', 'nrf_profile_read',
-    'nrf_debug_wgrad_segments', 'nrf_debug_ws_offset',
+    'nrf_debug_wgrad_segments', 'nrf_debug_ws_offset', 'nrf_train_step_loss_grad_ex', 'nrf_workspace_bytes_ex',
+    'nrf_warp_points_workspace_bytes', 'nrf_warp_points',
 ]
 
 _lib = None
@@ -107,6 +113,11 @@ def load_library(path=None):
       'nrf_profile_read': [vp, C.POINTER(ProfileEntry), C.POINTER(i32)],
       'nrf_debug_wgrad_segments': [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)],
       'nrf_debug_ws_offset': [vp, C.c_char_p, i32, C.POINTER(i64)],
+      'nrf_train_step_loss_grad_ex': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand),
+                                      C.POINTER(Background), vp, vp, vp, C.c_size_t, vp],
+      'nrf_workspace_bytes_ex': [vp, i32, u32, i32, C.POINTER(C.c_size_t)],
+      'nrf_warp_points_workspace_bytes': [vp, i32, C.POINTER(C.c_size_t)],
+      'nrf_warp_points': [vp, vp, vp, vp, i32, C.POINTER(StepScalars), vp, vp, C.c_size_t, vp],
   }
   for name, argtypes in sigs.items():
     fn = getattr(lib, name)

@@ -182,13 +182,13 @@ class NerfModel:
       self._layout = P.layout_from_infos(infos, total.value)
     return self._layout
 
-  def workspace(self, num_rays: int, train: bool, device) -> torch.Tensor:
-    key = (int(num_rays), bool(train), str(device))
+  def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0) -> torch.Tensor:
+    key = (int(num_rays), bool(train), str(device), int(num_background_points))
     ws = self._ws.get(key)
     if ws is None:
       nbytes = C.c_size_t(0)
-      L.check(self.lib.nrf_workspace_bytes(self.handle, num_rays, L.NRF_FLAG_TRAIN if train else 0, C.byref(nbytes)),
-              self.lib)
+      L.check(self.lib.nrf_workspace_bytes_ex(self.handle, num_rays, L.NRF_FLAG_TRAIN if train else 0,
+                                              int(num_background_points), C.byref(nbytes)), self.lib)
       ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
       self._ws[key] = ws
     return ws
@@ -296,8 +296,11 @@ class NerfModel:
     del keep
     return grad
 
-  def loss_and_grad(self, fp: P.FlatParams, batch, warp_extra=None, rngs=None, grad_out=None, stats_out=None):
-    """forward + MSE_coarse + MSE_fine + backward in one library call (training.py:168-265)."""
+  def loss_and_grad(self, fp: P.FlatParams, batch, warp_extra=None, rngs=None, grad_out=None, stats_out=None,
+                    background=None):
+    """forward + MSE_coarse + MSE_fine [+ background regulariser] + backward in one library call
+    (training.py:168-265).  `background` = dict(points (N,3) already noised, warp_ids (N,), weight, alpha=-2,
+    scale=1e-3) adds weight * mean(general_loss(|warp(x) - x|^2)) (training.py:117-135, 248-259)."""
     device = fp.flat.device
     rays, keep = self._rays_struct(batch, device)
     rnd, keep2 = self._rand_struct(rngs, rays.num_rays, device)
@@ -305,13 +308,39 @@ class NerfModel:
     grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
     stats = stats_out if stats_out is not None else torch.empty(8, device=device)
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
-    ws = self.workspace(rays.num_rays, True, device)
+    bg, nbg, keep3 = None, 0, []
+    if background is not None:
+      pts = _f32(background['points'], device).reshape(-1, 3)
+      ids = _ids(background['warp_ids'], device).reshape(-1)
+      nbg = pts.shape[0]
+      keep3 = [pts, ids]
+      bg = L.Background(nbg, _ptr(pts), _ptr(ids), float(background.get('weight', 1.0)), float(background.get('alpha', -2.0)),
+                        float(background.get('scale', 0.001)))
+    ws = self.workspace(rays.num_rays, True, device, nbg)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    L.check(self.lib.nrf_train_step_loss_grad(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
-                                              C.byref(rnd), _ptr(grad), _ptr(stats), _ptr(ws), ws.numel() * 4, stream),
-            self.lib)
-    del keep, keep2
+    L.check(self.lib.nrf_train_step_loss_grad_ex(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
+                                                 C.byref(rnd), C.byref(bg) if bg is not None else None, _ptr(grad),
+                                                 _ptr(stats), _ptr(ws), ws.numel() * 4, stream), self.lib)
+    del keep, keep2, keep3
     return grad, stats
+
+  def warp_points(self, variables, points, warp_ids, warp_extra):
+    """model.create_warp_field(model, num_batch_dims=1).apply(points, ids, warp_extra, False, False)
+    ['warped_points'] (models.py:165-184, warping.py:355-389): (N,3) points, one warp id per point."""
+    device = torch.as_tensor(points).device
+    fp = self.flat_params(variables, device)
+    pts = _f32(points, device).reshape(-1, 3)
+    ids = _ids(warp_ids, device).reshape(-1)
+    n = pts.shape[0]
+    nbytes = C.c_size_t(0)
+    L.check(self.lib.nrf_warp_points_workspace_bytes(self.handle, n, C.byref(nbytes)), self.lib)
+    ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
+    out = torch.empty(n, 3, device=device)
+    scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
+    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    L.check(self.lib.nrf_warp_points(self.handle, _ptr(fp.flat), _ptr(pts), _ptr(ids), n, C.byref(scal), _ptr(out), _ptr(ws),
+                                     ws.numel() * 4, stream), self.lib)
+    return out.reshape(torch.as_tensor(points).shape)
 
   def profile_enable(self, on=True):
     L.check(self.lib.nrf_profile_enable(self.handle, int(bool(on))), self.lib)

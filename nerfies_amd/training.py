@@ -92,20 +92,30 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
                use_warp_reg_loss: bool = False):
   """One optimisation step (training.py:138-271).  `batch` holds this rank's ray shard
   ('rgb','origins','directions','metadata').  Returns (new_state, stats, rng_key)."""
-  if use_elastic_loss or use_background_loss or use_warp_reg_loss:
-    raise L.NrfError('elastic / background / warp-reg losses need the warp field (SURVEY 8f rank 1; not built yet)')
+  if use_elastic_loss or use_warp_reg_loss:
+    raise L.NrfError('elastic / warp-reg losses (forward-mode warp Jacobian, SURVEY 8f rank 1) are not built yet')
   del elastic_reduce_method, elastic_loss_type
   # random.split(rng_key, 4) (training.py:168): derive the per-step stream keys from an int key
   rng_key = int(rng_key)
   mix = lambda k, i: (k * 6364136223846793005 + 1442695040888963407 + i) & 0xFFFFFFFFFFFFFFFF
-  next_key, fine_key, coarse_key = mix(rng_key, 0), mix(rng_key, 1), mix(rng_key, 2)
+  next_key, fine_key, coarse_key, reg_key = mix(rng_key, 0), mix(rng_key, 1), mix(rng_key, 2), mix(rng_key, 3)
   opt = state.optimizer
+  background = None
+  if use_background_loss:   # training.compute_background_loss (training.py:117-135, 248-259)
+    pts = torch.as_tensor(batch['background_points'], device=opt.target.flat.device).to(torch.float32).reshape(-1, 3)
+    g = torch.Generator(device=pts.device).manual_seed(reg_key & 0x7FFFFFFFFFFFFFFF)
+    ids_all = torch.as_tensor(list(model.warp_ids), device=pts.device, dtype=torch.int32)
+    ids = ids_all[torch.randint(0, ids_all.numel(), (pts.shape[0],), generator=g, device=pts.device)]   # random.choice(warp_ids)
+    noise = scalar_params.background_noise_std * torch.randn(pts.shape, generator=g, device=pts.device)
+    background = {'points': pts + noise, 'warp_ids': ids, 'weight': scalar_params.background_loss_weight}
   grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
-                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad)
+                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad, background=background)
   grad, stats, n = psum_gradients(grad, stats)
   opt.apply_gradient(grad, learning_rate=scalar_params.learning_rate, grad_scale=1.0 / n)
   out = {
       'coarse': {'loss/rgb': stats[0], 'loss/total': stats[0], 'metric/psnr': stats[2]},
       'fine': {'loss/rgb': stats[1], 'loss/total': stats[1], 'metric/psnr': stats[3]},
   }
+  if use_background_loss:
+    out['background_loss'] = stats[5]
   return state, out, next_key

@@ -403,3 +403,64 @@ def test_warp_train_step_runs_and_reduces_loss():
     state, stats, key = training.train_step(model, key, state, gb, sp)
     losses.append(stats['fine']['loss/rgb'].item())
   assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+# ---------------------------------------------------------------------------------------------
+# background regulariser + stand-alone warp (training.py:117-135; models.py:165-184)
+# ---------------------------------------------------------------------------------------------
+def test_warp_points_matches_oracle():
+  spec, model, fp, gb, p64, b64, alpha = _make_warp(3, num_warp_freqs=6)
+  g = torch.Generator().manual_seed(0)
+  for n in (1, 64, 257):
+    pts = (torch.rand(n, 3, generator=g) - 0.5).double()
+    ids = torch.randint(0, 4, (n, 1), generator=g)
+    ref = O.se3_field(p64['warp_field'], pts, ids, alpha, spec.num_warp_freqs)['warped_points']
+    got = model.warp_points({'params': fp}, pts.float().to(DEV), ids.to(DEV), {'alpha': alpha})
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize('nbg,weight', [(100, 1.0), (300, 0.25)])
+def test_background_loss_and_grad_parity(nbg, weight):
+  from nerfies_amd import params as P
+  spec, model, fp, gb, p64, b64, alpha = _make_warp(6, seed=5, num_nerf_point_freqs=3)
+  g = torch.Generator().manual_seed(1)
+  pts = ((torch.rand(nbg, 3, generator=g) - 0.5) * 0.8).double()
+  ids = torch.randint(0, 4, (nbg, 1), generator=g)
+  noise = 1e-3 * torch.randn(nbg, 3, generator=g).double()
+  bgo = {'points': pts, 'warp_ids': ids, 'noise': noise}
+  loss, ostats, ograds, _ = O.loss_and_grad(p64, spec, b64, warp_alpha=alpha, use_background_loss=True,
+                                            background_loss_weight=weight, background=bgo)
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha},
+                                    background={'points': (pts + noise).float().to(DEV), 'warp_ids': ids.to(DEV), 'weight': weight})
+  torch.cuda.synchronize()
+  assert abs(stats[5].item() - ostats['background_loss'].item()) < 1e-6 + 1e-4 * abs(ostats['background_loss'].item())
+  assert abs(stats[4].item() - loss.item()) < 3e-5
+  got = P.tree_from_flat(grad.cpu(), model.layout)
+  for path, og in O.tree_leaves_with_path(ograds):
+    node = got
+    for k in path.split('/'):
+      node = node[k]
+    scale = max(og.abs().max().item(), 1e-7)
+    err = (node.double() - og).abs().max().item() / scale
+    assert err < 2e-3, (path, err, scale)
+
+
+def test_train_step_with_background_loss():
+  from nerfies_amd import training
+  import helpers as H
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=4, use_warp=True)
+  oparams = O.init_params(spec, seed=2, trained_like=False, dtype=torch.float64)   # reference init: warp ~ identity
+  for k in ('branches_w', 'branches_v'):   # a visible but unsaturated warp (|x'-x| ~ the loss scale 1e-3)
+    oparams['warp_field'][k]['logit']['kernel'] *= 20.0
+  model, fp = H.gpu_model(spec, oparams, 32)
+  gb = H.gpu_batch(O.synthetic_batch(32, seed=3, dtype=torch.float64))
+  alpha = 8.0
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=alpha)
+  sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0, background_noise_std=1e-3)
+  gb = dict(gb)
+  gb['background_points'] = (torch.rand(500, 3, device=DEV) - 0.5) * 0.5
+  key, bgl = 0, []
+  for _ in range(20):
+    state, stats, key = training.train_step(model, key, state, gb, sp, use_background_loss=True)
+    bgl.append(stats['background_loss'].item())
+  assert np.isfinite(bgl).all() and bgl[-1] < bgl[0]   # the regulariser pulls the background warp to identity

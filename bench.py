@@ -114,12 +114,96 @@ def cpu_baseline(seconds_budget=18.0):
                     f'median of {len(times)} steps, {best_threads} threads (best of a probe up to {ncpu})'}
 
 
+def side_mode(args, world, rank, dev):
+  """Secondary workloads (never the default bench line): eval forward and the vrig training shape."""
+  from nerfies_amd import evaluation, models, training
+
+  def barrier():
+    if world > 1:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  if args.mode == 'eval':
+    class C(Cfg):
+      num_coarse_samples, num_fine_samples, use_stratified_sampling = 128, 128, False
+    n = 8192
+    model, fp = models.construct_nerf(0, C, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
+    rays = {k: v for k, v in synthetic_batch(n, 100 + rank, dev).items() if k != 'rgb'}
+    fn = evaluation.GraphedChunkRenderer(model)
+    step = lambda: fn(0, 1, fp, rays, {})
+    prof_step = lambda: model.apply({'params': fp}, rays, {})   # HIP events cannot be recorded inside a graph replay
+    per_step, name, flops = n, 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)', None
+    workload = 'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, warp off, deterministic, forward only'
+  else:
+    class C(Cfg):
+      num_coarse_samples, num_fine_samples = 128, 128
+      use_warp, num_warp_freqs, num_warp_features, use_camera_metadata = True, 6, 8, True
+      warp_field_type = 'se3'
+    n = 768
+    model, fp = models.construct_nerf(0, C, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
+    state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=6.0)
+    sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0)
+    batch = synthetic_batch(n, 100 + rank, dev)
+    g = torch.Generator().manual_seed(rank)
+    batch['metadata'] = {'warp': torch.randint(0, 4, (n, 1), generator=g).to(dev), 'camera': torch.randint(0, 2, (n, 1), generator=g).to(dev)}
+    batch['background_points'] = ((torch.rand(16384 // max(world, 1), 3, generator=g) - 0.5) * 0.8).to(dev)
+    box = {'state': state, 'key': 1 + rank}
+
+    def step():
+      box['state'], _, box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, use_background_loss=True)
+    prof_step = step
+    per_step, name = n, 'train rays/sec (256 samples/ray, SE3 warp + background regulariser, no elastic term)'
+    workload = ('gpu_vrig_paper.gin shape: 768 rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, background points '
+                '16384/world, stratified; the elastic regulariser of that preset is NOT built yet')
+  for _ in range(args.warmup):
+    step()
+  barrier()
+  t0 = time.perf_counter()
+  for _ in range(args.steps):
+    step()
+  barrier()
+  elapsed = time.perf_counter() - t0
+  if world > 1:
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = t.item()
+  model.profile_enable(True)
+  for _ in range(5):
+    prof_step()
+  torch.cuda.synchronize()
+  prof = model.profile_read()
+  model.profile_enable(False)
+  if rank == 0:
+    kernels = {e['name']: {'ms': e['ms'] / max(e['launches'], 1), 'launches_per_step': e['launches'] / 5,
+                           'tflops': (e['flops_per_launch'] / (e['ms'] / max(e['launches'], 1) * 1e-3) / 1e12)
+                           if e['flops_per_launch'] > 0 and e['ms'] > 0 else None} for e in prof}
+    mf = [e for e in prof if e['flops_per_launch'] > 0]
+    dom = max(mf, key=lambda e: e['ms'])
+    dom_ms = dom['ms'] / dom['launches']
+    achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
+    step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / 5
+    ms = 1e3 * elapsed / args.steps
+    print(json.dumps({
+        'metric': name, 'value': world * per_step * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'data': 'synthetic', 'config': {'workload': workload, 'rays_per_gpu': per_step, 'parallelism': f'ray-shard dp{world}'},
+        'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'kernel_ms': dom_ms},
+        'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernels}))
+  if world > 1:
+    dist.destroy_process_group()
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
   ap.add_argument('--steps', type=int, default=30)
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--mode', default='train', choices=['train', 'eval', 'vrig'],
+                  help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
+                       '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
+                       'SE3 warp F_w=6 + camera code + background regulariser; elastic term not built yet)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -135,6 +219,8 @@ def main():
   torch.cuda.set_device(dev)
 
   from nerfies_amd import models, training
+  if args.mode != 'train':
+    return side_mode(args, world, rank, dev)
   model, fp = models.construct_nerf(0, Cfg, RAYS_PER_GPU, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
   state = training.TrainState(optimizer=training.Optimizer(fp))
   sp = training.ScalarParams(learning_rate=1e-3)

@@ -12,6 +12,57 @@ def _tree_map(fn, tree):
   return fn(tree)
 
 
+class GraphedChunkRenderer:
+  """One fixed-size chunk of NerfModel.apply captured in a hipGraph (torch.cuda.CUDAGraph over the
+  library's launches on the capture stream) and replayed per chunk: the eval forward is ~20 kernel
+  launches of a few hundred microseconds at 8k rays, so launch gaps matter (BASELINE config E).
+
+  model_fn-compatible: `renderer(key_0, key_1, params, rays_dict, warp_extra)`; rays are copied into
+  static buffers, the graph is replayed and copies of the static outputs are returned.
+  The graph is (re)captured whenever the chunk size, the parameter buffer or warp_alpha changes."""
+
+  def __init__(self, model, use_warp=True):
+    self.model = model
+    self.use_warp = use_warp
+    self._key = None
+    self._graph = None
+    self._in = None
+    self._out = None
+
+  def _capture(self, fp, rays, warp_extra):
+    model = self.model
+    self._in = _tree_map(lambda x: x.clone(), rays)
+    call = lambda out=None: model.apply({'params': fp}, self._in, warp_extra, use_warp=self.use_warp, out=out)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+      self._out = call()          # warm-up: uploads the descriptor tables (not capturable), sizes the workspace
+      call(self._out)
+    torch.cuda.current_stream().wait_stream(s)
+    self._graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(self._graph):
+      call(self._out)
+
+  def __call__(self, key_0, key_1, params, rays, warp_extra):
+    del key_0, key_1               # eval is deterministic (eval.py:239 forces use_stratified_sampling off)
+    n = rays['origins'].shape[0]
+    alpha = float((warp_extra or {}).get('alpha', 0.0))
+    key = (n, params.flat.data_ptr(), alpha, tuple(sorted((rays.get('metadata') or {}).keys())))
+    if key != self._key:
+      self._capture(params, rays, warp_extra)
+      self._key = key
+    else:
+      def cp(dst, src):
+        if isinstance(dst, dict):
+          for k in dst:
+            cp(dst[k], src[k])
+        else:
+          dst.copy_(src)
+      cp(self._in, rays)
+    self._graph.replay()
+    return _tree_map(lambda x: x.clone(), self._out)   # the static buffers are overwritten by the next replay
+
+
 def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_count: int = 1, rng=0,
                  chunk: int = 8192, default_ret_key: Optional[str] = None):
   """Renders all pixels of an (H,W) ray image in chunks (evaluation.py:62-99).

@@ -236,9 +236,11 @@ class NerfModel:
   # ---- NerfModel.__call__ (models.py:289-375) ---------------------------------------------
   def apply(self, variables, rays_dict: Dict[str, Any], warp_extra: Dict[str, Any] = None, metadata_encoded=False,
             use_warp=True, return_points=False, return_weights=False, return_warp_jacobian=False,
-            deterministic=False, rngs=None, *, train=False, return_z_vals=False):
+            deterministic=False, rngs=None, *, train=False, return_z_vals=False, out=None):
     """Returns {'coarse': {...}, 'fine': {...}} like the reference.  `train=True` keeps the
-    activation stash so `backward` can follow (used by training.train_step / autograd)."""
+    activation stash so `backward` can follow (used by training.train_step / autograd).  `out`: a dict
+    returned by an earlier call with the same shapes/flags, to be overwritten in place (fixed output
+    addresses: what a captured hipGraph replay needs)."""
     del deterministic   # accepted and unused, as in the reference (models.py:298)
     if metadata_encoded:
       raise L.NrfError('metadata_encoded=True is not built yet')
@@ -256,19 +258,23 @@ class NerfModel:
     rnd, keep2 = self._rand_struct(rngs, B, device)
     return_weights = self.use_weights or return_weights
     S = (self.num_coarse_samples, self.num_coarse_samples + self.num_fine_samples)
+    reuse = out
     out = L.Outputs()
     ret = {}
     levels = [('coarse', out.coarse, S[0])] + ([('fine', out.fine, S[1])] if self.num_fine_samples > 0 else [])
     for name, lo, s in levels:
-      d = {'rgb': torch.empty(B, 3, device=device), 'depth': torch.empty(B, device=device),
-           'med_depth': torch.empty(B, device=device), 'acc': torch.empty(B, device=device)}
-      if return_weights:
-        d['weights'] = torch.empty(B, s, device=device)
-      if return_z_vals:   # extra (not in the reference dict): the sample depths of this level
-        d['z_vals'] = torch.empty(B, s, device=device)
-      if return_points:   # models.py:250-251, 266-267
-        d['points'] = torch.empty(B, s, 3, device=device)
-        d['warped_points'] = torch.empty(B, s, 3, device=device)
+      if reuse is not None:
+        d = reuse[name]
+      else:
+        d = {'rgb': torch.empty(B, 3, device=device), 'depth': torch.empty(B, device=device),
+             'med_depth': torch.empty(B, device=device), 'acc': torch.empty(B, device=device)}
+        if return_weights:
+          d['weights'] = torch.empty(B, s, device=device)
+        if return_z_vals:   # extra (not in the reference dict): the sample depths of this level
+          d['z_vals'] = torch.empty(B, s, device=device)
+        if return_points:   # models.py:250-251, 266-267
+          d['points'] = torch.empty(B, s, 3, device=device)
+          d['warped_points'] = torch.empty(B, s, 3, device=device)
       for k, t in d.items():
         setattr(lo, k, _ptr(t))
       ret[name] = d

@@ -464,3 +464,28 @@ def test_train_step_with_background_loss():
     state, stats, key = training.train_step(model, key, state, gb, sp, use_background_loss=True)
     bgl.append(stats['background_loss'].item())
   assert np.isfinite(bgl).all() and bgl[-1] < bgl[0]   # the regulariser pulls the background warp to identity
+
+
+def test_graphed_chunk_renderer_matches_direct_apply():
+  """hipGraph-captured eval forward (BASELINE config E) == direct NerfModel.apply, across replays, a ragged
+  last chunk (re-capture) and an in-place parameter update (same buffer, new values)."""
+  from nerfies_amd import evaluation, training
+  spec = O.ModelSpec(num_coarse_samples=32, num_fine_samples=32, use_camera_metadata=True)
+  oparams = O.init_params(spec, seed=7, trained_like=True, dtype=torch.float32)
+  import helpers as H
+  model, fp = H.gpu_model(spec, oparams, 0)
+  state = training.TrainState(optimizer=training.Optimizer(fp))
+  hh, ww = 9, 23   # 207 rays: chunks of 64 -> 64, 64, 64, 15
+  g = torch.Generator().manual_seed(3)
+  rays = {'origins': (torch.rand(hh, ww, 3, generator=g) - 0.5).to(DEV),
+          'directions': torch.nn.functional.normalize(torch.randn(hh, ww, 3, generator=g), dim=-1).to(DEV),
+          'metadata': {'camera': torch.randint(0, 2, (hh, ww, 1), generator=g).to(DEV)}}
+  direct = lambda k0, k1, params, r, we: model.apply({'params': params}, r, we)
+  graphed = evaluation.GraphedChunkRenderer(model)
+  for rep in range(2):
+    a = evaluation.render_image(state, rays, direct, chunk=64)
+    b = evaluation.render_image(state, rays, graphed, chunk=64)
+    for k in ('rgb', 'depth', 'med_depth', 'acc'):
+      assert a[k].shape == (hh, ww) + ((3,) if k == 'rgb' else ())
+      np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
+    fp.flat.mul_(1.01)   # "training" moved the weights in place: the replay must see the new values

@@ -194,15 +194,31 @@ typedef struct nrf_background {
   float loss_scale;         /* 0.001 */
 } nrf_background;
 
-/* nrf_train_step_loss_grad + the background regulariser (bg may be NULL).  stats[5] = mean background loss
- * (unweighted, training.py:259), stats[4] includes weight * stats[5].  The workspace must come from
- * nrf_workspace_bytes_ex with the same num_background_points. */
+/* Elastic regulariser of training.compute_elastic_loss (training.py:71-114, 177-197) on the COARSE samples
+ * (models.py:345): J = jax.jacfwd(SE3Field.warp) per sample (warping.py:385-387), loss_type 'log_svals':
+ * sum_k log(max(s_k(J), eps))^2 -> general_loss(alpha, scale) -> sum over samples with the stop-gradient
+ * compositing weights (elastic_reduce_method 'weight'; 'median' instead keeps only the sample at
+ * model_utils.compute_depth_index) -> mean over rays, times loss_weight.  The gradient
+ * (reverse over the forward-mode Jacobian, incl. exp_se3's second derivatives) is added to grad_params. */
+enum { NRF_ELASTIC_WEIGHT = 0, NRF_ELASTIC_MEDIAN = 1 };
+typedef struct nrf_elastic {
+  float loss_weight;      /* scalar_params.elastic_loss_weight */
+  int32_t reduce_method;  /* NRF_ELASTIC_* */
+  float eps;              /* 1e-6 */
+  float loss_alpha;       /* -2 (training.py:112-113) */
+  float loss_scale;       /* 0.03 */
+} nrf_elastic;
+
+/* nrf_train_step_loss_grad + the regularisers (bg and/or el may be NULL).  stats[5] = mean background loss
+ * (unweighted, training.py:259), stats[6] = elastic loss (unweighted, training.py:195), stats[7] = mean elastic
+ * residual (training.py:196); stats[4] includes the weighted terms.  The workspace must come from
+ * nrf_workspace_bytes_ex with the same num_background_points / use_elastic_loss. */
 int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
                                 const nrf_step_scalars* scalars, const nrf_rand* rnd, const nrf_background* bg,
-                                float* grad_params, float* stats, void* workspace, size_t workspace_bytes,
-                                void* stream);
+                                const nrf_elastic* el, float* grad_params, float* stats, void* workspace,
+                                size_t workspace_bytes, void* stream);
 int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points,
-                           size_t* bytes);
+                           int32_t use_elastic_loss, size_t* bytes);
 
 /* warping.SE3Field on arbitrary points with one warp id per point: model.create_warp_field(num_batch_dims=1)
  * .apply(points, metadata, warp_extra, False, False) (models.py:165-184, warping.py:355-389). */

@@ -203,9 +203,12 @@ __device__ __forceinline__ float4 mask4(const float4& v, uint32_t nib) {
   return make_float4((nib & 1u) ? v.x : 0.f, (nib & 2u) ? v.y : 0.f, (nib & 4u) ? v.z : 0.f, (nib & 8u) ? v.w : 0.f);
 }
 
-// Layer epilogue: [ReLU,] write the wave's 64 x 32*NCB outputs to the LDS activation tile and, in
-// training, to the fragment-order stash (+ 1 sign bit per element: bits_wave[lane*NCB + cb], nibble q).
-template <int NCB, bool RELU, bool STASH>
+// Layer epilogue: write the wave's 64 x 32*NCB outputs to the LDS activation tile and, in training, to the
+// fragment-order stash.  MODE 0: linear; 1: ReLU (+ 1 sign bit per element out: bits_wave[lane*NCB + cb],
+// nibble q); 2: multiply by the 0/1 mask read from bits_wave (tangent pass: the ReLU derivative of the
+// primal pass, warping.py:385-387 jacfwd).
+enum { EPI_LINEAR = 0, EPI_RELU = 1, EPI_MASK = 2 };
+template <int NCB, int MODE, bool STASH>
 __device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[2][NCB], int ncol0, float* act,
                                              __amdgpu_buffer_rsrc_t stash, int stash_soff, uint32_t* bits_wave,
                                              int lane) {
@@ -214,18 +217,20 @@ __device__ __forceinline__ void fwd_epilogue(f32x16 (&acc)[2][NCB], int ncol0, f
 #pragma unroll
   for (int cb = 0; cb < NCB; ++cb) {
     const int n = ncol0 + 32 * cb + j;
-    uint32_t mb = 0u;
+    uint32_t mb = MODE == EPI_MASK ? bits_wave[lane * NCB + cb] : 0u;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float4 v = acc_piece<NCB>(acc, cb, q);
-      if (RELU) {
+      if (MODE == EPI_RELU) {
         if (STASH) mb |= sign_nibble(v) << (4 * q);
         v.x = relu(v.x); v.y = relu(v.y); v.z = relu(v.z); v.w = relu(v.w);
+      } else if (MODE == EPI_MASK) {
+        v = mask4(v, (mb >> (4 * q)) & 15u);
       }
       *reinterpret_cast<float4*>(act + act_addr(n, q_granule(q, h))) = v;
       if (STASH) buf_store4(v, stash, lane * 16, stash_soff + (cb * 8 + q) * 1024);
     }
-    if (STASH && RELU) bits_wave[lane * NCB + cb] = mb;
+    if (STASH && MODE == EPI_RELU) bits_wave[lane * NCB + cb] = mb;
   }
   __syncthreads();
 }

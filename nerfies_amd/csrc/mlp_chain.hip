@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
       wnext = prefetch_quad<2>(wpk4 + ((l + 1 < TRUNK_DEPTH ? A.pk.fwd_L[l + 1] : A.pk.fwd_bn) / 4) + wave * 64 * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
       STAMP();   // k loop of layer l issued
-      fwd_epilogue<2, true, STASH>(
+      fwd_epilogue<2, EPI_RELU, STASH>(
           acc, wave * 64, act,
           make_rsrc(STASH ? A.st_h + l * st_h_layer + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff,
           STASH ? A.bits_trunk + (((size_t)l * A.ntiles + tile) * 4 + wave) * 128 : nullptr, lane);
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     const float4* wrgb = wpk4 + (A.pk.fwd_rgbh / 4) + wave * 32 * 64;
     const WQuad<1> wrgb0 = prefetch_quad<1>(wrgb, lane);
     __builtin_amdgcn_sched_barrier(0);
-    fwd_epilogue<2, false, STASH>(
+    fwd_epilogue<2, EPI_LINEAR, STASH>(
         acc, wave * 64, act,
         make_rsrc(STASH ? A.st_bn + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff, nullptr, lane);
 

@@ -37,13 +37,14 @@ struct LevelWs {   // float offsets from the workspace base, per level (0 = coar
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
   // SE3 warp field (per level: the field is evaluated on the coarse and on the fine samples)
   size_t wpoints, points_raw, d_points;
+  size_t el_dw4, el_dv4;   // coarse level: dL/d(w, v) of the elastic regulariser through exp_se3's second derivatives
   size_t w_st_win, w_st_h, w_st_wv, w_bits, w_dy, w_dw4, w_dv4, w_small_part;
 };
 
 struct WsPlan {
   int B = -1;
   uint32_t flags = 0;
-  int S[3], rows[3], ntiles[3];
+  int S[4], rows[4], ntiles[4];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
   size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b;
   std::vector<WgradSegment> segs;
@@ -52,11 +53,15 @@ struct WsPlan {
   size_t cond, mse, zero_rgb, slabs;
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
   size_t bg_loss;       // [64] background-loss accumulator
+  size_t el_sums;       // [64] elastic-loss / residual accumulators
+  size_t el_coef;       // [B][N_c] one-hot sample selector of elastic_reduce_method 'median'
   size_t timeline;      // [2 levels][4 waves][64] uint64 debug stamps of workgroup 0 of the forward chain kernel
   size_t seg_clock;     // [nsegs] uint64 wall-clock ticks per wgrad segment (cost-model calibration)
-  int nreduce_pass[3] = {0, 0, 0};   // reduce descriptors by pass: pass 0 overwrites, passes 1 (fine level) and 2
-                                     // (background batch) add into leaves shared with earlier passes, one launch each
-  LevelWs L[3];          // 0 coarse, 1 fine, 2 background points (SE3 field only, training.py:117-135)
+  int nreduce_pass[4] = {0, 0, 0, 0};   // reduce descriptors by pass: pass 0 overwrites, passes 1 (fine level) and 2
+                                     // (background batch), 3 (Jacobian tangents) add into leaves shared with earlier passes
+  LevelWs L[4];          // 0 coarse, 1 fine, 2 background points (SE3 field only, training.py:117-135),
+                         // 3 tangent pass of the coarse warp Jacobian (elastic regulariser, 3 x coarse tiles)
+  int elastic = 0;       // plan built with the elastic regulariser's buffers
   int bgN = 0;           // number of background points the plan was built for
   size_t total_floats;
   std::vector<PackDesc> pack;
@@ -124,6 +129,7 @@ struct nrf_handle_s {
   int uploaded_B = -1;
   uint32_t uploaded_flags = 0;
   int uploaded_bgN = 0;
+  int uploaded_elastic = 0;
   void* stashed_ws = nullptr;
   int stashed_B = -1;
   bool stashed_warp = false;
@@ -218,23 +224,28 @@ void build_pack_offsets(nrf_handle h) {
 
 // Lays out the workspace for B rays and (re)builds the descriptor tables.
 constexpr int BG = 2;   // level index of the background-point batch
+constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coarse tiles)
 
-void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
+void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 0) {
   WsPlan& p = h->plan;
-  if (p.B == B && p.flags == flags && p.bgN == bgN) return;
+  if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic) return;
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
   p = WsPlan();
   p.B = B;
   p.flags = flags;
   p.bgN = bgN;
+  p.elastic = elastic;
   p.S[0] = d.num_coarse_samples;
   p.S[1] = d.num_coarse_samples + d.num_fine_samples;
   p.S[BG] = 1;
+  p.S[TG] = 1;
   for (int lv = 0; lv < 3; ++lv) {
     p.rows[lv] = lv == BG ? bgN : B * p.S[lv];
     p.ntiles[lv] = (p.rows[lv] + TILE_ROWS - 1) / TILE_ROWS;
   }
+  p.ntiles[TG] = elastic ? 3 * p.ntiles[0] : 0;
+  p.rows[TG] = p.ntiles[TG] * TILE_ROWS;
   const int G = h->num_cus;
 
   // ---- wgrad groups (training) ----
@@ -300,6 +311,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
       if (h->warp) add_warp_groups(lv, lv > 0 ? 1 : 0);   // the field is shared by both passes: level 1 accumulates
     }
     if (h->warp && bgN > 0) add_warp_groups(BG, 2);
+    if (h->warp && elastic) add_warp_groups(TG, 3);   // tangent activations x tangent adjoints, same leaves
   }
 
   // ---- float layout ----
@@ -356,7 +368,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
   }
   p.ntasks = (int)p.segs.size();
   const int npack = 64;
-  const int nreduce_max = 160;
+  const int nreduce_max = 192;
   // tables region (bytes -> floats)
   p.pack_off_b = 0;
   p.groups_off_b = align_up(npack * sizeof(PackDesc), 256);
@@ -417,6 +429,13 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
     alloc_warp(p.L[BG], p.ntiles[BG]);
     p.bg_loss = take(64);
   }
+  if (h->warp && elastic && train) {
+    alloc_warp(p.L[TG], p.ntiles[TG]);
+    p.L[0].el_dw4 = take((size_t)p.ntiles[0] * TILE_ROWS * 4);
+    p.L[0].el_dv4 = take((size_t)p.ntiles[0] * TILE_ROWS * 4);
+    p.el_sums = take(64);
+    p.el_coef = take((size_t)p.rows[0]);
+  }
   if (h->warp) p.warp_wpk = take(h->wpk.total);
   p.seg_clock = take(2 * (p.segs.size() + 1));
   p.timeline = take(2 * (2 * 4 * 64 + 1024 + 4 * 4096));
@@ -463,7 +482,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
   }
 
   // ---- wgrad groups + slabs + reduce descriptors ----
-  std::vector<ReduceDesc> reduce2, reduce3;   // accumulating descriptors (second / third launch)
+  std::vector<ReduceDesc> reduce2, reduce3, reduce4;   // accumulating descriptors (later launches)
   if (train) {
     int first = 0;
     for (size_t i = 0; i < specs.size(); ++i) {
@@ -494,7 +513,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
         r.src_off = g.slab_off; r.src_ld = g.Nb * 32; r.part_stride = (int64_t)g.Kb * 32 * g.Nb * 32; r.nparts = g.nsplit;
       }
       p.groups.push_back(g);
-      (r.accumulate == 0 ? p.reduce : r.accumulate == 1 ? reduce2 : reduce3).push_back(r);
+      (r.accumulate == 0 ? p.reduce : r.accumulate == 1 ? reduce2 : r.accumulate == 2 ? reduce3 : reduce4).push_back(r);
     }
     auto warp_bias_descs = [&](int lv, int grid, int accu) {
       const WarpParamOffsets& w = h->wpo;
@@ -504,7 +523,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
         memset(&r, 0, sizeof(r));
         r.dst_off = dst; r.dst_ld = cols; r.rows = 1; r.cols = cols; r.accumulate = accu;
         r.src_off = (int64_t)L.w_small_part + sp_off; r.src_ld = cols; r.part_stride = WARP_SMALL_PART; r.nparts = grid;
-        (r.accumulate == 0 ? p.reduce : r.accumulate == 1 ? reduce2 : reduce3).push_back(r);
+        (r.accumulate == 0 ? p.reduce : r.accumulate == 1 ? reduce2 : r.accumulate == 2 ? reduce3 : reduce4).push_back(r);
       };
       for (int l = 0; l < WARP_DEPTH; ++l) wsmall(w.trunk_b[l], WARP_W, l * WARP_W);
       wsmall(w.w_b, 3, 768);
@@ -541,14 +560,16 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0) {
   p.nreduce_pass[0] = (int)p.reduce.size();
   p.nreduce_pass[1] = (int)reduce2.size();
   p.nreduce_pass[2] = (int)reduce3.size();
+  p.nreduce_pass[3] = (int)reduce4.size();
   p.reduce.insert(p.reduce.end(), reduce2.begin(), reduce2.end());
   p.reduce.insert(p.reduce.end(), reduce3.begin(), reduce3.end());
+  p.reduce.insert(p.reduce.end(), reduce4.begin(), reduce4.end());
   p.total_floats = o;
 }
 
 int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
   WsPlan& p = h->plan;
-  if (h->uploaded_ws == (void*)ws && h->uploaded_B == p.B && h->uploaded_flags == p.flags && h->uploaded_bgN == p.bgN) return NRF_OK;
+  if (h->uploaded_ws == (void*)ws && h->uploaded_B == p.B && h->uploaded_flags == p.flags && h->uploaded_bgN == p.bgN && h->uploaded_elastic == p.elastic) return NRF_OK;
   char* base = reinterpret_cast<char*>(ws + p.tables);
   hipError_t e;
   if (!p.pack.empty()) {
@@ -573,6 +594,7 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
   h->uploaded_B = p.B;
   h->uploaded_flags = p.flags;
   h->uploaded_bgN = p.bgN;
+  h->uploaded_elastic = p.elastic;
   return NRF_OK;
 }
 
@@ -670,12 +692,13 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
 }
 
 int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
-                 const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream, int bgN = 0) {
+                 const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream, int bgN = 0,
+                 int elastic = 0) {
   CK(validate_rays(h, rays));
   if (!params || !ws) return fail(NRF_E_NULL, "params / workspace is null");
   query_device(h);
   const int B = rays->num_rays;
-  build_plan(h, B, flags & NRF_FLAG_TRAIN, bgN);
+  build_plan(h, B, flags & NRF_FLAG_TRAIN, bgN, elastic);
   WsPlan& p = h->plan;
   if (ws_bytes < p.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (see nrf_workspace_bytes)");
   const nrf_model_desc& d = h->d;
@@ -716,6 +739,18 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
       launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train), train, grid, stream);
       pf.end(stream);
       a.points = ws + L.wpoints;
+      if (lv == 0 && train && p.elastic) {   // forward-mode Jacobian of the warp on the coarse samples (models.py:345)
+        const LevelWs& T = p.L[TG];
+        WarpFwdArgs ta = warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, true);
+        ta.nt_prim = p.ntiles[0]; ta.prim_win = ws + L.w_st_win; ta.prim_bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
+        ta.ntiles = p.ntiles[TG]; ta.rows = p.rows[TG];
+        ta.st_win = ws + T.w_st_win; ta.st_h = ws + T.w_st_h; ta.st_wv = reinterpret_cast<float4*>(ws + T.w_st_wv);
+        ta.bits = nullptr; ta.points_out = ws + T.wpoints; ta.points_raw = nullptr;
+        const int tgrid = p.ntiles[TG] < gmul * h->num_cus ? p.ntiles[TG] : gmul * h->num_cus;
+        pf.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[0], stream);
+        launch_warp_fwd(ta, true, tgrid, stream);
+        pf.end(stream);
+      }
     }
     pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
     launch_chain_fwd(a, train, grid, stream);
@@ -750,7 +785,7 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
 // d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
 int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
                   float* grad, float* stats, float* ws, hipStream_t stream, const nrf_background* bg = nullptr,
-                  const nrf_step_scalars* scalars = nullptr) {
+                  const nrf_step_scalars* scalars = nullptr, const nrf_elastic* el = nullptr) {
   WsPlan& p = h->plan;
   const nrf_model_desc& d = h->d;
   const int B = p.B;
@@ -787,10 +822,34 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
     launch_chain_bwd(a, grid, stream);
     h->prof.end(stream);
+    const bool el_on = el && p.elastic && warp_on && lv == 0;
+    if (el_on) {
+      const LevelWs& T = p.L[TG];
+      e = hipMemsetAsync(ws + p.el_sums, 0, 64 * sizeof(float), stream);
+      if (e != hipSuccess) return fail_hip(e, "zero elastic sums");
+      ElasticArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.prim_win = ws + L.w_st_win; ea.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+      ea.tan_wv = reinterpret_cast<const float4*>(ws + T.w_st_wv); ea.coef = ws + L.weights;
+      if (el->reduce_method == NRF_ELASTIC_MEDIAN) {   // training.py:182-188
+        launch_median_coef(ws + L.weights, B, p.S[0], ws + p.el_coef, stream);
+        ea.coef = ws + p.el_coef; ea.res_selected = 1;
+      }
+      ea.tan_dw4 = reinterpret_cast<float4*>(ws + T.w_dw4); ea.tan_dv4 = reinterpret_cast<float4*>(ws + T.w_dv4);
+      ea.prim_dw4 = reinterpret_cast<float4*>(ws + L.el_dw4); ea.prim_dv4 = reinterpret_cast<float4*>(ws + L.el_dv4);
+      ea.sums = ws + p.el_sums;
+      ea.rows = p.rows[0]; ea.rows_pad = p.ntiles[0] * TILE_ROWS; ea.PKS = (h->PKw + 31) / 32 * 32;
+      ea.eps = el->eps; ea.alpha = el->loss_alpha; ea.scale = el->loss_scale; ea.gscale = el->loss_weight / (float)B;
+      h->prof.begin("elastic", 0, stream);
+      launch_elastic(ea, stream);
+      h->prof.end(stream);
+    }
     if (warp_on) {
       WarpBwdArgs wa;
       memset(&wa, 0, sizeof(wa));
       wa.params = params; wa.po = h->wpo; wa.wpk = ws + p.warp_wpk; wa.pk = h->wpk;
+      wa.nt_prim = p.ntiles[lv];
+      if (el_on) { wa.extra_dw4 = reinterpret_cast<const float4*>(ws + L.el_dw4); wa.extra_dv4 = reinterpret_cast<const float4*>(ws + L.el_dv4); }
       wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
       wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
       wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
@@ -802,6 +861,19 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
       h->prof.begin(lv == 0 ? "warp_dgrad_coarse" : "warp_dgrad_fine", warp_dgrad_flops_row(h) * p.rows[lv], stream);
       launch_warp_bwd(wa, grid, stream);
       h->prof.end(stream);
+      if (el_on) {   // reverse of the tangent pass
+        const LevelWs& T = p.L[TG];
+        WarpBwdArgs ta = wa;
+        ta.tangent = 1; ta.nt_prim = p.ntiles[0]; ta.ntiles = p.ntiles[TG]; ta.rows = p.rows[TG];
+        ta.extra_dw4 = ta.extra_dv4 = nullptr;
+        ta.d_points = nullptr; ta.st_win = nullptr; ta.st_wv = nullptr;
+        ta.dy = ws + T.w_dy; ta.d_w4 = reinterpret_cast<float4*>(ws + T.w_dw4); ta.d_v4 = reinterpret_cast<float4*>(ws + T.w_dv4);
+        ta.small_part = nullptr;
+        const int tgrid = p.ntiles[TG] < 2 * h->num_cus ? p.ntiles[TG] : 2 * h->num_cus;
+        h->prof.begin("warp_tangent_dgrad", 3.0 * warp_dgrad_flops_row(h) * p.rows[0], stream);
+        launch_warp_bwd(ta, tgrid, stream);
+        h->prof.end(stream);
+      }
     }
     h->prof.begin("cond_wgrad", 0, stream);
     launch_cond_wgrad(ws + p.cond, ws + L.dray, B, h->R, ws + L.cond_grad, stream);
@@ -838,6 +910,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
     wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
     wa.point_ids = bg->warp_ids;
+    wa.nt_prim = p.ntiles[BG];
     wa.S = 1; wa.B = p.bgN; wa.rows = p.bgN; wa.ntiles = p.ntiles[BG];
     wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
     wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
@@ -856,10 +929,12 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
   h->prof.end(stream);
   h->prof.begin("grad_reduce", 0, stream);
   const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
-  for (int pass = 0, at = 0; pass < 3; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
+  for (int pass = 0, at = 0; pass < 4; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
     if (p.nreduce_pass[pass] > 0) launch_reduce(rd + at, p.nreduce_pass[pass], ws, grad, stream);
+  const bool el_any = el && p.elastic && warp_on;
   if (stats) launch_finish_stats(ws + p.mse, B, bg_on ? ws + p.bg_loss : nullptr, bg_on ? p.bgN : 0, bg_on ? bg->loss_weight : 0.f,
-                                 stats, stream);
+                                 el_any ? ws + p.el_sums : nullptr, el_any ? (el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]) : 0, el_any ? el->loss_weight : 0.f, stats,
+                                 stream);
   h->prof.end(stream);
   return check_launch("nrf_backward");
 }
@@ -978,9 +1053,16 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
 
 int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
                                 const nrf_step_scalars* scalars, const nrf_rand* rnd, const nrf_background* bg,
-                                float* grad_params, float* stats, void* workspace, size_t workspace_bytes, void* stream) {
+                                const nrf_elastic* el, float* grad_params, float* stats, void* workspace,
+                                size_t workspace_bytes, void* stream) {
   if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
   int bgN = 0;
+  if (el) {
+    if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the elastic regulariser needs the warp field");
+    if (el->reduce_method != NRF_ELASTIC_WEIGHT && el->reduce_method != NRF_ELASTIC_MEDIAN)
+      return fail(NRF_E_UNSUPPORTED, "unknown elastic reduce_method");
+    if (!scalars) return fail(NRF_E_NULL, "nrf_step_scalars required");
+  }
   if (bg && bg->num_points > 0) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the background regulariser needs the warp field");
     if (!bg->points || !bg->warp_ids) return fail(NRF_E_NULL, "background points / warp_ids is null");
@@ -988,18 +1070,21 @@ int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_ray
     bgN = bg->num_points;
   }
   CK(forward_impl(h, params, rays, scalars, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes,
-                  (hipStream_t)stream, bgN));
+                  (hipStream_t)stream, bgN, el ? 1 : 0));
   const float* dr[2] = {nullptr, nullptr};
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream,
-                       bgN > 0 ? bg : nullptr, scalars);
+                       bgN > 0 ? bg : nullptr, scalars, el);
 }
 
-int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points, size_t* bytes) {
+int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points,
+                           int32_t use_elastic_loss, size_t* bytes) {
   if (!h || !bytes) return fail(NRF_E_NULL, "null");
   if (num_rays <= 0 || num_background_points < 0) return fail(NRF_E_SHAPE, "bad sizes");
-  if (num_background_points > 0 && !h->warp) return fail(NRF_E_UNSUPPORTED, "the background regulariser needs the warp field");
+  if ((num_background_points > 0 || use_elastic_loss) && !h->warp)
+    return fail(NRF_E_UNSUPPORTED, "the background / elastic regularisers need the warp field");
   query_device(h);
-  build_plan(h, num_rays, flags & NRF_FLAG_TRAIN, (flags & NRF_FLAG_TRAIN) ? num_background_points : 0);
+  const bool tr = flags & NRF_FLAG_TRAIN;
+  build_plan(h, num_rays, flags & NRF_FLAG_TRAIN, tr ? num_background_points : 0, tr && use_elastic_loss ? 1 : 0);
   *bytes = h->plan.total_floats * sizeof(float);
   return NRF_OK;
 }

@@ -128,7 +128,11 @@ struct WarpFwdArgs {
   float* st_win;             // [ntiles][PKw][128] trunk input (training stash)
   float* st_h;               // [6][ntiles][128*128] h1..h6, fragment-native
   float4* st_wv;             // [ntiles*128][2] raw head outputs (w, v)
-  uint32_t* bits;            // [6][ntiles][4 waves][64 lanes] x 2 dwords
+  uint32_t* bits;            // [6][ntiles][4 waves][64 lanes] sign bits of the trunk pre-activations
+  // tangent pass (prim_win != nullptr): tile tt = c * nt_prim + t, inputs / masks of primal tile t
+  int nt_prim;
+  const float* prim_win;
+  const uint32_t* prim_bits;
 };
 
 struct WarpBwdArgs {
@@ -149,6 +153,27 @@ struct WarpBwdArgs {
   float4* d_v4;              // [ntiles*128] (dv, 0)
   float* grad_embed;         // flat gradient + embedding offset (atomics)
   float* small_part;         // [gridDim.x][WARP_SMALL_PART]
+  const float4* extra_dw4;   // primal pass: + dL/d(w, v) of the elastic regulariser, or nullptr
+  const float4* extra_dv4;
+  int tangent;               // reverse of the tangent pass: d_w4 / d_v4 are INPUTS, masks of primal tile tt % nt_prim
+  int nt_prim;               // tiles of the primal level (== ntiles for the primal pass)
+};
+
+// training.compute_elastic_loss on the coarse samples (see warp_chain.hip elastic_kernel)
+struct ElasticArgs {
+  const float* prim_win;     // primal trunk-input stash (x = features 0..2)
+  const float4* prim_wv;     // primal raw head outputs (w, v) per row
+  const float4* tan_wv;      // [3][rows_pad] x 2: (dw/dx_c, dv/dx_c)
+  const float* coef;         // [rows] stop-gradient sample weights (elastic_reduce_method 'weight')
+  float4* tan_dw4;           // out [3][rows_pad]: dL/d(dw/dx_c)
+  float4* tan_dv4;
+  float4* prim_dw4;          // out [rows_pad]: dL/dw, dL/dv through exp_se3's second derivatives
+  float4* prim_dv4;
+  float* sums;               // [2] += sum coef*rho, sum residual
+  int rows, rows_pad, PKS;
+  float eps, alpha, scale;
+  float gscale;              // elastic_loss_weight / num_rays
+  int res_selected;          // 'median': the residual statistic only counts the selected sample of each ray
 };
 
 // One split-K slice of a weight-gradient GEMM  dW[k][n] = sum_rows X[row][k] dY[row][n].
@@ -203,6 +228,8 @@ void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t s
 void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
 void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream);
 void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream);
+void launch_elastic(const ElasticArgs& a, hipStream_t stream);
+void launch_median_coef(const float* weights, int B, int S, float* coef, hipStream_t stream);
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   unsigned long long* seg_clock, hipStream_t stream);
 void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
@@ -230,8 +257,8 @@ void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float
 void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
                             int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
                             float* grad, hipStream_t stream);
-void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, float* stats,
-                         hipStream_t stream);
+void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, const float* el_sums,
+                         int el_rows, float el_weight, float* stats, hipStream_t stream);
 void launch_background_loss(const float* points, const float* warped, int N, int rows_pad, float alpha, float scale,
                             float weight, float* d_points, float* loss_sum, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,

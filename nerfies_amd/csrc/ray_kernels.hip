@@ -418,22 +418,50 @@ void launch_cond_embed_grad(const float* params, const float* dray, const int32_
 }
 
 __global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, const float* __restrict__ bg_sum, int bgN,
-                                    float bg_weight, float* __restrict__ stats) {
+                                    float bg_weight, const float* __restrict__ el_sums, int el_rows, float el_weight,
+                                    float* __restrict__ stats) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float mc = mse_sums[0] / (3.f * B), mf = mse_sums[1] / (3.f * B);
     const float bgl = bg_sum ? bg_sum[0] / (float)bgN : 0.f;
+    const float ell = el_sums ? el_sums[0] / (float)B : 0.f;          // sum over samples, mean over rays (training.py:194)
     stats[0] = mc; stats[1] = mf;
     stats[2] = -10.f * logf(mc) / logf(10.f);   // utils.compute_psnr (utils.py:94-103)
     stats[3] = -10.f * logf(mf) / logf(10.f);
-    stats[4] = mc + mf + bg_weight * bgl;         // training.py:261 (+ :257-258)
+    stats[4] = mc + mf + bg_weight * bgl + el_weight * ell;   // training.py:261 (+ :197, :257-258)
     stats[5] = bgl;                               // stats['background_loss'] (training.py:259)
-    stats[6] = stats[7] = 0.f;
+    stats[6] = ell;                               // stats['loss/elastic']
+    stats[7] = el_sums ? el_sums[1] / (float)el_rows : 0.f;   // stats['residual/elastic'] (training.py:196)
   }
 }
 
-void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, float* stats,
-                         hipStream_t stream) {
-  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, mse_sums, B, bg_sum, bgN, bg_weight, stats);
+void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, const float* el_sums,
+                         int el_rows, float el_weight, float* stats, hipStream_t stream) {
+  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, mse_sums, B, bg_sum, bgN, bg_weight, el_sums, el_rows,
+                     el_weight, stats);
+}
+
+// ------------------------------------------------------------------ elastic 'median' reduce
+// coef[ray][s] = 1 at model_utils.compute_depth_index(weights) (first sample whose cumulative weight reaches
+// 0.5, sample 0 if none does: argmax of an all-zero mask, model_utils.py:218-246), else 0.
+__global__ __launch_bounds__(256) void median_coef_kernel(const float* __restrict__ w, int B, int S, float* __restrict__ coef) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= B) return;
+  float carry = 0.f;
+  int idx = 0;
+  bool found = false;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const float cum = wave_incl_sum(s < S ? w[(size_t)ray * S + s] : 0.f, lane) + carry;
+    const unsigned long long m = __ballot(s < S && cum >= 0.5f);
+    if (!found && m) { idx = s0 + __ffsll((long long)m) - 1; found = true; }
+    carry = __shfl(cum, 63);
+  }
+  for (int s = lane; s < S; s += 64) coef[(size_t)ray * S + s] = s == idx ? 1.f : 0.f;
+}
+
+void launch_median_coef(const float* weights, int B, int S, float* coef, hipStream_t stream) {
+  hipLaunchKernelGGL(median_coef_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, weights, B, S, coef);
 }
 
 // ------------------------------------------------------------------ background regulariser

@@ -19,75 +19,108 @@ namespace nrf {
 // small_part layout (floats): db_trunk[6][128] | db_w[3] | db_v[3]
 constexpr int WSP_DB_TRUNK = 0, WSP_DB_W = 768, WSP_DB_V = 771;
 
-struct V3 { float x, y, z; };
-__device__ __forceinline__ V3 v3(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
-__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
-__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
-__device__ __forceinline__ V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
-__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-__device__ __forceinline__ V3 cross(V3 a, V3 b) {
-  return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+// Scalar with one forward-mode tangent: the warp Jacobian (jax.jacfwd(self.warp), warping.py:385-387) and the
+// Hessian-vector products its reverse pass needs both come from running the SAME closed forms on Duals.
+struct Dual {
+  float v, d;
+  __device__ __forceinline__ Dual() : v(0.f), d(0.f) {}
+  __device__ __forceinline__ Dual(float a) : v(a), d(0.f) {}
+  __device__ __forceinline__ Dual(float a, float b) : v(a), d(b) {}
+};
+__device__ __forceinline__ Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+__device__ __forceinline__ Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+__device__ __forceinline__ Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.v * b.d + a.d * b.v); }
+__device__ __forceinline__ Dual operator/(Dual a, Dual b) { const float q = a.v / b.v; return Dual(q, (a.d - q * b.d) / b.v); }
+__device__ __forceinline__ float val(float a) { return a; }
+__device__ __forceinline__ float val(Dual a) { return a.v; }
+__device__ __forceinline__ float sqrt_t(float a) { return sqrtf(a); }
+__device__ __forceinline__ Dual sqrt_t(Dual a) { const float r = sqrtf(a.v); return Dual(r, 0.5f * a.d / r); }
+__device__ __forceinline__ void sincos_t(float a, float& s, float& c) { sincosf(a, &s, &c); }
+__device__ __forceinline__ void sincos_t(Dual a, Dual& s, Dual& c) {
+  float sv, cv;
+  sincosf(a.v, &sv, &cv);
+  s = Dual(sv, cv * a.d); c = Dual(cv, -sv * a.d);
+}
+
+template <typename T> struct V3T { T x, y, z; };
+typedef V3T<float> V3;
+template <typename T> __device__ __forceinline__ V3T<T> v3t(T x, T y, T z) { V3T<T> r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 v3(float x, float y, float z) { return v3t<float>(x, y, z); }
+template <typename T> __device__ __forceinline__ V3T<T> operator+(V3T<T> a, V3T<T> b) { return v3t<T>(a.x + b.x, a.y + b.y, a.z + b.z); }
+template <typename T> __device__ __forceinline__ V3T<T> operator-(V3T<T> a, V3T<T> b) { return v3t<T>(a.x - b.x, a.y - b.y, a.z - b.z); }
+template <typename T> __device__ __forceinline__ V3T<T> operator*(T s, V3T<T> a) { return v3t<T>(s * a.x, s * a.y, s * a.z); }
+template <typename T> __device__ __forceinline__ T dot(V3T<T> a, V3T<T> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename T> __device__ __forceinline__ V3T<T> cross(V3T<T> a, V3T<T> b) {
+  return v3t<T>(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 
 // Coefficients of the closed form of exp_se3 applied to a point, as functions of
 // t2 = |w|^2:  A = sin t / t,  B = (1 - cos t) / t^2,  C = (t - sin t) / t^3  and their
 // derivatives  dA/dw = Ab w,  dB/dw = Bb w,  dC/dw = Cb w  with
-//   Ab = C - B... (= (t cos t - sin t)/t^3),  Bb = (A - 2B)/t^2,  Cb = (B - 3C)/t^2.
+//   Ab = C - B (= (t cos t - sin t)/t^3),  Bb = (A - 2B)/t^2,  Cb = (B - 3C)/t^2.
 // The reference evaluates the un-simplified normalised-axis form in fp32 (rigid_body.py:54-89),
 // whose 1-cos / t-sin terms cancel catastrophically for small angles and are NaN at t = 0; here
 // small angles use the Taylor series, so the result tracks the exact value to fp32 rounding.
-struct Se3Coef { float A, B, C, Ab, Bb, Cb; };
-__device__ __forceinline__ Se3Coef se3_coef(float t2) {
-  Se3Coef c;
-  if (t2 < 0.04f) {
-    c.A = 1.f + t2 * (-1.f / 6.f + t2 * (1.f / 120.f + t2 * (-1.f / 5040.f)));
-    c.B = 0.5f + t2 * (-1.f / 24.f + t2 * (1.f / 720.f + t2 * (-1.f / 40320.f)));
-    c.C = 1.f / 6.f + t2 * (-1.f / 120.f + t2 * (1.f / 5040.f + t2 * (-1.f / 362880.f)));
-    c.Ab = -1.f / 3.f + t2 * (1.f / 30.f + t2 * (-1.f / 840.f + t2 * (1.f / 45360.f)));
-    c.Bb = -1.f / 12.f + t2 * (1.f / 180.f + t2 * (-1.f / 6720.f + t2 * (1.f / 453600.f)));
-    c.Cb = -1.f / 60.f + t2 * (1.f / 1260.f + t2 * (-1.f / 60480.f + t2 * (1.f / 4989600.f)));
+template <typename T> struct Se3Coef { T A, B, C, Ab, Bb, Cb; };
+template <typename T>
+__device__ __forceinline__ Se3Coef<T> se3_coef(T t2) {
+  Se3Coef<T> c;
+  if (val(t2) < 0.04f) {
+    c.A = T(1.f) + t2 * (T(-1.f / 6.f) + t2 * (T(1.f / 120.f) + t2 * T(-1.f / 5040.f)));
+    c.B = T(0.5f) + t2 * (T(-1.f / 24.f) + t2 * (T(1.f / 720.f) + t2 * T(-1.f / 40320.f)));
+    c.C = T(1.f / 6.f) + t2 * (T(-1.f / 120.f) + t2 * (T(1.f / 5040.f) + t2 * T(-1.f / 362880.f)));
+    c.Ab = T(-1.f / 3.f) + t2 * (T(1.f / 30.f) + t2 * (T(-1.f / 840.f) + t2 * T(1.f / 45360.f)));
+    c.Bb = T(-1.f / 12.f) + t2 * (T(1.f / 180.f) + t2 * (T(-1.f / 6720.f) + t2 * T(1.f / 453600.f)));
+    c.Cb = T(-1.f / 60.f) + t2 * (T(1.f / 1260.f) + t2 * (T(-1.f / 60480.f) + t2 * T(1.f / 4989600.f)));
   } else {
-    const float t = sqrtf(t2);
-    float s, co;
-    sincosf(t, &s, &co);
-    const float sh = sinf(0.5f * t);
+    const T t = sqrt_t(t2);
+    T s, co, sh, ch;
+    sincos_t(t, s, co);
+    sincos_t(T(0.5f) * t, sh, ch);
     c.A = s / t;
-    c.B = 2.f * sh * sh / t2;
+    c.B = T(2.f) * sh * sh / t2;
     c.C = (t - s) / (t2 * t);
     c.Ab = c.C - c.B;
-    c.Bb = (c.A - 2.f * c.B) / t2;
-    c.Cb = (c.B - 3.f * c.C) / t2;
+    c.Bb = (c.A - T(2.f) * c.B) / t2;
+    c.Cb = (c.B - T(3.f) * c.C) / t2;
   }
   return c;
 }
 
-// x' = exp_se3([w; v]) x = x + A w*x + B w*(w*x) + v + B w*v + C w*(w*v)   (warping.py:330-344)
-__device__ __forceinline__ V3 se3_apply(V3 w, V3 v, V3 x) {
-  const Se3Coef c = se3_coef(dot(w, w));
-  const V3 wx = cross(w, x), wv = cross(w, v);
-  const V3 wwx = cross(w, wx), wwv = cross(w, wv);
-  return x + c.A * wx + c.B * wwx + v + c.B * wv + c.C * wwv;
+// x' - x = exp_se3([w; v]) x - x = A w*x + B w*(w*x) + v + B w*v + C w*(w*v)   (warping.py:330-344)
+template <typename T>
+__device__ __forceinline__ V3T<T> se3_delta(V3T<T> w, V3T<T> v, V3T<T> x) {
+  const Se3Coef<T> c = se3_coef<T>(dot(w, w));
+  const V3T<T> wx = cross(w, x), wv = cross(w, v);
+  const V3T<T> wwx = cross(w, wx), wwv = cross(w, wv);
+  return c.A * wx + c.B * wwx + v + c.B * wv + c.C * wwv;
 }
+__device__ __forceinline__ V3 se3_apply(V3 w, V3 v, V3 x) { return x + se3_delta<float>(w, v, x); }
 
 // VJP of se3_apply for upstream g = dL/dx':  dL/dw, dL/dv  (dL/dx is not needed: sample points
-// carry no parameters).
-__device__ __forceinline__ void se3_vjp(V3 w, V3 v, V3 x, V3 g, V3& dw, V3& dv) {
-  const Se3Coef c = se3_coef(dot(w, w));
-  const V3 gw = cross(g, w);            // g x w
-  const V3 wgw = cross(w, cross(w, g)); // w x (w x g)
-  dv = g + c.B * gw + c.C * wgw;        // V^T g
-  const V3 wx = cross(w, x), wv = cross(w, v);
-  const V3 wwx = cross(w, wx), wwv = cross(w, wv);
-  const float wg = dot(w, g);
-  auto D = [&](V3 y) { return wg * y + dot(w, y) * g - 2.f * dot(y, g) * w; };
-  const float sa = c.Ab * dot(g, wx) + c.Bb * (dot(g, wwx) + dot(g, wv)) + c.Cb * dot(g, wwv);
+// carry no parameters).  On Duals the value parts are the VJP, the tangent parts its directional
+// derivative = the Hessian-vector product of g . exp_se3(w, v) x along the Dual direction.
+template <typename T>
+__device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, V3T<T>& dw, V3T<T>& dv) {
+  const Se3Coef<T> c = se3_coef<T>(dot(w, w));
+  const V3T<T> gw = cross(g, w);            // g x w
+  const V3T<T> wgw = cross(w, cross(w, g)); // w x (w x g)
+  dv = g + c.B * gw + c.C * wgw;            // V^T g
+  const V3T<T> wx = cross(w, x), wv = cross(w, v);
+  const V3T<T> wwx = cross(w, wx), wwv = cross(w, wv);
+  const T wg = dot(w, g);
+  auto D = [&](V3T<T> y) { return wg * y + dot(w, y) * g - (T(2.f) * dot(y, g)) * w; };
+  const T sa = c.Ab * dot(g, wx) + c.Bb * (dot(g, wwx) + dot(g, wv)) + c.Cb * dot(g, wwv);
   dw = c.A * cross(x, g) + c.B * (D(x) + cross(v, g)) + c.C * D(v) + sa * w;
 }
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <bool STASH>
+// TANGENT: forward-mode pass of the warp Jacobian (warping.py:385-387): tile tt = c * nt_prim + t carries the
+// tangent of primal tile t along coordinate c through the trunk (no biases, ReLU derivative = the primal
+// sign bits) and emits (dw/dx_c, dv/dx_c) per row; exp_se3's part of the Jacobian is applied by elastic_kernel.
+template <bool STASH, bool TANGENT>
 __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* act = smem;                  // [128][64] swizzled
@@ -104,9 +137,36 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
 
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
     // ---- prologue: sample point, AnnealedSinusoidalEncoder (modules.py:231-294), GLO code ----
-    float x[3];
+    float x[3] = {0.f, 0.f, 0.f};
     const int row = tile * TILE_ROWS + p;
-    {
+    const int tprim = TANGENT ? tile % A.nt_prim : tile;   // primal tile whose masks / inputs this tile uses
+    if (TANGENT) {
+      // d input / d x_c from the primal input tile: d(win sin a) = f (win cos a), d(win cos a) = -f (win sin a)
+      const int c = tile / A.nt_prim;
+      const float* pw = A.prim_win + (size_t)tprim * PKS * TILE_ROWS;
+      float* stp = STASH ? A.st_win + (size_t)tile * PKS * TILE_ROWS : nullptr;
+      auto put = [&](int k, float v) {
+        win[k * TILE_ROWS + p] = v;
+        if (STASH) stp[frag_index(k, p)] = v;
+      };
+      if (part == 0) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) put(cc, cc == c ? 1.f : 0.f);
+      } else if (part == 1) {
+        for (int k = 3 + 6 * A.F; k < PKw; ++k) put(k, 0.f);
+        if (STASH) for (int k = PKw; k < PKS; ++k) stp[frag_index(k, p)] = 0.f;
+      }
+      for (int f = part; f < A.F; f += 4) {
+        const float fr = (float)(1 << f);
+        const int ns = 3 + 6 * f, nc = ns + 3;
+        const float sn = pw[frag_index(ns + c, p)], cs = pw[frag_index(nc + c, p)];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          put(ns + cc, cc == c ? fr * cs : 0.f);
+          put(nc + cc, cc == c ? -fr * sn : 0.f);
+        }
+      }
+    } else {
       const int r = row < A.rows ? row : A.rows - 1;
       int id;
       if (A.points_in) {
@@ -161,7 +221,8 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
     WQuad<1> wnext = prefetch_quad<1>(wL0, lane);
 #pragma unroll 1
     for (int l = 0; l < WARP_DEPTH; ++l) {
-      bias_acc<1>(acc, prm + A.po.trunk_b[l], wave * 32, lane);
+      if (TANGENT) zero_acc<1>(acc);
+      else bias_acc<1>(acc, prm + A.po.trunk_b[l], wave * 32, lane);
       if (l == 0) {
         mfma_k_loop<1, false>(acc, win, nq_in, wL0, lane, wnext);
       } else {
@@ -173,10 +234,16 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
       }
       wnext = prefetch_quad<1>(wpk4 + (A.pk.fwd_L[l + 1 < WARP_DEPTH ? l + 1 : l] / 4) + wave * 16 * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
-      fwd_epilogue<1, true, STASH>(
-          acc, wave * 32, act,
-          make_rsrc(STASH ? A.st_h + l * st_layer + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4),
-          wave * 8 * 1024, STASH ? A.bits + (((size_t)l * A.ntiles + tile) * 4 + wave) * 64 : nullptr, lane);
+      if (TANGENT)
+        fwd_epilogue<1, EPI_MASK, STASH>(
+            acc, wave * 32, act,
+            make_rsrc(STASH ? A.st_h + l * st_layer + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4), wave * 8 * 1024,
+            const_cast<uint32_t*>(A.prim_bits) + (((size_t)l * A.nt_prim + tprim) * 4 + wave) * 64, lane);
+      else
+        fwd_epilogue<1, EPI_RELU, STASH>(
+            acc, wave * 32, act,
+            make_rsrc(STASH ? A.st_h + l * st_layer + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4),
+            wave * 8 * 1024, STASH ? A.bits + (((size_t)l * A.ntiles + tile) * 4 + wave) * 64 : nullptr, lane);
     }
 
     // ---- heads: w = Dense(128->3)(h), v = Dense(128->3)(h)  (warping.py:271-288, 328-329) ----
@@ -193,7 +260,13 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
 #pragma unroll
       for (int c = 0; c < 6; ++c) win[(6 * part + c) * TILE_ROWS + p] = s[c];
       __syncthreads();
-      if (part == 0) {
+      if (part == 0 && TANGENT) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+          s[c] = (win[c * TILE_ROWS + p] + win[(6 + c) * TILE_ROWS + p]) + (win[(12 + c) * TILE_ROWS + p] + win[(18 + c) * TILE_ROWS + p]);
+        A.st_wv[2 * (size_t)row] = make_float4(s[0], s[1], s[2], 0.f);       // dw / dx_c
+        A.st_wv[2 * (size_t)row + 1] = make_float4(s[3], s[4], s[5], 0.f);   // dv / dx_c
+      } else if (part == 0) {
 #pragma unroll
         for (int c = 0; c < 6; ++c)
           s[c] = (win[c * TILE_ROWS + p] + win[(6 + c) * TILE_ROWS + p]) + (win[(12 + c) * TILE_ROWS + p] + win[(18 + c) * TILE_ROWS + p]) +
@@ -214,18 +287,21 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
 void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream) {
   const int pk = a.PKw < 32 ? 32 : a.PKw;   // the head scratch needs 24 rows
   const size_t lds = (size_t)(WACT_FLOATS + pk * TILE_ROWS) * sizeof(float);
-  if (stash) {
-    (void)hipFuncSetAttribute((const void*)se3_warp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(se3_warp_fwd_kernel<true>, dim3(grid), dim3(256), lds, stream, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)se3_warp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(se3_warp_fwd_kernel<false>, dim3(grid), dim3(256), lds, stream, a);
-  }
+  const void* fn = a.prim_win ? (const void*)se3_warp_fwd_kernel<true, true>
+                              : stash ? (const void*)se3_warp_fwd_kernel<true, false> : (const void*)se3_warp_fwd_kernel<false, false>;
+  (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (a.prim_win) hipLaunchKernelGGL((se3_warp_fwd_kernel<true, true>), dim3(grid), dim3(256), lds, stream, a);
+  else if (stash) hipLaunchKernelGGL((se3_warp_fwd_kernel<true, false>), dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL((se3_warp_fwd_kernel<false, false>), dim3(grid), dim3(256), lds, stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------
 // backward (data gradients of the trunk, bias gradients, GLO-code gradient)
 // ---------------------------------------------------------------------------------------------
+// TANGENT: reverse of the tangent pass: starts from dL/d(dw/dx_c), dL/d(dv/dx_c) (written by elastic_kernel into
+// d_w4 / d_v4), same masks as the primal tile, no bias / GLO-code gradients (the tangent input does not depend
+// on them); its dY stash feeds the wgrad kernel together with the tangent activations.
+template <bool TANGENT>
 __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* act = smem;                       // [128][64] swizzled: current dpre tile
@@ -249,8 +325,16 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
 
 #pragma unroll 1
   for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+    const int tprim = TANGENT ? tile % A.nt_prim : tile;
     // ---- exp_se3 VJP per row ----
-    if (tid < TILE_ROWS) {
+    if (TANGENT) {
+      if (tid < TILE_ROWS) {
+        const int row = tile * TILE_ROWS + tid;
+        const float4 a = A.d_w4[row], b = A.d_v4[row];
+        dwv[tid] = a.x; dwv[TILE_ROWS + tid] = a.y; dwv[2 * TILE_ROWS + tid] = a.z;
+        dwv[3 * TILE_ROWS + tid] = b.x; dwv[4 * TILE_ROWS + tid] = b.y; dwv[5 * TILE_ROWS + tid] = b.z;
+      }
+    } else if (tid < TILE_ROWS) {
       const int row = tile * TILE_ROWS + tid;
       V3 dw = v3(0.f, 0.f, 0.f), dv = dw;
       if (row < A.rows) {
@@ -258,7 +342,11 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
         const V3 x = v3(sw[frag_index(0, tid)], sw[frag_index(1, tid)], sw[frag_index(2, tid)]);
         const float4 w4 = A.st_wv[2 * (size_t)row], v4 = A.st_wv[2 * (size_t)row + 1];
         const V3 g = v3(A.d_points[3 * (size_t)row], A.d_points[3 * (size_t)row + 1], A.d_points[3 * (size_t)row + 2]);
-        se3_vjp(v3(w4.x, w4.y, w4.z), v3(v4.x, v4.y, v4.z), x, g, dw, dv);
+        se3_vjp<float>(v3(w4.x, w4.y, w4.z), v3(v4.x, v4.y, v4.z), x, g, dw, dv);
+        if (A.extra_dw4) {   // + the elastic regulariser's gradient w.r.t. the primal head outputs
+          const float4 a = A.extra_dw4[row], b = A.extra_dv4[row];
+          dw = dw + v3(a.x, a.y, a.z); dv = dv + v3(b.x, b.y, b.z);
+        }
       }
       dwv[tid] = dw.x; dwv[TILE_ROWS + tid] = dw.y; dwv[2 * TILE_ROWS + tid] = dw.z;
       dwv[3 * TILE_ROWS + tid] = dv.x; dwv[4 * TILE_ROWS + tid] = dv.y; dwv[5 * TILE_ROWS + tid] = dv.z;
@@ -273,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
       float wh[6];
 #pragma unroll
       for (int c = 0; c < 3; ++c) { wh[c] = prm[A.po.w_k + 3 * n + c]; wh[3 + c] = prm[A.po.v_k + 3 * n + c]; }
-      const uint32_t mb = A.bits[(((size_t)(WARP_DEPTH - 1) * A.ntiles + tile) * 4 + wave) * 64 + lane];
+      const uint32_t mb = A.bits[(((size_t)(WARP_DEPTH - 1) * A.nt_prim + tprim) * 4 + wave) * 64 + lane];
       const __amdgpu_buffer_rsrc_t dy =
           make_rsrc(A.dy + (size_t)(WARP_DEPTH - 1) * layer_fl + (size_t)tile * FRAG_TILE_128, FRAG_TILE_128 * 4);
       float bsum = 0.f;
@@ -314,8 +402,8 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
     WQuad<1> wnext = prefetch_quad<1>(wpk4 + (A.pk.bwd_LT[WARP_DEPTH - 1] / 4) + wave * 16 * 64, lane);
 #pragma unroll 1
     for (int l = WARP_DEPTH - 1; l >= 1; --l) {
-      if (l == WARP_SKIP) code_grad(A.po.trunk_k[WARP_SKIP] + (int64_t)(WARP_W + 3 + 6 * A.F) * WARP_W);
-      const uint32_t mb = A.bits[(((size_t)(l - 1) * A.ntiles + tile) * 4 + wave) * 64 + lane];
+      if (!TANGENT && l == WARP_SKIP) code_grad(A.po.trunk_k[WARP_SKIP] + (int64_t)(WARP_W + 3 + 6 * A.F) * WARP_W);
+      const uint32_t mb = A.bits[(((size_t)(l - 1) * A.nt_prim + tprim) * 4 + wave) * 64 + lane];
       zero_acc<1>(acc);
       mfma_k_loop<1, true>(acc, act, 8, wpk4 + (A.pk.bwd_LT[l] / 4) + wave * 16 * 64, lane, wnext);
       wnext = prefetch_quad<1>(wpk4 + (A.pk.bwd_LT[l > 1 ? l - 1 : 1] / 4) + wave * 16 * 64, lane);
@@ -336,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
         if (q == l - 1) db[q] += bsum;
       __syncthreads();
     }
+    if (TANGENT) continue;
     code_grad(A.po.trunk_k[0] + (int64_t)(3 + 6 * A.F) * WARP_W);
 
     // ---- per-ray sums of d code -> scatter-add into the embedding-table gradient ----
@@ -364,6 +453,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
     __syncthreads();
   }
 
+  if (TANGENT) return;
   // ---- flush the per-workgroup bias partials ----
   float* sp = A.small_part + (size_t)blockIdx.x * WARP_SMALL_PART;
 #pragma unroll
@@ -386,8 +476,151 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
 
 void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)(WACT_FLOATS + 16 * TILE_ROWS) * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)se3_warp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(se3_warp_bwd_kernel, dim3(grid), dim3(256), lds, stream, a);
+  if (a.tangent) {
+    (void)hipFuncSetAttribute((const void*)se3_warp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(se3_warp_bwd_kernel<true>, dim3(grid), dim3(256), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)se3_warp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(se3_warp_bwd_kernel<false>, dim3(grid), dim3(256), lds, stream, a);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// elastic regulariser (training.compute_elastic_loss, training.py:71-114, 177-197; loss_type 'log_svals')
+// ---------------------------------------------------------------------------------------------
+// Symmetric 3x3 eigen-decomposition (cyclic Jacobi): D = V diag(mu) V^T.
+__device__ __forceinline__ void jacobi3(float (&D)[3][3], float (&V)[3][3]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) V[i][k] = i == k ? 1.f : 0.f;
+  for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll
+    for (int pq = 0; pq < 3; ++pq) {
+      const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+      const float apq = D[p][q];
+      if (fabsf(apq) < 1e-30f) continue;
+      const float theta = (D[q][q] - D[p][p]) / (2.f * apq);
+      const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
+      const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {   // D <- D J
+        const float dkp = D[k][p], dkq = D[k][q];
+        D[k][p] = c * dkp - s * dkq; D[k][q] = s * dkp + c * dkq;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {   // D <- J^T D
+        const float dpk = D[p][k], dqk = D[q][k];
+        D[p][k] = c * dpk - s * dqk; D[q][k] = s * dpk + c * dqk;
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float vkp = V[k][p], vkq = V[k][q];
+        V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+      }
+    }
+  }
+}
+
+// One thread per coarse sample.  With the raw head outputs (w, v), their tangents (wd_c, vd_c) along x_c and the
+// point x:  E = J - I, column c = d/dx_c [exp_se3(w, v) x - x] (Dual evaluation of se3_delta);
+// J^T J - I = E + E^T + E^T E = V diag(mu) V^T;  log s_k = 0.5 log1p(mu_k)  (accurate near the identity);
+// sq = sum log(max(s_k, eps))^2;  rho = general_loss(sq, alpha, scale);  L = (1/B) sum_rows coef_row rho_row.
+// dL/dJ = coef/B * weight * rho'(sq) * J V diag(2 log s_k / s_k^2) V^T;  its pull-back through exp_se3 comes
+// from se3_vjp on Duals: value parts -> adjoints of (wd_c, vd_c), tangent parts (Hessian-vector products)
+// -> adjoints of the primal (w, v).
+__global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  float rho_c = 0.f, res = 0.f;
+  if (row < A.rows_pad) {
+    V3 wbar = v3(0.f, 0.f, 0.f), vbar = wbar;
+    V3 wdb[3], vdb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) wdb[c] = vdb[c] = v3(0.f, 0.f, 0.f);
+    if (row < A.rows) {
+      const int tile = row / TILE_ROWS, p = row % TILE_ROWS;
+      const float* sw = A.prim_win + (size_t)tile * A.PKS * TILE_ROWS;
+      const V3 x = v3(sw[frag_index(0, p)], sw[frag_index(1, p)], sw[frag_index(2, p)]);
+      const float4 w4 = A.prim_wv[2 * (size_t)row], v4 = A.prim_wv[2 * (size_t)row + 1];
+      const V3 w = v3(w4.x, w4.y, w4.z), v = v3(v4.x, v4.y, v4.z);
+      V3 wd[3], vd[3];
+      float E[3][3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const size_t tr = (size_t)c * A.rows_pad + row;
+        const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
+        wd[c] = v3(a.x, a.y, a.z); vd[c] = v3(b.x, b.y, b.z);
+        const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
+        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
+        const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
+        const V3T<Dual> dl = se3_delta<Dual>(W, Vv, X);
+        E[0][c] = dl.x.d; E[1][c] = dl.y.d; E[2][c] = dl.z.d;
+      }
+      float D[3][3], Vm[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) D[i][k] = E[i][k] + E[k][i] + (E[0][i] * E[0][k] + E[1][i] * E[1][k] + E[2][i] * E[2][k]);
+      jacobi3(D, Vm);
+      float m[3], sq = 0.f;
+      const float log_eps = logf(A.eps);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float mu = D[k][k], lam = 1.f + mu;
+        const bool live = lam > A.eps * A.eps;     // s_k > eps (training.py:88)
+        const float ls = live ? 0.5f * log1pf(mu) : log_eps;
+        sq += ls * ls;
+        m[k] = live ? 2.f * ls / lam : 0.f;         // (d sq / d s_k) / s_k
+      }
+      const float beta = fmaxf(1.1920929e-7f, fabsf(A.alpha - 2.f));
+      const float a_safe = (A.alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(A.alpha));
+      const float u = sq / (A.scale * A.scale * beta) + 1.f;
+      const float rho = A.scale * (beta / a_safe) * (powf(u, 0.5f * A.alpha) - 1.f);
+      const float drho = (0.5f / A.scale) * powf(u, 0.5f * A.alpha - 1.f);
+      const float coef = A.coef[row];
+      rho_c = coef * rho;
+      res = (A.res_selected && coef == 0.f) ? 0.f : sqrtf(sq);
+      // G = gs * J M,  M = V diag(m) V^T,  J = I + E
+      const float gs = coef * A.gscale * drho;
+      float M[3][3], G[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) M[i][k] = Vm[i][0] * m[0] * Vm[k][0] + Vm[i][1] * m[1] * Vm[k][1] + Vm[i][2] * m[2] * Vm[k][2];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) G[i][k] = gs * (M[i][k] + E[i][0] * M[0][k] + E[i][1] * M[1][k] + E[i][2] * M[2][k]);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
+        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
+        const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
+        const V3T<Dual> g = v3t<Dual>(Dual(G[0][c]), Dual(G[1][c]), Dual(G[2][c]));
+        V3T<Dual> dw, dv;
+        se3_vjp<Dual>(W, Vv, X, g, dw, dv);
+        wdb[c] = v3(dw.x.v, dw.y.v, dw.z.v); vdb[c] = v3(dv.x.v, dv.y.v, dv.z.v);
+        wbar = wbar + v3(dw.x.d, dw.y.d, dw.z.d); vbar = vbar + v3(dv.x.d, dv.y.d, dv.z.d);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t tr = (size_t)c * A.rows_pad + row;
+      A.tan_dw4[tr] = make_float4(wdb[c].x, wdb[c].y, wdb[c].z, 0.f);
+      A.tan_dv4[tr] = make_float4(vdb[c].x, vdb[c].y, vdb[c].z, 0.f);
+    }
+    A.prim_dw4[row] = make_float4(wbar.x, wbar.y, wbar.z, 0.f);
+    A.prim_dv4[row] = make_float4(vbar.x, vbar.y, vbar.z, 0.f);
+  }
+  // loss / residual sums (one atomic per wave)
+  float a = rho_c, b = res;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if ((threadIdx.x & 63) == 0 && (a != 0.f || b != 0.f)) { atomicAdd(A.sums, a); atomicAdd(A.sums + 1, b); }
+}
+
+void launch_elastic(const ElasticArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(elastic_kernel, dim3((a.rows_pad + 255) / 256), dim3(256), 0, stream, a);
 }
 
 }  // namespace nrf

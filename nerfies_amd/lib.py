@@ -64,6 +64,11 @@ class Background(C.Structure):
               ('loss_alpha', C.c_float), ('loss_scale', C.c_float)]
 
 
+class Elastic(C.Structure):
+  _fields_ = [('loss_weight', C.c_float), ('reduce_method', C.c_int32), ('eps', C.c_float), ('loss_alpha', C.c_float),
+              ('loss_scale', C.c_float)]
+
+
 class ProfileEntry(C.Structure):
   _fields_ = [('name', C.c_char * 32), ('ms', C.c_double), ('launches', C.c_int32), ('pad_', C.c_int32),
               ('flops_per_launch', C.c_double)]
@@ -114,8 +119,8 @@ def load_library(path=None):
       'nrf_debug_wgrad_segments': [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)],
       'nrf_debug_ws_offset': [vp, C.c_char_p, i32, C.POINTER(i64)],
       'nrf_train_step_loss_grad_ex': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand),
-                                      C.POINTER(Background), vp, vp, vp, C.c_size_t, vp],
-      'nrf_workspace_bytes_ex': [vp, i32, u32, i32, C.POINTER(C.c_size_t)],
+                                      C.POINTER(Background), C.POINTER(Elastic), vp, vp, vp, C.c_size_t, vp],
+      'nrf_workspace_bytes_ex': [vp, i32, u32, i32, i32, C.POINTER(C.c_size_t)],
       'nrf_warp_points_workspace_bytes': [vp, i32, C.POINTER(C.c_size_t)],
       'nrf_warp_points': [vp, vp, vp, vp, i32, C.POINTER(StepScalars), vp, vp, C.c_size_t, vp],
   }

@@ -182,13 +182,13 @@ class NerfModel:
       self._layout = P.layout_from_infos(infos, total.value)
     return self._layout
 
-  def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0) -> torch.Tensor:
-    key = (int(num_rays), bool(train), str(device), int(num_background_points))
+  def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0, elastic: bool = False) -> torch.Tensor:
+    key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic))
     ws = self._ws.get(key)
     if ws is None:
       nbytes = C.c_size_t(0)
       L.check(self.lib.nrf_workspace_bytes_ex(self.handle, num_rays, L.NRF_FLAG_TRAIN if train else 0,
-                                              int(num_background_points), C.byref(nbytes)), self.lib)
+                                              int(num_background_points), int(bool(elastic)), C.byref(nbytes)), self.lib)
       ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
       self._ws[key] = ws
     return ws
@@ -303,10 +303,13 @@ class NerfModel:
     return grad
 
   def loss_and_grad(self, fp: P.FlatParams, batch, warp_extra=None, rngs=None, grad_out=None, stats_out=None,
-                    background=None):
+                    background=None, elastic=None):
     """forward + MSE_coarse + MSE_fine [+ background regulariser] + backward in one library call
     (training.py:168-265).  `background` = dict(points (N,3) already noised, warp_ids (N,), weight, alpha=-2,
-    scale=1e-3) adds weight * mean(general_loss(|warp(x) - x|^2)) (training.py:117-135, 248-259)."""
+    scale=1e-3) adds weight * mean(general_loss(|warp(x) - x|^2)) (training.py:117-135, 248-259).
+    `elastic` = dict(weight, reduce_method='weight', eps=1e-6, alpha=-2, scale=0.03) adds the elastic regulariser
+    on the coarse samples (training.py:71-114, 177-197).  stats = [mse_c, mse_f, psnr_c, psnr_f, total,
+    background_loss, loss/elastic, residual/elastic]."""
     device = fp.flat.device
     rays, keep = self._rays_struct(batch, device)
     rnd, keep2 = self._rand_struct(rngs, rays.num_rays, device)
@@ -322,10 +325,18 @@ class NerfModel:
       keep3 = [pts, ids]
       bg = L.Background(nbg, _ptr(pts), _ptr(ids), float(background.get('weight', 1.0)), float(background.get('alpha', -2.0)),
                         float(background.get('scale', 0.001)))
-    ws = self.workspace(rays.num_rays, True, device, nbg)
+    el = None
+    if elastic is not None:
+      method = elastic.get('reduce_method', 'weight')
+      if method not in ('weight', 'median'):
+        raise L.NrfError(f'unknown elastic_reduce_method {method!r}')
+      el = L.Elastic(float(elastic.get('weight', 0.0)), 0 if method == 'weight' else 1, float(elastic.get('eps', 1e-6)),
+                     float(elastic.get('alpha', -2.0)), float(elastic.get('scale', 0.03)))
+    ws = self.workspace(rays.num_rays, True, device, nbg, el is not None)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     L.check(self.lib.nrf_train_step_loss_grad_ex(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
-                                                 C.byref(rnd), C.byref(bg) if bg is not None else None, _ptr(grad),
+                                                 C.byref(rnd), C.byref(bg) if bg is not None else None,
+                                                 C.byref(el) if el is not None else None, _ptr(grad),
                                                  _ptr(stats), _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2, keep3
     return grad, stats

@@ -92,9 +92,10 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
                use_warp_reg_loss: bool = False):
   """One optimisation step (training.py:138-271).  `batch` holds this rank's ray shard
   ('rgb','origins','directions','metadata').  Returns (new_state, stats, rng_key)."""
-  if use_elastic_loss or use_warp_reg_loss:
-    raise L.NrfError('elastic / warp-reg losses (forward-mode warp Jacobian, SURVEY 8f rank 1) are not built yet')
-  del elastic_reduce_method, elastic_loss_type
+  if use_warp_reg_loss:
+    raise L.NrfError('warp_reg loss is not built (no shipped preset enables it, configs.py use_warp_reg_loss=False)')
+  if use_elastic_loss and elastic_loss_type != 'log_svals':
+    raise L.NrfError("only elastic_loss_type='log_svals' (the default, training.py:71) is built")
   # random.split(rng_key, 4) (training.py:168): derive the per-step stream keys from an int key
   rng_key = int(rng_key)
   mix = lambda k, i: (k * 6364136223846793005 + 1442695040888963407 + i) & 0xFFFFFFFFFFFFFFFF
@@ -109,7 +110,9 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
     noise = scalar_params.background_noise_std * torch.randn(pts.shape, generator=g, device=pts.device)
     background = {'points': pts + noise, 'warp_ids': ids, 'weight': scalar_params.background_loss_weight}
   grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
-                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad, background=background)
+                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad, background=background,
+                                    elastic={'weight': scalar_params.elastic_loss_weight, 'reduce_method': elastic_reduce_method}
+                                    if use_elastic_loss else None)
   grad, stats, n = psum_gradients(grad, stats)
   opt.apply_gradient(grad, learning_rate=scalar_params.learning_rate, grad_scale=1.0 / n)
   out = {
@@ -118,4 +121,8 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
   }
   if use_background_loss:
     out['background_loss'] = stats[5]
+  if use_elastic_loss:   # coarse level only (training.py:246)
+    out['coarse']['loss/elastic'] = stats[6]
+    out['coarse']['residual/elastic'] = stats[7]
+    out['coarse']['loss/total'] = stats[0] + scalar_params.elastic_loss_weight * stats[6]
   return state, out, next_key

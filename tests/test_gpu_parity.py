@@ -489,3 +489,59 @@ def test_graphed_chunk_renderer_matches_direct_apply():
       assert a[k].shape == (hh, ww) + ((3,) if k == 'rgb' else ())
       np.testing.assert_array_equal(a[k].cpu().numpy(), b[k].cpu().numpy())
     fp.flat.mul_(1.01)   # "training" moved the weights in place: the replay must see the new values
+
+
+# ---------------------------------------------------------------------------------------------
+# elastic regulariser (training.py:71-114, 177-197): forward-mode warp Jacobian + log-singular-value loss
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw,alpha,weight,method', [(dict(num_nerf_point_freqs=2), 3.5, 0.01, 'weight'),
+                                                     (dict(num_nerf_point_freqs=3, num_warp_freqs=6), 6.0, 0.001, 'weight'),
+                                                     (dict(num_nerf_point_freqs=2, num_coarse_samples=48), 8.0, 0.01, 'median')])
+def test_elastic_loss_and_grad_parity(kw, alpha, weight, method):
+  from nerfies_amd import params as P
+  spec, model, fp, gb, p64, b64, _ = _make_warp(5, seed=11, **kw)
+  loss, ostats, ograds, _ = O.loss_and_grad(p64, spec, b64, warp_alpha=alpha, use_elastic_loss=True,
+                                            elastic_loss_weight=weight, elastic_reduce_method=method)
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha}, elastic={'weight': weight, 'reduce_method': method})
+  torch.cuda.synchronize()
+  oe, orr = ostats['coarse']['loss/elastic'].item(), ostats['coarse']['residual/elastic'].item()
+  assert abs(stats[6].item() - oe) < 1e-6 + 2e-4 * abs(oe), (stats[6].item(), oe)
+  assert abs(stats[7].item() - orr) < 1e-6 + 2e-4 * abs(orr), (stats[7].item(), orr)
+  assert abs(stats[4].item() - loss.item()) < 3e-5
+  f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+  p32 = O.tree_map(f32, p64)
+  b32 = {k: (O.tree_map(f32, v) if isinstance(v, dict) else f32(v)) for k, v in b64.items()}
+  _, _, ograds32, _ = O.loss_and_grad(p32, spec, b32, warp_alpha=alpha, use_elastic_loss=True, elastic_loss_weight=weight,
+                                      elastic_reduce_method=method)
+  got = P.tree_from_flat(grad.cpu(), model.layout)
+  for (path, og), (_, og32) in zip(O.tree_leaves_with_path(ograds), O.tree_leaves_with_path(ograds32)):
+    node = got
+    for k in path.split('/'):
+      node = node[k]
+    scale = max(og.abs().max().item(), 1e-7)
+    err = min((node.double() - og).abs().max().item(), (node.double() - og32.double()).abs().max().item()) / scale
+    assert err < 3e-3, (path, err, scale)
+
+
+def test_train_step_with_elastic_and_background_losses():
+  """gpu_vrig_paper-style step: SE3 warp + elastic ('weight') + background regularisers, camera code."""
+  from nerfies_amd import training
+  import helpers as H
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=4, use_warp=True, num_warp_freqs=6,
+                     use_camera_metadata=True, use_stratified_sampling=True)
+  oparams = O.init_params(spec, seed=4, trained_like=False, dtype=torch.float64)
+  for k in ('branches_w', 'branches_v'):
+    oparams['warp_field'][k]['logit']['kernel'] *= 8.0   # a visible, unsaturated deformation for the regularisers to shrink
+  model, fp = H.gpu_model(spec, oparams, 32)
+  gb = H.gpu_batch(O.synthetic_batch(32, seed=5, dtype=torch.float64))
+  gb['background_points'] = (torch.rand(300, 3, device=DEV) - 0.5) * 0.5
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=6.0)
+  sp = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=1.0, background_loss_weight=1.0)
+  key, el, bg = 0, [], []
+  for _ in range(30):
+    state, stats, key = training.train_step(model, key, state, gb, sp, use_elastic_loss=True, elastic_reduce_method='weight',
+                                            use_background_loss=True)
+    el.append(stats['coarse']['loss/elastic'].item()); bg.append(stats['background_loss'].item())
+  assert np.isfinite(el).all() and np.isfinite(bg).all()
+  assert 0 < el[0] < 0.04, el[0]   # below the robust loss's plateau (2 * 0.03)
+  assert el[-1] < el[0] and bg[-1] < bg[0], (el[0], el[-1], bg[0], bg[-1])

@@ -142,7 +142,7 @@ def side_mode(args, world, rank, dev):
     n = 768
     model, fp = models.construct_nerf(0, C, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
     state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=6.0)
-    sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0)
+    sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0, elastic_loss_weight=0.001)
     batch = synthetic_batch(n, 100 + rank, dev)
     g = torch.Generator().manual_seed(rank)
     batch['metadata'] = {'warp': torch.randint(0, 4, (n, 1), generator=g).to(dev), 'camera': torch.randint(0, 2, (n, 1), generator=g).to(dev)}
@@ -150,11 +150,12 @@ def side_mode(args, world, rank, dev):
     box = {'state': state, 'key': 1 + rank}
 
     def step():
-      box['state'], _, box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, use_background_loss=True)
+      box['state'], _, box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, use_elastic_loss=True,
+                                                        elastic_reduce_method='weight', use_background_loss=True)
     prof_step = step
-    per_step, name = n, 'train rays/sec (256 samples/ray, SE3 warp + background regulariser, no elastic term)'
-    workload = ('gpu_vrig_paper.gin shape: 768 rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, background points '
-                '16384/world, stratified; the elastic regulariser of that preset is NOT built yet')
+    per_step, name = n, 'train rays/sec (256 samples/ray, SE3 warp + elastic + background regularisers)'
+    workload = ('gpu_vrig_paper.gin shape: 768 rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, elastic loss '
+                "(reduce 'weight', w=0.001) on the coarse samples, background points 16384/world (w=1), stratified")
   for _ in range(args.warmup):
     step()
   barrier()
@@ -203,7 +204,7 @@ def main():
   ap.add_argument('--mode', default='train', choices=['train', 'eval', 'vrig'],
                   help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
                        '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
-                       'SE3 warp F_w=6 + camera code + background regulariser; elastic term not built yet)')
+                       'SE3 warp F_w=6 + camera code + elastic + background regularisers)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))

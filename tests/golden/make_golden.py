@@ -43,7 +43,23 @@ CASES = {
     'warp_vrig': (dict(num_coarse_samples=32, num_fine_samples=32, num_nerf_point_freqs=8,
                        use_stratified_sampling=True, use_warp=True, num_warp_freqs=6, num_warp_features=8,
                        num_warp_embeddings=4, use_camera_metadata=True, num_camera_embeddings=2), 5, 'uniforms', 6.0),
+    # every loss term of gpu_vrig_paper.gin: SE3 warp + elastic ('weight') + background regulariser, camera code.
+    # Low NeRF posenc frequencies keep the fp32/fp64 ReLU branches identical (see compute()).
+    'vrig_full': (dict(num_coarse_samples=32, num_fine_samples=32, num_nerf_point_freqs=2, use_stratified_sampling=True,
+                       use_warp=True, num_warp_freqs=6, num_warp_features=8, num_warp_embeddings=4,
+                       use_camera_metadata=True, num_camera_embeddings=2), 5, 'uniforms', 6.0),
 }
+# loss kwargs of the cases that train with regularisers
+LOSS_KW = {'vrig_full': dict(use_elastic_loss=True, elastic_loss_weight=0.01, elastic_reduce_method='weight',
+                             use_background_loss=True, background_loss_weight=1.0)}
+
+
+def background_inputs(name, spec):
+  seed = sum(ord(c) for c in name) + 7
+  rng = np.random.default_rng(seed)
+  n = 150
+  return {'points': torch.tensor(rng.uniform(-0.4, 0.4, size=(n, 3))), 'warp_ids': torch.tensor(rng.integers(0, spec.num_warp_embeddings, size=(n, 1))),
+          'noise': torch.tensor(1e-3 * rng.normal(size=(n, 3)))}
 
 
 def case_inputs(name):
@@ -68,8 +84,18 @@ def leaf_digest(t):
 
 def compute(name):
   spec, params, batch, t_rand, u, alpha = case_inputs(name)
-  total, stats, grads, ret = O.loss_and_grad(params, spec, batch, warp_alpha=alpha, t_rand=t_rand, u=u)
+  lkw = dict(LOSS_KW.get(name, {}))
+  if lkw.get('use_background_loss'):
+    lkw['background'] = background_inputs(name, spec)
+  total, stats, grads, ret = O.loss_and_grad(params, spec, batch, warp_alpha=alpha, t_rand=t_rand, u=u, **lkw)
   out = {'loss': np.array(total.item())}
+  if 'background' in lkw:
+    out['background_loss'] = np.array(stats['background_loss'].item())
+    for k, v in lkw['background'].items():
+      out['in/background/' + k] = v.numpy()
+  if lkw.get('use_elastic_loss'):
+    out['coarse/loss_elastic'] = np.array(stats['coarse']['loss/elastic'].item())
+    out['coarse/residual_elastic'] = np.array(stats['coarse']['residual/elastic'].item())
   for lv in ret:
     for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights', 'z_vals'):
       out[f'{lv}/{k}'] = ret[lv][k].detach().numpy()
@@ -84,8 +110,11 @@ def compute(name):
   f32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
   p32 = O.tree_map(f32, params)
   b32 = {k: (O.tree_map(f32, v) if isinstance(v, dict) else f32(v)) for k, v in batch.items()}
+  lkw32 = dict(lkw)
+  if 'background' in lkw32:
+    lkw32['background'] = {k: f32(v) for k, v in lkw32['background'].items()}
   _, _, grads32, _ = O.loss_and_grad(p32, spec, b32, warp_alpha=alpha, t_rand=f32(t_rand) if t_rand is not None else None,
-                                     u=f32(u) if u is not None else None)
+                                     u=f32(u) if u is not None else None, **lkw32)
   for path, g in O.tree_leaves_with_path(grads32):
     out['grad32/' + path] = leaf_digest(g.double())
   for k in ('origins', 'directions', 'rgb'):

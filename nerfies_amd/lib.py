@@ -90,6 +90,9 @@ def load_library(path=None):
   global _lib
   if _lib is not None and path is None:
     return _lib
+  # torch first: its wheel carries its own HIP runtime; loading ours before it would put two runtimes in one
+  # process (device pointers of one are "no ROCm-capable device" errors in the other)
+  import torch  # noqa: F401
   path = path or os.environ.get('NRF_LIB_PATH') or LIB_PATH   # NRF_LIB_PATH: experiment builds of the same ABI
   if not os.path.exists(path):
     raise NrfError(

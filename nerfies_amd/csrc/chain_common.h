@@ -141,23 +141,18 @@ __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* 
   }
 }
 
-// Two workgroups share a CU.  Started together they run in lockstep (same work per tile): their
-// epilogues coincide and the matrix pipe idles through both.  The phase difference between the
-// two is preserved from layer to layer (whoever is alone in its K loop runs at full MFMA rate), so a
-// one-off delay of the later-dispatched half of the grid keeps one workgroup's epilogue under
-// the other's K loop for the whole kernel.  Placement is not architecturally guaranteed
-// (blocks >= grid/2 normally take the second slot of each CU); a wrong guess only loses the gain.
-__device__ __forceinline__ void dephase_second_half(int cfg) {
-  const int sleeps = cfg & 0xff, mode = cfg >> 8;
-  const int b = blockIdx.x;
-  bool late;
-  if (mode == 0) late = b >= (gridDim.x + 1) / 2;
-  else if (mode == 1) late = b & 1;
-  else if (mode == 2) late = (b >> 3) & 1;
-  else if (mode == 3) late = (b >> 4) & 1;
-  else late = (b >> 5) & 1;
-  if (late)
-    for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);   // 127 x 64 clocks each
+// Tile hand-out.  counter == nullptr (default): static round-robin split.  Otherwise workgroups pull 64-row
+// tiles from a global counter (zeroed by the host before the launch; `slot` is one free LDS word at the tile
+// boundary).  Two workgroups share a CU and the older one wins the MFMA arbitration, so with the static split it
+// finishes early and leaves the younger one alone for the last ~20 % of the kernel; the dynamic hand-out removes
+// that tail but measured 4-6 % slower overall (nrf_api.hip tile_counter_or_null), so it is off by default.
+__device__ __forceinline__ int next_tile(int* __restrict__ counter, int* slot, int prev = -1) {
+  if (!counter) return prev < 0 ? (int)blockIdx.x : prev + (int)gridDim.x;   // static round-robin split
+  if (threadIdx.x == 0) *slot = atomicAdd(counter, 1);
+  __syncthreads();
+  const int t = *slot;
+  __syncthreads();
+  return t;
 }
 
 // acc = bias[n] broadcast down the rows: the bias add rides in the MFMA accumulator for free.

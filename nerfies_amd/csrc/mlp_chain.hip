@@ -53,7 +53,6 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
   const int PK = A.PK;
   const int PKS = (PK + 31) / 32 * 32;   // features per posenc stash tile (whole 32-feature blocks)
   const int nq_pe = PK / 16;
-  dephase_second_half(A.dephase);
   int stamp_i = 0;
   auto STAMP = [&]() {
     if (A.timeline && blockIdx.x == 0 && lane == 0 && stamp_i < 64) A.timeline[wave * 64 + stamp_i] = clock64();
@@ -62,7 +61,8 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
 
   unsigned long long wg_t0 = 0;
   if (A.timeline && tid == 0) wg_t0 = clock64();
-  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+  int* tslot = reinterpret_cast<int*>(pe);   // free between tiles
+  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
     STAMP();   // tile start
     // ---- prologue: sample point + SinusoidalEncoder (modules.py:213-228) ----
     {
@@ -277,10 +277,10 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
 
   const size_t layer_fl = (size_t)A.ntiles * FRAG_TILE_256;   // floats per trunk layer
   const int wv = wave * 2 * 8 * 1024;                           // bytes: this wave's slice of a tile
-  dephase_second_half(A.dephase);
 
+  int* tslot = reinterpret_cast<int*>(dr);   // free between tiles
 #pragma unroll 1
-  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
     if (tid < TILE_ROWS) {
       const float4 d = A.d_raw4[(size_t)tile * TILE_ROWS + tid];
       dr[tid] = d.x; dr[TILE_ROWS + tid] = d.y; dr[2 * TILE_ROWS + tid] = d.z; dr[3 * TILE_ROWS + tid] = d.w;

@@ -55,6 +55,7 @@ struct WsPlan {
   size_t bg_loss;       // [64] background-loss accumulator
   size_t el_sums;       // [64] elastic-loss / residual accumulators
   size_t el_coef;       // [B][N_c] one-hot sample selector of elastic_reduce_method 'median'
+  size_t counters;      // [64] ints: dynamic tile counters of the chain kernels, zeroed at the start of forward / backward
   size_t timeline;      // [2 levels][4 waves][64] uint64 debug stamps of workgroup 0 of the forward chain kernel
   size_t seg_clock;     // [nsegs] uint64 wall-clock ticks per wgrad segment (cost-model calibration)
   int nreduce_pass[4] = {0, 0, 0, 0};   // reduce descriptors by pass: pass 0 overwrites, passes 1 (fine level) and 2
@@ -223,6 +224,15 @@ void build_pack_offsets(nrf_handle h) {
 }
 
 // Lays out the workspace for B rays and (re)builds the descriptor tables.
+// dynamic tile counters (ints at ws + plan.counters)
+enum { CT_WARP_FWD = 0, CT_MLP_FWD = 2, CT_TAN_FWD = 4, CT_MLP_BWD = 5, CT_WARP_BWD = 7, CT_TAN_BWD = 9, CT_BG_FWD = 10, CT_BG_BWD = 11 };
+// Measured (r01): pulling tiles from a global counter is 4-6 % SLOWER than the static round-robin split for the
+// chain kernels (fine forward 1.99 vs 1.87 ms) although it removes the tail where the younger workgroup of a CU
+// runs alone -- so static is the default and NRF_DYNAMIC_TILES=1 keeps the other path testable.
+int* tile_counter_or_null(float* base, int idx) {
+  static const bool dynamic = getenv("NRF_DYNAMIC_TILES") != nullptr;
+  return dynamic ? reinterpret_cast<int*>(base) + idx : nullptr;
+}
 constexpr int BG = 2;   // level index of the background-point batch
 constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coarse tiles)
 
@@ -438,6 +448,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   }
   if (h->warp) p.warp_wpk = take(h->wpk.total);
   p.seg_clock = take(2 * (p.segs.size() + 1));
+  p.counters = take(64);
   p.timeline = take(2 * (2 * 4 * 64 + 1024 + 4 * 4096));
 
   // ---- pack descriptors (both levels, forward and transposed streams) ----
@@ -638,7 +649,7 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
   a.points = nullptr; a.out4 = reinterpret_cast<float4*>(ws + L.out4);
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
   a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation;
-  a.dephase = getenv("NRF_DEPHASE") ? atoi(getenv("NRF_DEPHASE")) : 3;
+  a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_FWD + lv);
   a.timeline = getenv("NRF_TIMELINE") ? reinterpret_cast<unsigned long long*>(ws + p.timeline) + lv * (256 + 512 + 4 * 2048) : nullptr;
   if (train) {
     a.st_pe = ws + L.st_pe; a.st_h = ws + L.st_h; a.st_bn = ws + L.st_bn; a.st_rgbh = ws + L.st_rgbh;
@@ -684,6 +695,7 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
   a.points_out = ws + L.wpoints; a.points_raw = ws + L.points_raw;
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
   a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = alpha;
+  a.tile_counter = tile_counter_or_null(ws + p.counters, CT_WARP_FWD + lv);
   if (train) {
     a.st_win = ws + L.w_st_win; a.st_h = ws + L.w_st_h; a.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
     a.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
@@ -709,6 +721,7 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
+  if (hipMemsetAsync(ws + p.counters, 0, 64 * sizeof(int), stream) != hipSuccess) return fail(NRF_E_HIP, "zero tile counters");
 
   Prof& pf = h->prof;
   pf.begin("pack_prep_sample", 0, stream);
@@ -746,6 +759,7 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
         ta.ntiles = p.ntiles[TG]; ta.rows = p.rows[TG];
         ta.st_win = ws + T.w_st_win; ta.st_h = ws + T.w_st_h; ta.st_wv = reinterpret_cast<float4*>(ws + T.w_st_wv);
         ta.bits = nullptr; ta.points_out = ws + T.wpoints; ta.points_raw = nullptr;
+        ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_FWD);
         const int tgrid = p.ntiles[TG] < gmul * h->num_cus ? p.ntiles[TG] : gmul * h->num_cus;
         pf.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[0], stream);
         launch_warp_fwd(ta, true, tgrid, stream);
@@ -795,6 +809,8 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
   if (e != hipSuccess) return fail_hip(e, "zero grad");
   e = hipMemsetAsync(ws + p.mse, 0, 64 * sizeof(float), stream);
   if (e != hipSuccess) return fail_hip(e, "zero mse");
+  e = hipMemsetAsync(reinterpret_cast<int*>(ws + p.counters) + CT_MLP_BWD, 0, (64 - CT_MLP_BWD) * sizeof(int), stream);
+  if (e != hipSuccess) return fail_hip(e, "zero tile counters");
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
     e = hipMemsetAsync(ws + L.dray, 0, (size_t)B * RGB_W * sizeof(float), stream);
@@ -817,7 +833,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     a.small_part = ws + L.small_part;
     if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
     a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
-    a.dephase = getenv("NRF_DEPHASE") ? atoi(getenv("NRF_DEPHASE")) : 3;
+    a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_BWD + lv);
     const int grid = p.ntiles[lv] < 2 * h->num_cus ? p.ntiles[lv] : 2 * h->num_cus;   // two workgroups per CU
     h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
     launch_chain_bwd(a, grid, stream);
@@ -849,6 +865,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
       memset(&wa, 0, sizeof(wa));
       wa.params = params; wa.po = h->wpo; wa.wpk = ws + p.warp_wpk; wa.pk = h->wpk;
       wa.nt_prim = p.ntiles[lv];
+      wa.tile_counter = tile_counter_or_null(ws + p.counters, CT_WARP_BWD + lv);
       if (el_on) { wa.extra_dw4 = reinterpret_cast<const float4*>(ws + L.el_dw4); wa.extra_dv4 = reinterpret_cast<const float4*>(ws + L.el_dv4); }
       wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
       wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
@@ -869,6 +886,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
         ta.d_points = nullptr; ta.st_win = nullptr; ta.st_wv = nullptr;
         ta.dy = ws + T.w_dy; ta.d_w4 = reinterpret_cast<float4*>(ws + T.w_dw4); ta.d_v4 = reinterpret_cast<float4*>(ws + T.w_dv4);
         ta.small_part = nullptr;
+        ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_BWD);
         const int tgrid = p.ntiles[TG] < 2 * h->num_cus ? p.ntiles[TG] : 2 * h->num_cus;
         h->prof.begin("warp_tangent_dgrad", 3.0 * warp_dgrad_flops_row(h) * p.rows[0], stream);
         launch_warp_bwd(ta, tgrid, stream);
@@ -896,6 +914,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = scalars->warp_alpha;
     fa.st_win = ws + L.w_st_win; fa.st_h = ws + L.w_st_h; fa.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
     fa.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
+    fa.tile_counter = tile_counter_or_null(ws + p.counters, CT_BG_FWD);
     h->prof.begin("warp_fwd_bg", warp_fwd_flops_row(h) * p.bgN, stream);
     launch_warp_fwd(fa, true, grid, stream);
     h->prof.end(stream);
@@ -911,6 +930,7 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
     wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
     wa.point_ids = bg->warp_ids;
     wa.nt_prim = p.ntiles[BG];
+    wa.tile_counter = tile_counter_or_null(ws + p.counters, CT_BG_BWD);
     wa.S = 1; wa.B = p.bgN; wa.rows = p.bgN; wa.ntiles = p.ntiles[BG];
     wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
     wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
@@ -1093,7 +1113,7 @@ int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32
 // field training.compute_background_loss applies, training.py:127-130).  Mini workspace:
 // [pack descriptors | packed trunk weights | padded output].
 namespace {
-struct WarpPointsPlan { size_t desc_f, wpk_f, out_f, total_f; int ntiles; };
+struct WarpPointsPlan { size_t desc_f, wpk_f, out_f, ctr_f, total_f; int ntiles; };
 WarpPointsPlan warp_points_plan(nrf_handle h, int n) {
   WarpPointsPlan q;
   q.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
@@ -1102,6 +1122,7 @@ WarpPointsPlan warp_points_plan(nrf_handle h, int n) {
   q.desc_f = take(16 * sizeof(PackDesc) / 4);
   q.wpk_f = take(h->wpk.total);
   q.out_f = take((size_t)q.ntiles * TILE_ROWS * 3);
+  q.ctr_f = take(16);
   q.total_f = o;
   return q;
 }
@@ -1150,6 +1171,9 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   a.S = 1; a.B = num_points; a.rows = num_points; a.ntiles = q.ntiles;
   a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha;
   const int grid = q.ntiles < 2 * h->num_cus ? q.ntiles : 2 * h->num_cus;
+  e = hipMemsetAsync(ws + q.ctr_f, 0, 16 * sizeof(int), st);
+  if (e != hipSuccess) return fail_hip(e, "zero tile counter");
+  a.tile_counter = tile_counter_or_null(ws + q.ctr_f, 0);
   launch_warp_fwd(a, false, grid, st);
   e = hipMemcpyAsync(warped, ws + q.out_f, (size_t)num_points * 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return fail_hip(e, "copy warped points");

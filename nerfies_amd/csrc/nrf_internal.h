@@ -75,7 +75,7 @@ struct ChainFwdArgs {
   int S, B, rows, ntiles;
   int F, P, PK;              // point freqs, 3+6F, P rounded up to a multiple of 16
   int sigma_act;
-  int dephase;               // s_sleep(127) count for the second half of the grid (chain_common.h)
+  int* tile_counter;         // zeroed before the launch: dynamic tile hand-out (chain_common.h next_tile)
   unsigned long long* timeline;   // debug: [4 waves][64] shader-clock stamps of workgroup 0 (or nullptr)
   // activation stash (training only)
   float* st_pe;              // [ntiles][PK][128]
@@ -105,7 +105,7 @@ struct ChainBwdArgs {
   float* d_points;           // [ntiles*128][3] or nullptr
   const float* st_pe;        // posenc stash of the forward pass
   int F, P, PK;
-  int dephase;
+  int* tile_counter;
 };
 
 // SE3Field forward (warping.py:322-353): x = o + z d (or explicit points) -> warped points.
@@ -133,6 +133,7 @@ struct WarpFwdArgs {
   int nt_prim;
   const float* prim_win;
   const uint32_t* prim_bits;
+  int* tile_counter;         // zeroed before the launch
 };
 
 struct WarpBwdArgs {
@@ -155,6 +156,7 @@ struct WarpBwdArgs {
   float* small_part;         // [gridDim.x][WARP_SMALL_PART]
   const float4* extra_dw4;   // primal pass: + dL/d(w, v) of the elastic regulariser, or nullptr
   const float4* extra_dv4;
+  int* tile_counter;         // zeroed before the launch
   int tangent;               // reverse of the tangent pass: d_w4 / d_v4 are INPUTS, masks of primal tile tt % nt_prim
   int nt_prim;               // tiles of the primal level (== ntiles for the primal pass)
 };

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
   const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
   const size_t st_layer = (size_t)A.ntiles * FRAG_TILE_128;
 
-  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+  int* tslot = reinterpret_cast<int*>(win);   // free between tiles
+  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
     // ---- prologue: sample point, AnnealedSinusoidalEncoder (modules.py:231-294), GLO code ----
     float x[3] = {0.f, 0.f, 0.f};
     const int row = tile * TILE_ROWS + p;
@@ -323,8 +324,9 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
   for (int l = 0; l < WARP_DEPTH; ++l) db[l] = 0.f;
   float hsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // threads < 64: column sums of (dw, dv)
 
+  int* tslot = reinterpret_cast<int*>(dwv);   // free between tiles
 #pragma unroll 1
-  for (int tile = blockIdx.x; tile < A.ntiles; tile += gridDim.x) {
+  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
     const int tprim = TANGENT ? tile % A.nt_prim : tile;
     // ---- exp_se3 VJP per row ----
     if (TANGENT) {

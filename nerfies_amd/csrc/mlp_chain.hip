@@ -138,10 +138,25 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     // ---- alpha head: Dense(256->1) on the trunk output (modules.py:152-157) ----
     float sigma_raw = 0.f;
     {
-      const float* __restrict__ wa = prm + A.po.alpha_k;
+      // weights in chunks of 16 (wave-uniform -> one s_load_dwordx16 per chunk instead of a scalar load and a
+      // wait per k), activations as 16 independent LDS reads
+      const float4* __restrict__ wa4 = reinterpret_cast<const float4*>(prm + A.po.alpha_k) + part * 16;
       float s = 0.f;
       const int k0 = part * 64;
-      for (int k = k0; k < k0 + 64; ++k) s = fmaf(act[act_elem(k, p)], wa[k], s);
+#pragma unroll 1
+      for (int kc = 0; kc < 4; ++kc) {
+        float4 w4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w4[i] = wa4[4 * kc + i];
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = act[act_elem(k0 + 16 * kc + i, p)];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          s = fmaf(a[4 * i], w4[i].x, s); s = fmaf(a[4 * i + 1], w4[i].y, s);
+          s = fmaf(a[4 * i + 2], w4[i].z, s); s = fmaf(a[4 * i + 3], w4[i].w, s);
+        }
+      }
       pe[part * TILE_ROWS + p] = s;   // scratch (posenc no longer needed for this tile)
       __syncthreads();
       if (part == 0)
@@ -165,15 +180,16 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     {
       f32x16 acc1[2][1];
       zero_acc<1>(acc1);
-      mfma_k_loop<1, true>(acc1, act, 16, wrgb, lane, wrgb0);
       const int n = wave * 32 + j;
-      const __amdgpu_buffer_rsrc_t st = make_rsrc(STASH ? A.st_rgbh + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4);
-      __syncthreads();
-      uint32_t mb = 0u;
-      // rows visited by this lane increase with q: walk the ray boundaries instead of dividing
+      // rows visited by this lane increase with q: walk the ray boundaries instead of dividing.  The first
+      // condition term is fetched before the K loop so that its latency hides under the MFMAs.
       int ray = (tile * TILE_ROWS) / A.S;
       int nextb = (ray + 1) * A.S - tile * TILE_ROWS;   // first tile row of the next ray
       float ct = A.condterm[(size_t)min(ray, A.B - 1) * RGB_W + n];
+      mfma_k_loop<1, true>(acc1, act, 16, wrgb, lane, wrgb0);
+      const __amdgpu_buffer_rsrc_t st = make_rsrc(STASH ? A.st_rgbh + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4);
+      __syncthreads();
+      uint32_t mb = 0u;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int g = q_granule(q, h);
@@ -199,13 +215,25 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     STAMP();   // rgb hidden done
     // ---- rgb logits Dense(128->3), sigmoid; sigma activation (models.py:276-277) ----
     {
-      const float* __restrict__ wl = prm + A.po.logit_k;   // [128][3]
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+      // [128][3] row-major: this part's 32 k = 96 consecutive floats, read as 6 chunks of 16
+      const float4* __restrict__ wl4 = reinterpret_cast<const float4*>(prm + A.po.logit_k) + part * 24;
+      float sc[3] = {0.f, 0.f, 0.f};
       const int k0 = part * 32;
-      for (int k = k0; k < k0 + 32; ++k) {
-        const float a = act[act_elem(k, p)];
-        s0 = fmaf(a, wl[3 * k], s0); s1 = fmaf(a, wl[3 * k + 1], s1); s2 = fmaf(a, wl[3 * k + 2], s2);
+#pragma unroll 1
+      for (int kc = 0; kc < 2; ++kc) {   // 16 k = 48 weights per trip
+        float4 w4[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) w4[i] = wl4[12 * kc + i];
+        const float* wf = reinterpret_cast<const float*>(w4);
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = act[act_elem(k0 + 16 * kc + i, p)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          sc[0] = fmaf(a[i], wf[3 * i], sc[0]); sc[1] = fmaf(a[i], wf[3 * i + 1], sc[1]); sc[2] = fmaf(a[i], wf[3 * i + 2], sc[2]);
+        }
       }
+      const float s0 = sc[0], s1 = sc[1], s2 = sc[2];
       pe[(3 * part) * TILE_ROWS + p] = s0; pe[(3 * part + 1) * TILE_ROWS + p] = s1; pe[(3 * part + 2) * TILE_ROWS + p] = s2;
       __syncthreads();
       if (part == 0) {

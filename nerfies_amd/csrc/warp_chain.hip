@@ -249,14 +249,26 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
 
     // ---- heads: w = Dense(128->3)(h), v = Dense(128->3)(h)  (warping.py:271-288, 328-329) ----
     {
-      const float* __restrict__ ww = prm + A.po.w_k;   // [128][3]
-      const float* __restrict__ wv = prm + A.po.v_k;
+      // [128][3] each: this part's 32 k = 96 consecutive floats per head, in chunks of 16 k (wave-uniform loads)
+      const float4* __restrict__ ww4 = reinterpret_cast<const float4*>(prm + A.po.w_k) + part * 24;
+      const float4* __restrict__ wv4 = reinterpret_cast<const float4*>(prm + A.po.v_k) + part * 24;
       float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const int k0 = part * 32;
-      for (int k = k0; k < k0 + 32; ++k) {
-        const float a = act[act_elem(k, p)];
+#pragma unroll 1
+      for (int kc = 0; kc < 2; ++kc) {
+        float4 a4[12], b4[12];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { s[c] = fmaf(a, ww[3 * k + c], s[c]); s[3 + c] = fmaf(a, wv[3 * k + c], s[3 + c]); }
+        for (int i = 0; i < 12; ++i) { a4[i] = ww4[12 * kc + i]; b4[i] = wv4[12 * kc + i]; }
+        const float* wf = reinterpret_cast<const float*>(a4);
+        const float* vf = reinterpret_cast<const float*>(b4);
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = act[act_elem(k0 + 16 * kc + i, p)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) { s[c] = fmaf(a[i], wf[3 * i + c], s[c]); s[3 + c] = fmaf(a[i], vf[3 * i + c], s[3 + c]); }
+        }
       }
 #pragma unroll
       for (int c = 0; c < 6; ++c) win[(6 * part + c) * TILE_ROWS + p] = s[c];
@@ -391,12 +403,25 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
     float dcode[2] = {0.f, 0.f};
     auto code_grad = [&](int64_t krow_off) {
       const int g0 = 2 * part;
-      for (int k = 0; k < WARP_W; ++k) {
-        const float a = act[act_elem(k, p)];
+      // the two weight rows of this thread's codes, 16 k at a time (wave-uniform loads, no per-k scalar waits)
+      const float4* __restrict__ r0 = reinterpret_cast<const float4*>(prm + krow_off + (int64_t)min(g0, A.G - 1) * WARP_W);
+      const float4* __restrict__ r1 = reinterpret_cast<const float4*>(prm + krow_off + (int64_t)min(g0 + 1, A.G - 1) * WARP_W);
+      float d0 = 0.f, d1 = 0.f;
+#pragma unroll 1
+      for (int kc = 0; kc < WARP_W / 16; ++kc) {
+        float4 w0[4], w1[4];
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          if (g0 + q < A.G) dcode[q] = fmaf(a, prm[krow_off + (int64_t)(g0 + q) * WARP_W + k], dcode[q]);
+        for (int i = 0; i < 4; ++i) { w0[i] = r0[4 * kc + i]; w1[i] = r1[4 * kc + i]; }
+        const float* f0 = reinterpret_cast<const float*>(w0);
+        const float* f1 = reinterpret_cast<const float*>(w1);
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a[i] = act[act_elem(16 * kc + i, p)];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { d0 = fmaf(a[i], f0[i], d0); d1 = fmaf(a[i], f1[i], d1); }
       }
+      if (g0 < A.G) dcode[0] += d0;
+      if (g0 + 1 < A.G) dcode[1] += d1;
     };
 
     // ---- l = 5..1: d h_l = dpre_l . W_l[0:128]^T ; mask h_l > 0 -> dpre_{l-1} ----

@@ -1,11 +1,17 @@
 """CPU oracle for the nerfies hot path.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED: the reference (google/nerfies, JAX/Flax) ships no tests,
-golden vectors or fixtures for this path, and JAX/Flax are not installable in
-the build container, so this restatement cannot be pinned against reference
-outputs.  It is pinned instead against independent known-answer checks
-(tests/test_oracle_known_answers.py: scipy expm, searchsorted, sequential fp64
-loops, finite differences).
+PARITY PINNED against the reference's own sources: JAX/Flax are not installable in
+the build container, so the reference cannot run natively, but its modules
+(rigid_body, model_utils, modules, warping, models, training, utils) are imported
+UNMODIFIED from /root/reference and executed on NumPy float64 through import-name
+stand-ins (oracle/_shim: jax.numpy -> numpy, a minimal eager flax.linen,
+jax.random -> supplied arrays, jax.jacfwd -> central differences).  Their outputs
+are committed as tests/golden/ref_*.npz (tests/golden/make_reference_vectors.py)
+and this restatement reproduces them to 1e-8..1e-12, including NerfModel.apply end
+to end with the warp field (tests/test_reference_vectors.py).  Not covered by that
+route: reverse-mode gradients (no autodiff in the shim) -- those are torch.autograd
+on the pinned forward, checked by finite differences
+(tests/test_oracle_known_answers.py) -- and XLA's float32 evaluation order.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this module.  The product path (nerfies_amd/) never does.

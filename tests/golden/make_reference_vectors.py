@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Golden vectors from the REAL reference sources (google/nerfies at /root/reference), executed on NumPy
+float64 through the import-name stand-ins of oracle/_shim (jax.numpy -> numpy, a minimal eager flax.linen,
+jax.random -> caller-supplied arrays, jax.jacfwd -> central differences; see oracle/_shim/README.md).
+
+Runs only where /root/reference exists (the build container); writes tests/golden/ref_*.npz, which
+tests/test_reference_vectors.py replays against oracle/nerfies_oracle.py on any machine.  No reference
+source is copied: the modules are imported from /root/reference as they lie.
+
+  python tests/golden/make_reference_vectors.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path[:0] = [os.path.join(ROOT, 'oracle', '_shim'), REF, ROOT]
+
+import torch  # noqa: E402
+
+from jax import random as jrandom  # noqa: E402  (the shim)
+from nerfies import camera as ref_camera  # noqa: E402
+from nerfies import model_utils as ref_mu  # noqa: E402
+from nerfies import models as ref_models  # noqa: E402
+from nerfies import modules as ref_modules  # noqa: E402
+from nerfies import rigid_body as ref_rigid  # noqa: E402
+from nerfies import schedules as ref_sched  # noqa: E402
+from nerfies import training as ref_training  # noqa: E402
+from nerfies import utils as ref_utils  # noqa: E402
+from nerfies import warping as ref_warping  # noqa: E402
+from flax import linen as nn  # noqa: E402  (the shim)
+
+from oracle import nerfies_oracle as O  # noqa: E402  (only for parameter trees and synthetic batches)
+
+
+# jnp arrays are immutable: `weights += eps` (model_utils.py:156) REBINDS the local name under JAX, whereas NumPy
+# would add eps into the caller's array (the coarse weights the model returns).  The only in-place statement on the
+# path is given JAX semantics by handing that function a private copy; the reference source itself is untouched.
+_pdf = ref_mu.piecewise_constant_pdf
+ref_mu.piecewise_constant_pdf = lambda key, bins, weights, *a, **k: _pdf(key, bins, np.array(weights, copy=True), *a, **k)
+
+
+def tree_np(t):
+  return {k: tree_np(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t.detach().numpy() if torch.is_tensor(t) else t)
+
+
+def save(name, **arrays):
+  path = os.path.join(HERE, f'ref_{name}.npz')
+  np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+  print(f'ref_{name}.npz: {len(arrays)} arrays, {os.path.getsize(path)} bytes')
+
+
+def rigid_body():
+  rng = np.random.default_rng(1)
+  S, th, T = [], [], []
+  for _ in range(16):
+    w = rng.normal(size=3); w /= np.linalg.norm(w)
+    v = rng.normal(size=3)
+    theta = rng.uniform(1e-3, 2.5)
+    S.append(np.concatenate([w, v])); th.append(theta)
+    T.append(ref_rigid.exp_se3(S[-1], theta))
+  w = rng.normal(size=3)
+  save('rigid_body', screw=np.stack(S), theta=np.array(th), exp_se3=np.stack(T), skew_in=w, skew=ref_rigid.skew(w),
+       exp_so3=ref_rigid.exp_so3(S[0][:3], th[0]))
+
+
+def model_utils():
+  rng = np.random.default_rng(2)
+  B, Nc, Nf = 5, 12, 9
+  o = rng.uniform(-0.5, 0.5, (B, 3)); d = rng.normal(size=(B, 3)); d /= np.linalg.norm(d, axis=-1, keepdims=True)
+  t_rand = rng.uniform(0, 1, (B, Nc)); u = rng.uniform(0, 1, (B, Nf))
+  out = dict(origins=o, directions=d, t_rand=t_rand, u=u, near=0.1, far=1.7)
+  for strat in (0, 1):
+    for lind in (0, 1):
+      z, pts = ref_mu.sample_along_rays(jrandom.Key(uniform=t_rand), o, d, Nc, 0.1, 1.7, bool(strat), bool(lind))
+      out[f'sample_z_s{strat}_l{lind}'] = z; out[f'sample_pts_s{strat}_l{lind}'] = pts
+  z = out['sample_z_s1_l0']
+  rgb = rng.uniform(0, 1, (B, Nc, 3)); sigma = rng.uniform(0, 30, (B, Nc))
+  out.update(vr_rgb=rgb, vr_sigma=sigma, vr_z=z)
+  for white in (0, 1):
+    for inf in (0, 1):
+      r = ref_mu.volumetric_rendering(rgb, sigma, z, d, use_white_background=bool(white), sample_at_infinity=bool(inf),
+                                      return_weights=True)
+      for k, v in r.items():
+        out[f'vr_w{white}_i{inf}_{k}'] = v
+  w = ref_mu.volumetric_rendering(rgb, sigma, z, d, use_white_background=False, return_weights=True)['weights']
+  out['depth_index'] = ref_mu.compute_depth_index(w); out['depth_map'] = ref_mu.compute_depth_map(w, z)
+  out['opaqueness_mask'] = ref_mu.compute_opaqueness_mask(w)
+  z_mid = .5 * (z[..., 1:] + z[..., :-1])
+  for strat in (0, 1):
+    zs = ref_mu.piecewise_constant_pdf(jrandom.Key(uniform=u), z_mid, w[..., 1:-1], Nf, bool(strat))
+    zf, pf = ref_mu.sample_pdf(jrandom.Key(uniform=u), z_mid, w[..., 1:-1], o, d, z, Nf, bool(strat))
+    out[f'pdf_z_s{strat}'] = zs; out[f'sample_pdf_z_s{strat}'] = zf; out[f'sample_pdf_pts_s{strat}'] = pf
+  out['pdf_weights'] = w
+  save('model_utils', **out)
+
+
+def encoders_and_mlps():
+  rng = np.random.default_rng(3)
+  x = rng.uniform(-1, 1, (6, 3))
+  out = dict(x=x)
+  for F in (0, 4, 8):
+    enc = ref_modules.SinusoidalEncoder(num_freqs=F)
+    out[f'posenc_F{F}'] = np.stack([enc.apply({'params': {}}, xi) for xi in x])
+  for alpha in (0.0, 2.5, 8.0):
+    enc = ref_modules.AnnealedSinusoidalEncoder(num_freqs=8)
+    out[f'annealed_a{alpha}'] = np.stack([enc.apply({'params': {}}, xi, alpha) for xi in x])
+  out['window_a3.25'] = ref_modules.AnnealedSinusoidalEncoder.cosine_easing_window(0, 7, 8, 3.25)
+  # NerfMLP with viewdir + camera condition (R = 27 + 2), skip at 4
+  spec = O.ModelSpec(use_camera_metadata=True)
+  p = tree_np(O.init_params(spec, seed=4, trained_like=True))['nerf_mlps_coarse']
+  B, S = 3, 5
+  pe = rng.normal(size=(B, S, spec.point_feat)); cond = rng.normal(size=(B, spec.rgb_cond_width))
+  mlp = ref_modules.NerfMLP(trunk_depth=8, trunk_width=256, rgb_branch_depth=1, rgb_branch_width=128, skips=(4,))
+  r = mlp.apply({'params': p}, pe, None, None, cond)
+  out.update(mlp_in=pe, mlp_cond=cond, mlp_rgb=r['rgb'], mlp_alpha=r['alpha'])
+  save('modules', **out)
+
+
+def se3_field():
+  rng = np.random.default_rng(5)
+  spec = O.ModelSpec(use_warp=True, num_warp_freqs=6, num_warp_features=8, num_warp_embeddings=4)
+  wp = tree_np(O.init_params(spec, seed=6, trained_like=True))['warp_field']
+  field = ref_warping.SE3Field(num_freqs=6, num_embeddings=4, num_embedding_features=8)
+  pts = rng.uniform(-0.5, 0.5, (7, 3)); ids = rng.integers(0, 4, (7, 1))
+  outs = [field.apply({'params': wp}, pts[i], ids[i], {'alpha': 4.5, 'time_alpha': 0.0}, True, False) for i in range(7)]
+  out = dict(points=pts, ids=ids, alpha=4.5, warped=np.stack([o['warped_points'] for o in outs]),
+             jacobian_fd=np.stack([o['jacobian'] for o in outs]))
+  save('se3_field', **out)
+
+
+NERF_CASES = {
+    'nowarp': (dict(num_coarse_samples=10, num_fine_samples=7, num_nerf_point_freqs=6, use_stratified_sampling=True), 0.0),
+    'camera': (dict(num_coarse_samples=8, num_fine_samples=8, num_nerf_point_freqs=4, use_stratified_sampling=False,
+                    use_camera_metadata=True), 0.0),
+    'warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                  num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True), 3.25),
+}
+
+
+def build_ref_model(spec):
+  return ref_models.NerfModel(
+      num_coarse_samples=spec.num_coarse_samples, num_fine_samples=spec.num_fine_samples, use_viewdirs=spec.use_viewdirs,
+      near=spec.near, far=spec.far, noise_std=None, nerf_trunk_depth=8, nerf_trunk_width=256, nerf_rgb_branch_depth=1,
+      nerf_rgb_branch_width=128, nerf_skips=(4,), alpha_channels=1, rgb_channels=3,
+      use_stratified_sampling=spec.use_stratified_sampling, num_nerf_point_freqs=spec.num_nerf_point_freqs,
+      num_nerf_viewdir_freqs=spec.num_nerf_viewdir_freqs, appearance_ids=tuple(range(spec.num_appearance_embeddings)),
+      camera_ids=tuple(range(spec.num_camera_embeddings)), warp_ids=tuple(range(spec.num_warp_embeddings)),
+      num_appearance_features=spec.num_appearance_features, num_camera_features=spec.num_camera_features,
+      num_warp_features=spec.num_warp_features, num_warp_freqs=spec.num_warp_freqs, sigma_activation=nn.softplus,
+      use_camera_metadata=spec.use_camera_metadata, use_warp=spec.use_warp, warp_field_type='se3')
+
+
+def nerf_model():
+  for name, (kw, alpha) in NERF_CASES.items():
+    spec = O.ModelSpec(**kw)
+    seed = sum(ord(c) for c in name)
+    params = O.init_params(spec, seed=seed, trained_like=True)
+    batch = O.synthetic_batch(3, seed=seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    t_rand = rng.uniform(0, 1, (3, spec.num_coarse_samples)); u = rng.uniform(0, 1, (3, spec.num_fine_samples))
+    model = build_ref_model(spec)
+    rays = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(),
+            'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}}
+    ret = model.apply({'params': tree_np(params)}, rays, {'alpha': alpha, 'time_alpha': 0.0}, return_points=spec.use_warp,
+                      return_weights=True, return_warp_jacobian=spec.use_warp,
+                      rngs={'coarse': jrandom.Key(uniform=t_rand), 'fine': jrandom.Key(uniform=u)})
+    out = dict(t_rand=t_rand, u=u, alpha=alpha, seed=seed)
+    for lv, d in ret.items():
+      for k, v in d.items():
+        out[f'{lv}/{k}'] = v
+    if spec.use_warp:   # the elastic term of training.py on the coarse Jacobians (finite-difference Jacobians: ~1e-7)
+      el, res = zip(*[ref_training.compute_elastic_loss(j) for j in ret['coarse']['warp_jacobian'].reshape(-1, 3, 3)])
+      out['coarse/elastic_loss'] = np.array(el).reshape(3, -1); out['coarse/elastic_residual'] = np.array(res).reshape(3, -1)
+    save('nerf_' + name, **out)
+
+
+def losses_and_schedules():
+  sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
+  out = dict(sq=sq, gl_m2_c03=ref_utils.general_loss_with_squared_residual(sq, alpha=-2.0, scale=0.03),
+             gl_m2_c001=ref_utils.general_loss_with_squared_residual(sq, alpha=-2.0, scale=0.001),
+             gl_1_c1=ref_utils.general_loss_with_squared_residual(sq, alpha=1.0, scale=1.0),
+             psnr=ref_utils.compute_psnr(np.array([0.5, 0.01, 1e-4])))
+  rng = np.random.default_rng(9)
+  J = np.eye(3) + 0.2 * rng.normal(size=(5, 3, 3))
+  el = [ref_training.compute_elastic_loss(j) for j in J]
+  out.update(el_J=J, el_loss=np.array([e[0] for e in el]), el_residual=np.array([e[1] for e in el]))
+  steps = np.array([0, 1, 10, 499, 500, 501, 2500, 10000, 80000, 250000])
+  defs = {
+      'constant': ('constant', 0.3),
+      'linear': ('linear', 0.0, 8.0, 80000),
+      'exponential': ('exponential', 1e-3, 1e-4, 250000),
+      'cosine_easing': ('cosine_easing', 0.01, 1e-8, 5000),
+      'piecewise': ('piecewise', [(500, ('constant', 0.01)), (2000, ('cosine_easing', 0.01, 1e-5, 2000)), (1, ('constant', 1e-5))]),
+      'delayed': ('delayed', ('exponential', 1e-3, 1e-4, 250000), 2500, 0.01),
+  }
+  for k, dfn in defs.items():
+    sch = ref_sched.from_tuple(dfn)
+    out['sched_' + k] = np.array([float(sch(int(s))) for s in steps])
+  out['sched_steps'] = steps
+  save('losses_schedules', **out)
+
+
+def cameras():
+  rng = np.random.default_rng(11)
+  out = {}
+  for tag, dist in (('pinhole', None), ('distorted', ([0.05, -0.02, 0.004], [0.001, -0.002]))):
+    q = rng.normal(size=(3, 3)); R, _ = np.linalg.qr(q)
+    cam = ref_camera.Camera(orientation=R, position=rng.normal(size=3), focal_length=412.5, principal_point=[160.2, 119.7],
+                            image_size=[320, 240], skew=0.3, pixel_aspect_ratio=1.02,
+                            radial_distortion=None if dist is None else dist[0],
+                            tangential_distortion=None if dist is None else dist[1], dtype=np.float64)
+    px = rng.uniform(0, [320, 240], size=(40, 2))
+    rays = cam.pixels_to_rays(px)
+    pts = cam.position + rays * rng.uniform(0.5, 3.0, (40, 1))
+    out.update({f'{tag}/orientation': R, f'{tag}/position': cam.position, f'{tag}/pixels': px, f'{tag}/rays': rays,
+                f'{tag}/points': pts, f'{tag}/project': cam.project(pts),
+                f'{tag}/radial': cam.radial_distortion, f'{tag}/tangential': cam.tangential_distortion})
+    small = ref_camera.Camera(orientation=R, position=cam.position, focal_length=20.0, principal_point=[3.5, 2.5], image_size=[7, 5],
+                              radial_distortion=None if dist is None else dist[0],
+                              tangential_distortion=None if dist is None else dist[1], dtype=np.float64)
+    out[f'{tag}/centers_7x5'] = small.get_pixel_centers()
+    out[f'{tag}/centers_rays_7x5'] = small.pixels_to_rays(small.get_pixel_centers())
+  out['intrinsics'] = np.array([412.5, 160.2, 119.7, 0.3, 1.02])
+  save('camera', **out)
+
+
+if __name__ == '__main__':
+  rigid_body()
+  model_utils()
+  encoders_and_mlps()
+  se3_field()
+  nerf_model()
+  losses_and_schedules()
+  cameras()

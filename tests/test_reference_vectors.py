@@ -1,0 +1,136 @@
+"""The oracle against vectors produced by the REAL reference sources (tests/golden/ref_*.npz, written by
+tests/golden/make_reference_vectors.py, which imports google/nerfies from /root/reference and executes it on
+NumPy float64 through the import-name stand-ins of oracle/_shim).  This is what pins oracle/nerfies_oracle.py to
+the reference's own code for: rigid_body, model_utils (sampling, compositing, PDF, depth), the sinusoidal /
+annealed encoders, MLP / NerfMLP, SE3Field (+ its Jacobian by finite differences of the reference warp),
+NerfModel.apply end to end (coarse + fine, conditions, warp), the elastic loss, general_loss, psnr, schedules.
+Parameters are regenerated from the seeds (O.init_params is deterministic numpy)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nerfies_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def ref(name):
+  return dict(np.load(os.path.join(HERE, 'golden', f'ref_{name}.npz'), allow_pickle=False))
+
+
+T = lambda a: torch.tensor(np.asarray(a), dtype=torch.float64)
+
+
+def close(a, b, tol=1e-10, msg=''):
+  np.testing.assert_allclose(a.detach().numpy() if torch.is_tensor(a) else a, b, rtol=tol, atol=tol, err_msg=msg)
+
+
+def test_rigid_body():
+  r = ref('rigid_body')
+  close(O.exp_se3(T(r['screw']), T(r['theta'])), r['exp_se3'])
+  close(O.skew(T(r['skew_in'])), r['skew'])
+  close(O.exp_so3(T(r['screw'][0, :3]), T(r['theta'][0])), r['exp_so3'])
+
+
+def test_sample_along_rays():
+  r = ref('model_utils')
+  for s in (0, 1):
+    for l in (0, 1):
+      z, pts = O.sample_along_rays(T(r['origins']), T(r['directions']), 12, float(r['near']), float(r['far']), bool(s), bool(l),
+                                   T(r['t_rand']))
+      close(z, r[f'sample_z_s{s}_l{l}']); close(pts, r[f'sample_pts_s{s}_l{l}'])
+
+
+def test_volumetric_rendering_and_depth():
+  r = ref('model_utils')
+  for w in (0, 1):
+    for i in (0, 1):
+      out = O.volumetric_rendering(T(r['vr_rgb']), T(r['vr_sigma']), T(r['vr_z']), T(r['directions']), bool(w), bool(i))
+      for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights'):
+        close(out[k], r[f'vr_w{w}_i{i}_{k}'], msg=f'w{w} i{i} {k}')
+  w = T(r['pdf_weights'])
+  assert (O.compute_depth_index(w).numpy() == r['depth_index']).all()
+  close(O.compute_depth_map(w, T(r['vr_z'])), r['depth_map'])
+  close(O.compute_opaqueness_mask(w), r['opaqueness_mask'])
+
+
+def test_piecewise_constant_pdf_and_sample_pdf():
+  r = ref('model_utils')
+  z = T(r['vr_z']); w = T(r['pdf_weights'])
+  z_mid = .5 * (z[..., 1:] + z[..., :-1])
+  for s in (0, 1):
+    zs = O.piecewise_constant_pdf(z_mid, w[..., 1:-1], 9, bool(s), T(r['u']))
+    close(zs, r[f'pdf_z_s{s}'])
+    zf, pf = O.sample_pdf(z_mid, w[..., 1:-1], T(r['origins']), T(r['directions']), z, 9, bool(s), T(r['u']))
+    close(zf, r[f'sample_pdf_z_s{s}']); close(pf, r[f'sample_pdf_pts_s{s}'])
+
+
+def test_encoders():
+  r = ref('modules')
+  x = T(r['x'])
+  for F in (0, 4, 8):
+    close(O.sinusoidal_encode(x, F), r[f'posenc_F{F}'])
+  for a in (0.0, 2.5, 8.0):
+    close(O.annealed_sinusoidal_encode(x, 8, a), r[f'annealed_a{a}'])
+  close(O.cosine_easing_window(8, 3.25, torch.float64), r['window_a3.25'])
+
+
+def test_nerf_mlp():
+  r = ref('modules')
+  spec = O.ModelSpec(use_camera_metadata=True)
+  p = O.init_params(spec, seed=4, trained_like=True)['nerf_mlps_coarse']
+  rgb, alpha = O.nerf_mlp(p, T(r['mlp_in']), None, T(r['mlp_cond']), spec)
+  close(rgb, r['mlp_rgb'], 1e-9); close(alpha, r['mlp_alpha'], 1e-9)
+
+
+def test_se3_field_and_jacobian():
+  r = ref('se3_field')
+  spec = O.ModelSpec(use_warp=True, num_warp_freqs=6, num_warp_features=8, num_warp_embeddings=4)
+  wp = O.init_params(spec, seed=6, trained_like=True)['warp_field']
+  out = O.se3_field(wp, T(r['points']), torch.tensor(r['ids']), float(r['alpha']), 6, return_jacobian=True)
+  close(out['warped_points'], r['warped'], 1e-9)
+  close(out['jacobian'], r['jacobian_fd'], 2e-6)   # reference side: central differences of ITS warp (jax.jacfwd in the original)
+
+
+@pytest.mark.parametrize('name', ['nowarp', 'camera', 'warp'])
+def test_nerf_model_apply_end_to_end(name):
+  import sys
+  sys.path.insert(0, os.path.join(HERE, 'golden'))
+  import make_golden  # noqa: F401  (only for sys.path symmetry)
+  cases = {
+      'nowarp': (dict(num_coarse_samples=10, num_fine_samples=7, num_nerf_point_freqs=6, use_stratified_sampling=True), 0.0),
+      'camera': (dict(num_coarse_samples=8, num_fine_samples=8, num_nerf_point_freqs=4, use_stratified_sampling=False,
+                      use_camera_metadata=True), 0.0),
+      'warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                    num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True), 3.25),
+  }
+  kw, alpha = cases[name]
+  r = ref('nerf_' + name)
+  spec = O.ModelSpec(**kw)
+  seed = int(r['seed'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(3, seed=seed + 1)
+  ret = O.nerf_model_apply(params, spec, batch, alpha, return_points=spec.use_warp, return_warp_jacobian=spec.use_warp,
+                           t_rand=T(r['t_rand']), u=T(r['u']))
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights'):
+      close(ret[lv][k], r[f'{lv}/{k}'], 1e-8, msg=f'{name} {lv}/{k}')
+    if spec.use_warp:
+      close(ret[lv]['points'], r[f'{lv}/points'], 1e-10); close(ret[lv]['warped_points'], r[f'{lv}/warped_points'], 1e-9)
+      close(ret[lv]['warp_jacobian'], r[f'{lv}/warp_jacobian'], 2e-6)
+  if spec.use_warp:
+    el, res = O.compute_elastic_loss(ret['coarse']['warp_jacobian'])
+    close(el, r['coarse/elastic_loss'], 2e-6); close(res, r['coarse/elastic_residual'], 2e-6)
+
+
+def test_losses_psnr_elastic():
+  r = ref('losses_schedules')
+  sq = T(r['sq'])
+  close(O.general_loss_with_squared_residual(sq, -2.0, 0.03), r['gl_m2_c03'], 1e-12)
+  close(O.general_loss_with_squared_residual(sq, -2.0, 0.001), r['gl_m2_c001'], 1e-12)
+  close(O.general_loss_with_squared_residual(sq, 1.0, 1.0), r['gl_1_c1'], 1e-12)
+  close(O.compute_psnr(T([0.5, 0.01, 1e-4])), r['psnr'], 1e-12)
+  el, res = O.compute_elastic_loss(T(r['el_J']))
+  close(el, r['el_loss'], 1e-10); close(res, r['el_residual'], 1e-10)

@@ -283,6 +283,38 @@ int nrf_sample_pdf(const float* z_coarse, const float* weights_coarse, int32_t n
                    int32_t num_coarse, int32_t num_fine, int32_t stratified, const float* u,
                    uint64_t seed, uint64_t offset, float* z_out, void* stream);
 
+/* ---- camera geometry (the eval / dataset side of the path) ----
+ * nerfies/camera.py Camera: orientation is the world-to-camera rotation (row-major),
+ * position the camera centre in world space; intrinsics as camera.py:110-140. */
+typedef struct nrf_camera {
+  float orientation[9];
+  float position[3];
+  float focal_length;
+  float principal_point[2];
+  float skew;
+  float pixel_aspect_ratio;
+  float radial_distortion[3];      /* k1 k2 k3 */
+  float tangential_distortion[2];  /* p1 p2 */
+  int32_t image_size[2];           /* width, height */
+} nrf_camera;
+
+/* Camera.pixels_to_rays (camera.py:244-269) incl. the fixed 10-iteration Newton
+ * undistort (camera.py:26-105).  pixels: device [n,2] fp32, or NULL for the pixel
+ * centres of the whole image in row-major [H,W] order (get_pixel_centers,
+ * camera.py:317-321; then n must equal width*height) -- which makes this
+ * datasets/core.py:50-75 camera_to_rays in one launch: directions [n,3], and,
+ * when non-NULL, origins [n,3] (the tiled camera position) and pixels_out [n,2]. */
+int nrf_camera_pixels_to_rays(const nrf_camera* camera, const float* pixels, int64_t n, float* origins,
+                              float* directions, float* pixels_out, void* stream);
+
+/* Camera.pixels_to_points (camera.py:271-277): points [n,3] at `depth` [n] measured
+ * along the optical axis. */
+int nrf_camera_pixels_to_points(const nrf_camera* camera, const float* pixels, const float* depth, int64_t n,
+                                float* points, void* stream);
+
+/* Camera.project (camera.py:283-315): world points [n,3] -> distorted pixel positions [n,2]. */
+int nrf_camera_project(const nrf_camera* camera, const float* points, int64_t n, float* pixels, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1283,4 +1283,65 @@ int nrf_sample_pdf(const float* z_coarse, const float* weights_coarse, int32_t n
   return check_launch("nrf_sample_pdf");
 }
 
+namespace {
+int camera_args(const nrf_camera* cam, CameraArgs* c) {
+  if (!cam) return fail(NRF_E_NULL, "camera is null");
+  if (!(cam->focal_length > 0.f) || !(cam->pixel_aspect_ratio > 0.f))
+    return fail(NRF_E_SHAPE, "focal_length and pixel_aspect_ratio must be positive");
+  if (cam->image_size[0] <= 0 || cam->image_size[1] <= 0) return fail(NRF_E_SHAPE, "image_size must be positive");
+  for (int i = 0; i < 9; ++i) c->R[i] = cam->orientation[i];
+  for (int i = 0; i < 3; ++i) c->pos[i] = cam->position[i];
+  c->focal = cam->focal_length;
+  c->cx = cam->principal_point[0];
+  c->cy = cam->principal_point[1];
+  c->skew = cam->skew;
+  c->aspect = cam->pixel_aspect_ratio;
+  c->k1 = cam->radial_distortion[0];
+  c->k2 = cam->radial_distortion[1];
+  c->k3 = cam->radial_distortion[2];
+  c->p1 = cam->tangential_distortion[0];
+  c->p2 = cam->tangential_distortion[1];
+  c->width = cam->image_size[0];
+  c->height = cam->image_size[1];
+  // has_radial_distortion or has_tangential_distortion (camera.py:232): the solver is skipped, not run to a no-op
+  c->distorted = (c->k1 != 0.f || c->k2 != 0.f || c->k3 != 0.f || c->p1 != 0.f || c->p2 != 0.f) ? 1 : 0;
+  return NRF_OK;
+}
+bool aligned8(const void* p) { return ((uintptr_t)p & 7u) == 0; }
+}  // namespace
+
+int nrf_camera_pixels_to_rays(const nrf_camera* camera, const float* pixels, int64_t n, float* origins,
+                              float* directions, float* pixels_out, void* stream) {
+  CameraArgs c;
+  CK(camera_args(camera, &c));
+  if (!directions) return fail(NRF_E_NULL, "directions is null");
+  if (n <= 0) return fail(NRF_E_SHAPE, "n must be positive");
+  if (!pixels && n != (int64_t)c.width * c.height)
+    return fail(NRF_E_SHAPE, "pixels == NULL renders the pixel centres: n must equal width*height");
+  if (!aligned8(pixels) || !aligned8(pixels_out)) return fail(NRF_E_SHAPE, "pixel buffers must be 8-byte aligned");
+  launch_camera_rays(c, pixels, nullptr, (long)n, origins, directions, pixels_out, (hipStream_t)stream);
+  return check_launch("nrf_camera_pixels_to_rays");
+}
+
+int nrf_camera_pixels_to_points(const nrf_camera* camera, const float* pixels, const float* depth, int64_t n,
+                                float* points, void* stream) {
+  CameraArgs c;
+  CK(camera_args(camera, &c));
+  if (!pixels || !depth || !points) return fail(NRF_E_NULL, "pixels / depth / points is null");
+  if (n <= 0) return fail(NRF_E_SHAPE, "n must be positive");
+  if (!aligned8(pixels)) return fail(NRF_E_SHAPE, "pixel buffers must be 8-byte aligned");
+  launch_camera_rays(c, pixels, depth, (long)n, nullptr, points, nullptr, (hipStream_t)stream);
+  return check_launch("nrf_camera_pixels_to_points");
+}
+
+int nrf_camera_project(const nrf_camera* camera, const float* points, int64_t n, float* pixels, void* stream) {
+  CameraArgs c;
+  CK(camera_args(camera, &c));
+  if (!points || !pixels) return fail(NRF_E_NULL, "points / pixels is null");
+  if (n <= 0) return fail(NRF_E_SHAPE, "n must be positive");
+  if (!aligned8(pixels)) return fail(NRF_E_SHAPE, "pixel buffers must be 8-byte aligned");
+  launch_camera_project(c, points, (long)n, pixels, (hipStream_t)stream);
+  return check_launch("nrf_camera_project");
+}
+
 }  // extern "C"

@@ -266,4 +266,15 @@ void launch_background_loss(const float* points, const float* warped, int N, int
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
                  double b2, double eps, int64_t step, double gscale, hipStream_t stream);
 
+// camera.hip -- Camera.pixels_to_rays / pixels_to_points / project (nerfies/camera.py)
+struct CameraArgs {
+  float R[9], pos[3];
+  float focal, cx, cy, skew, aspect;
+  float k1, k2, k3, p1, p2;
+  int width, height, distorted;
+};
+void launch_camera_rays(const CameraArgs& c, const float* pixels, const float* depth, long n, float* origins,
+                        float* directions, float* pixels_out, hipStream_t stream);
+void launch_camera_project(const CameraArgs& c, const float* points, long n, float* pixels, hipStream_t stream);
+
 }  // namespace nrf

@@ -69,6 +69,13 @@ class Elastic(C.Structure):
               ('loss_scale', C.c_float)]
 
 
+class CameraDesc(C.Structure):
+  _fields_ = [('orientation', C.c_float * 9), ('position', C.c_float * 3), ('focal_length', C.c_float),
+              ('principal_point', C.c_float * 2), ('skew', C.c_float), ('pixel_aspect_ratio', C.c_float),
+              ('radial_distortion', C.c_float * 3), ('tangential_distortion', C.c_float * 2),
+              ('image_size', C.c_int32 * 2)]
+
+
 class ProfileEntry(C.Structure):
   _fields_ = [('name', C.c_char * 32), ('ms', C.c_double), ('launches', C.c_int32), ('pad_', C.c_int32),
               ('flops_per_launch', C.c_double)]
@@ -80,6 +87,7 @@ EXPORTS = [
     'nrf_sample_along_rays', 'nrf_volumetric_rendering', 'nrf_sample_pdf', 'nrf_profile_enable', 'nrf_profile_read',
     'nrf_debug_wgrad_segments', 'nrf_debug_ws_offset', 'nrf_train_step_loss_grad_ex', 'nrf_workspace_bytes_ex',
     'nrf_warp_points_workspace_bytes', 'nrf_warp_points',
+    'nrf_camera_pixels_to_rays', 'nrf_camera_pixels_to_points', 'nrf_camera_project',
 ]
 
 _lib = None
@@ -126,6 +134,9 @@ def load_library(path=None):
       'nrf_workspace_bytes_ex': [vp, i32, u32, i32, i32, C.POINTER(C.c_size_t)],
       'nrf_warp_points_workspace_bytes': [vp, i32, C.POINTER(C.c_size_t)],
       'nrf_warp_points': [vp, vp, vp, vp, i32, C.POINTER(StepScalars), vp, vp, C.c_size_t, vp],
+      'nrf_camera_pixels_to_rays': [C.POINTER(CameraDesc), vp, i64, vp, vp, vp, vp],
+      'nrf_camera_pixels_to_points': [C.POINTER(CameraDesc), vp, vp, i64, vp, vp],
+      'nrf_camera_project': [C.POINTER(CameraDesc), vp, i64, vp, vp],
   }
   for name, argtypes in sigs.items():
     fn = getattr(lib, name)

@@ -196,9 +196,12 @@ def losses_and_schedules():
       'cosine_easing': ('cosine_easing', 0.01, 1e-8, 5000),
       'piecewise': ('piecewise', [(500, ('constant', 0.01)), (2000, ('cosine_easing', 0.01, 1e-5, 2000)), (1, ('constant', 1e-5))]),
       'delayed': ('delayed', ('exponential', 1e-3, 1e-4, 250000), 2500, 0.01),
+      'step': ('step', 1e-3, 1000, 0.5, 3),
+      'dict_linear': {'type': 'linear', 'initial_value': 1.0, 'final_value': 0.25, 'num_steps': 1000},
   }
   for k, dfn in defs.items():
-    sch = ref_sched.from_tuple(dfn)
+    # from_config's Mapping test uses collections.Mapping (removed in Python 3.10): dispatch here instead
+    sch = ref_sched.from_dict(dfn) if isinstance(dfn, dict) else ref_sched.from_tuple(dfn)
     out['sched_' + k] = np.array([float(sch(int(s))) for s in steps])
   out['sched_steps'] = steps
   save('losses_schedules', **out)

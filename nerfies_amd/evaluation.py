@@ -102,3 +102,27 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
       ret = {k: v[:-pad] for k, v in ret.items()}
     ret_maps.append(ret)
   return {k: torch.cat([r[k] for r in ret_maps], 0).reshape(h, w, *ret_maps[0][k].shape[1:]) for k in ret_maps[0]}
+
+
+def rays_from_camera(camera, metadata: Optional[Dict[str, int]] = None, device='cuda'):
+  """One dataset item for a camera, built on the GPU: what datasets/core.py:163-190 (_camera_to_rays_fn +
+  _tf_broadcast_metadata_fn) assembles on the host -- origins / directions / pixels [H, W, .] and every metadata id
+  ('warp', 'appearance', 'camera') broadcast to [H, W, 1] int32."""
+  rays = camera.to_rays(device)
+  h, w = rays['origins'].shape[:2]
+  if metadata:
+    rays['metadata'] = {k: torch.full((h, w, 1), int(v), dtype=torch.int32, device=rays['origins'].device)
+                       for k, v in metadata.items()}
+  return rays
+
+
+def compute_psnr(mse):
+  """utils.compute_psnr (utils.py:283-293): -10 log10(mse)."""
+  return -10.0 * torch.log10(torch.as_tensor(mse))
+
+
+def image_metrics(rgb: torch.Tensor, target: torch.Tensor) -> Dict[str, torch.Tensor]:
+  """mse / psnr of a rendered frame against its target (eval.py:121-125).  The multiscale SSIM of eval.py:60-62 is
+  tf.image.ssim_multiscale, a third-party routine outside this path: not rebuilt."""
+  mse = ((rgb - target.to(rgb.device)) ** 2).mean()
+  return {'mse': mse, 'psnr': compute_psnr(mse)}

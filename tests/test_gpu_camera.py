@@ -109,3 +109,33 @@ def test_errors():
   assert b'width*height' in lib.nrf_last_error()
   d.focal_length = 0.0
   assert lib.nrf_camera_project(d, out.data_ptr(), 4, out.data_ptr(), None) != 0
+
+
+def test_render_frame_from_camera_matches_oracle():
+  """Camera -> rays on the GPU -> chunked render (evaluation.py:62-99) == the oracle applied to oracle-camera rays."""
+  import helpers as H
+  from nerfies_amd import evaluation, training
+  from oracle import nerfies_oracle as O
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=4, use_stratified_sampling=False,
+                     use_warp=True, num_warp_freqs=4, use_camera_metadata=True)
+  oparams = O.init_params(spec, seed=3, trained_like=True)
+  model, fp = H.gpu_model(spec, oparams)
+  cam, ocam, _ = _pair(9, size=(12, 9), focal=15.0, skew=0.0, par=1.0)
+  cam.position[:] = [0.05, -0.02, 0.1]; ocam['position'][:] = cam.position
+  meta = {'warp': 2, 'camera': 1, 'appearance': 0}
+  rays = evaluation.rays_from_camera(cam, meta)
+  assert rays['metadata']['warp'].shape == (9, 12, 1) and rays['metadata']['warp'].dtype == torch.int32
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=2.0)
+  fn = lambda k0, k1, params, r, extra: model.apply({'params': params}, r, extra)
+  img = evaluation.render_image(state, rays, fn, 1, 0, chunk=50)
+  want_rays = CO.camera_to_rays(ocam)
+  n = 12 * 9
+  batch = {'origins': torch.from_numpy(want_rays['origins'].reshape(n, 3)).double(),
+           'directions': torch.from_numpy(want_rays['directions'].reshape(n, 3)).double(),
+           'metadata': {k: torch.full((n, 1), v, dtype=torch.int64) for k, v in meta.items()}}
+  ref = O.nerf_model_apply(oparams, spec, batch, 2.0)
+  got = img['rgb'].reshape(n, 3).cpu().numpy()
+  np.testing.assert_allclose(got, ref['fine']['rgb'].numpy(), rtol=0, atol=2e-4)
+  np.testing.assert_allclose(img['depth'].reshape(n).cpu().numpy(), ref['fine']['depth'].numpy(), rtol=0, atol=2e-4)
+  m = evaluation.image_metrics(img['rgb'], torch.from_numpy(ref['fine']['rgb'].numpy()).float().reshape(9, 12, 3))
+  assert float(m['psnr']) > 60

@@ -59,8 +59,8 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     ++stamp_i;
   };
 
-  unsigned long long wg_t0 = 0;
-  if (A.timeline && tid == 0) wg_t0 = clock64();
+  unsigned long long wg_t0 = 0, wg_w0 = 0;
+  if (A.timeline && tid == 0) { wg_t0 = clock64(); wg_w0 = wall_clock64(); }
   int* tslot = reinterpret_cast<int*>(pe);   // free between tiles
   for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
     STAMP();   // tile start
@@ -254,7 +254,8 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     unsigned long long* rec = A.timeline + 1024 + 4 * (size_t)blockIdx.x;
     rec[0] = wg_t0; rec[1] = clock64();
     rec[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
-    rec[3] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));   // HW_REG_XCC_ID
+    rec[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf)   // HW_REG_XCC_ID
+             | ((wall_clock64() - wg_w0) << 8);                               // residency in 100 MHz ticks
   }
 }
 

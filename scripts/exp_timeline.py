@@ -8,7 +8,7 @@ dev = torch.device('cuda:0')
 train = len(sys.argv) > 1 and sys.argv[1] == 'train'
 model, fp = models.construct_nerf(0, bench.Cfg, 1024, [0,1,2,3],[0,1],[0,1,2,3], 0.0206, 0.826, device=dev)
 batch = bench.synthetic_batch(1024, 100, dev)
-for _ in range(3): model.apply({'params': fp}, batch, {}, rngs={'coarse': 1, 'fine': 2}, train=train)
+for _ in range(int(os.environ.get('WARM', 40))): model.apply({'params': fp}, batch, {}, rngs={'coarse': 1, 'fine': 2}, train=train)
 torch.cuda.synchronize()
 ws = model.workspace(1024, train, dev)
 o = C.c_int64(0); L.check(model.lib.nrf_debug_ws_offset(model.handle, b'timeline', 1, C.byref(o)))
@@ -30,7 +30,8 @@ nwg = int((rec[:, 1] > 0).sum())
 rec = rec[:nwg]
 t0 = rec[:, 0].min()
 st, en = rec[:, 0] - t0, rec[:, 1] - t0
-hw = rec[:, 2]; xcc = rec[:, 3] & 0xf
+hw = rec[:, 2]; xcc = rec[:, 3] & 0xf; wall = rec[:, 3] >> 8
+print('shader clock during the kernel: median %.0f MHz (min %.0f max %.0f)' % tuple(np.percentile((en - st) / np.maximum(wall, 1) * 100.0, [50, 0, 100])))
 cu = (hw >> 8) & 0xf; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7
 print('workgroups', nwg, 'kernel span', en.max(), ' start spread: p50 %d p90 %d max %d' % tuple(np.percentile(st, [50, 90, 100])))
 print('durations: min %d median %d max %d' % (np.min(en - st), np.median(en - st), np.max(en - st)))

@@ -70,8 +70,24 @@ def _worker(rank, port, tmp):
   # ---- eval: rank-sliced chunks + all_gather reassemble the full image (evaluation.py:62-99) ----
   rays = {'origins': torch.linspace(-1, 1, 5 * 7 * 3).reshape(5, 7, 3), 'directions': torch.ones(5, 7, 3) * 0.1}
   img = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=9)   # 35 px: ragged, needs padding
+  # ---- data: every rank takes its own 1/world slice of each global batch (core.py:110-121) ----
+  from nerfies_amd import datasets
+  n = 50
+  table = datasets.RayTable({'origins': torch.arange(n * 3, dtype=torch.float32).reshape(n, 3),
+                             'metadata/warp': torch.arange(n, dtype=torch.int32).reshape(n, 1)}, n)
+  mine = [b['metadata']['warp'][:, 0] for b in table.batches(16, repeat=False)]
+  gathered = []
+  for b in mine:
+    parts = [torch.zeros(16 // WORLD if len(b) == 16 // WORLD else len(b), dtype=torch.int32) for _ in range(WORLD)]
+    dist.all_gather(parts, b)
+    gathered.append(torch.cat(parts))
+  try:
+    next(table.batches(15))
+    odd = 'accepted'
+  except ValueError:
+    odd = 'rejected'
   if rank == 0:
-    torch.save({'grad_sum': g, 'stats': st, 'img': img}, tmp)
+    torch.save({'grad_sum': g, 'stats': st, 'img': img, 'batches': gathered, 'odd': odd}, tmp)
   dist.barrier()
   dist.destroy_process_group()
 
@@ -98,3 +114,7 @@ def test_two_rank_gradients_and_render(tmp_path):
     assert ref[k].shape == got['img'][k].shape
     np.testing.assert_allclose(got['img'][k].numpy(), ref[k].numpy(), atol=1e-7)
   assert ref['rgb'].shape == (5, 7, 3) and ref['depth'].shape == (5, 7)
+  # the two ranks' shards of each batch, concatenated in rank order, are the global batches in table order
+  assert got['odd'] == 'rejected'          # batch_size % device_count != 0 (train.py:155-156)
+  assert torch.equal(torch.cat(got['batches']), torch.arange(50, dtype=torch.int32))
+  assert [len(b) for b in got['batches']] == [16, 16, 16, 2]

@@ -46,7 +46,8 @@ struct WsPlan {
   uint32_t flags = 0;
   int S[4], rows[4], ntiles[4];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
-  size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b;
+  size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b, emb_off_b;
+  size_t iparams = 0, igrad = 0;   // zero-padded parameter image / its gradient (models narrower than the kernels)
   std::vector<WgradSegment> segs;
   std::vector<int> seg_begin;
   int wgrad_nwg = 0;
@@ -112,8 +113,13 @@ struct Prof {
 struct nrf_handle_s {
   Prof prof;
   nrf_model_desc d;
-  std::vector<nrf_tensor_info> layout;
+  std::vector<nrf_tensor_info> layout;    // INTERNAL leaves (kernel widths); == xlayout unless `embed`
   int64_t nparams = 0;
+  std::vector<nrf_tensor_info> xlayout;   // the caller's leaves (nrf_param_layout)
+  int64_t xnparams = 0;
+  std::vector<EmbedDesc> emb;             // external <-> internal element map, one per leaf
+  bool embed = false;                     // trunk / rgb branch narrower than the kernels: run on a zero-padded image
+  WarpParamOffsets xwpo;                  // warp leaves at their EXTERNAL offsets (nrf_warp_points reads the caller's buffer)
   MlpParamOffsets po[2];
   PackOffsets pk;
   int64_t app_off = -1, cam_off = -1;
@@ -140,7 +146,12 @@ struct nrf_handle_s {
 
 namespace {
 
-void add_leaf(nrf_handle h, const std::string& name, int rows, int cols, int64_t* off_out) {
+// Appends a leaf to the internal layout (rows x cols = what the kernels index) and to the external one
+// (xrows x xcols = what the model owns; defaults to the same).  External rows >= split sit `shift` rows lower inside.
+void add_leaf(nrf_handle h, const std::string& name, int rows, int cols, int64_t* off_out, int xrows = -1, int xcols = -1,
+              int split = -1, int64_t* xoff_out = nullptr) {
+  if (xrows < 0) xrows = rows;
+  if (xcols < 0) xcols = cols;
   nrf_tensor_info t;
   memset(&t, 0, sizeof(t));
   snprintf(t.name, sizeof(t.name), "%s", name.c_str());
@@ -151,42 +162,59 @@ void add_leaf(nrf_handle h, const std::string& name, int rows, int cols, int64_t
   h->nparams += (int64_t)rows * cols;
   h->nparams = (int64_t)align_up((size_t)h->nparams, 4);   // keep every leaf 16-byte aligned
   h->layout.push_back(t);
+  nrf_tensor_info x = t;
+  x.offset = h->xnparams;
+  x.rows = xrows;
+  x.cols = xcols;
+  if (xoff_out) *xoff_out = x.offset;
+  h->xnparams += (int64_t)xrows * xcols;
+  h->xnparams = (int64_t)align_up((size_t)h->xnparams, 4);
+  h->xlayout.push_back(x);
+  EmbedDesc e;
+  e.ext_off = x.offset; e.int_off = t.offset; e.rows = xrows; e.ext_cols = xcols; e.int_cols = cols;
+  e.split = split < 0 ? xrows : split; e.shift = rows - xrows; e.pad_ = 0;
+  h->emb.push_back(e);
+  if (xrows != rows || xcols != cols) h->embed = true;
 }
 
 void build_layout(nrf_handle h) {
   const nrf_model_desc& d = h->d;
-  const int W = d.nerf_trunk_width;
+  const int W = TRUNK_W, RW = RGB_W;                               // what the kernels index
+  const int XW = d.nerf_trunk_width, XRW = d.nerf_rgb_branch_width;   // what the model owns (<= W, RW)
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const std::string base = lv == 0 ? "nerf_mlps_coarse" : "nerf_mlps_fine";
     MlpParamOffsets& po = h->po[lv];
     for (int i = 0; i < d.nerf_trunk_depth; ++i) {
-      int fin = i == 0 ? h->P : W;
-      if (i == d.nerf_skip_layer) fin += h->P;
-      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/kernel", fin, W, &po.trunk_k[i]);
-      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/bias", 1, W, &po.trunk_b[i]);
+      const int hid = i == 0 ? 0 : 1;                 // rows of the running activation, then (layer 0 / skip) the posenc rows
+      const int pe = (i == 0 || i == d.nerf_skip_layer) ? h->P : 0;
+      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/kernel", hid * W + pe, W, &po.trunk_k[i], hid * XW + pe, XW,
+               hid * XW);
+      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/bias", 1, W, &po.trunk_b[i], 1, XW);
     }
-    add_leaf(h, base + "/bottleneck/kernel", W, W, &po.bn_k);
-    add_leaf(h, base + "/bottleneck/bias", 1, W, &po.bn_b);
-    add_leaf(h, base + "/MLP_1/hidden_0/kernel", W + h->R, d.nerf_rgb_branch_width, &po.rgbh_k);
-    add_leaf(h, base + "/MLP_1/hidden_0/bias", 1, d.nerf_rgb_branch_width, &po.rgbh_b);
-    add_leaf(h, base + "/MLP_1/logit/kernel", d.nerf_rgb_branch_width, 3, &po.logit_k);
+    add_leaf(h, base + "/bottleneck/kernel", W, W, &po.bn_k, XW, XW);
+    add_leaf(h, base + "/bottleneck/bias", 1, W, &po.bn_b, 1, XW);
+    add_leaf(h, base + "/MLP_1/hidden_0/kernel", W + h->R, RW, &po.rgbh_k, XW + h->R, XRW, XW);
+    add_leaf(h, base + "/MLP_1/hidden_0/bias", 1, RW, &po.rgbh_b, 1, XRW);
+    add_leaf(h, base + "/MLP_1/logit/kernel", RW, 3, &po.logit_k, XRW, 3);
     add_leaf(h, base + "/MLP_1/logit/bias", 1, 3, &po.logit_b);
-    add_leaf(h, base + "/MLP_2/logit/kernel", W, 1, &po.alpha_k);
+    add_leaf(h, base + "/MLP_2/logit/kernel", W, 1, &po.alpha_k, XW, 1);
     add_leaf(h, base + "/MLP_2/logit/bias", 1, 1, &po.alpha_b);
   }
   if (h->warp) {   // warping.SE3Field (warping.py:202-320); flax names per SURVEY.md A.2
     WarpParamOffsets& w = h->wpo;
-    add_leaf(h, "warp_field/metadata_encoder/embed/embedding", d.num_warp_embeddings, d.num_warp_features, &w.embed);
+    WarpParamOffsets& x = h->xwpo;
+    add_leaf(h, "warp_field/metadata_encoder/embed/embedding", d.num_warp_embeddings, d.num_warp_features, &w.embed, -1, -1, -1,
+             &x.embed);
     for (int i = 0; i < WARP_DEPTH; ++i) {
       int fin = i == 0 ? h->Win : WARP_W;
       if (i == WARP_SKIP) fin += h->Win;
-      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", fin, WARP_W, &w.trunk_k[i]);
-      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/bias", 1, WARP_W, &w.trunk_b[i]);
+      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", fin, WARP_W, &w.trunk_k[i], -1, -1, -1, &x.trunk_k[i]);
+      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/bias", 1, WARP_W, &w.trunk_b[i], -1, -1, -1, &x.trunk_b[i]);
     }
-    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k);
-    add_leaf(h, "warp_field/branches_w/logit/bias", 1, 3, &w.w_b);
-    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k);
-    add_leaf(h, "warp_field/branches_v/logit/bias", 1, 3, &w.v_b);
+    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k, -1, -1, -1, &x.w_k);
+    add_leaf(h, "warp_field/branches_w/logit/bias", 1, 3, &w.w_b, -1, -1, -1, &x.w_b);
+    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k, -1, -1, -1, &x.v_k);
+    add_leaf(h, "warp_field/branches_v/logit/bias", 1, 3, &w.v_b, -1, -1, -1, &x.v_b);
   }
   if (d.use_appearance_metadata)
     add_leaf(h, "appearance_encoder/embed/embedding", d.num_appearance_embeddings, d.num_appearance_features, &h->app_off);
@@ -385,8 +413,13 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   p.reduce_off_b = p.groups_off_b + align_up(specs.size() * sizeof(WgradGroup) + 256, 256);
   p.segs_off_b = p.reduce_off_b + align_up(nreduce_max * sizeof(ReduceDesc), 256);
   p.segbegin_off_b = p.segs_off_b + align_up(p.segs.size() * sizeof(WgradSegment) + 256, 256);
-  const size_t table_bytes = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
+  p.emb_off_b = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
+  const size_t table_bytes = p.emb_off_b + align_up((h->emb.size() + 1) * sizeof(EmbedDesc), 256);
   p.tables = take(table_bytes / 4);
+  if (h->embed) {
+    p.iparams = take((size_t)h->nparams);
+    if (train) p.igrad = take((size_t)h->nparams);
+  }
 
   auto alloc_warp = [&](LevelWs& L, size_t nt) {
     L.wpoints = take(nt * TILE_ROWS * 3);
@@ -597,6 +630,10 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
     e = hipMemcpyAsync(base + p.segbegin_off_b, p.seg_begin.data(), p.seg_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload wgrad segment index");
   }
+  if (h->embed) {
+    e = hipMemcpyAsync(base + p.emb_off_b, h->emb.data(), h->emb.size() * sizeof(EmbedDesc), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload embed table");
+  }
   if (!p.reduce.empty()) {
     e = hipMemcpyAsync(base + p.reduce_off_b, p.reduce.data(), p.reduce.size() * sizeof(ReduceDesc), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload reduce table");
@@ -703,11 +740,11 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
   return a;
 }
 
-int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
+int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
                  const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream, int bgN = 0,
                  int elastic = 0) {
   CK(validate_rays(h, rays));
-  if (!params || !ws) return fail(NRF_E_NULL, "params / workspace is null");
+  if (!params_x || !ws) return fail(NRF_E_NULL, "params / workspace is null");
   query_device(h);
   const int B = rays->num_rays;
   build_plan(h, B, flags & NRF_FLAG_TRAIN, bgN, elastic);
@@ -722,6 +759,12 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
   if (hipMemsetAsync(ws + p.counters, 0, 64 * sizeof(int), stream) != hipSuccess) return fail(NRF_E_HIP, "zero tile counters");
+  const float* params = params_x;
+  if (h->embed) {   // narrower model: run on its zero-padded image (nrf_internal.h EmbedDesc)
+    if (hipMemsetAsync(ws + p.iparams, 0, (size_t)h->nparams * sizeof(float), stream) != hipSuccess) return fail(NRF_E_HIP, "zero padded params");
+    launch_embed(reinterpret_cast<const EmbedDesc*>(tables + p.emb_off_b), (int)h->emb.size(), params_x, ws + p.iparams, true, stream);
+    params = ws + p.iparams;
+  }
 
   Prof& pf = h->prof;
   pf.begin("pack_prep_sample", 0, stream);
@@ -797,14 +840,18 @@ int forward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const 
 }
 
 // d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
-int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
-                  float* grad, float* stats, float* ws, hipStream_t stream, const nrf_background* bg = nullptr,
+int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
+                  float* grad_x, float* stats, float* ws, hipStream_t stream, const nrf_background* bg = nullptr,
                   const nrf_step_scalars* scalars = nullptr, const nrf_elastic* el = nullptr) {
   WsPlan& p = h->plan;
   const nrf_model_desc& d = h->d;
   const int B = p.B;
   const bool warp_on = h->stashed_warp;
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
+  // narrower model: the stashed forward left the padded parameter image in the workspace; gradients are formed
+  // in the padded layout and copied out at the end
+  const float* params = h->embed ? ws + p.iparams : params_x;
+  float* grad = h->embed ? ws + p.igrad : grad_x;
   hipError_t e = hipMemsetAsync(grad, 0, (size_t)h->nparams * sizeof(float), stream);
   if (e != hipSuccess) return fail_hip(e, "zero grad");
   e = hipMemsetAsync(ws + p.mse, 0, 64 * sizeof(float), stream);
@@ -951,6 +998,11 @@ int backward_impl(nrf_handle h, const float* params, const nrf_rays* rays, const
   const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
   for (int pass = 0, at = 0; pass < 4; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
     if (p.nreduce_pass[pass] > 0) launch_reduce(rd + at, p.nreduce_pass[pass], ws, grad, stream);
+  if (h->embed) {
+    e = hipMemsetAsync(grad_x, 0, (size_t)h->xnparams * sizeof(float), stream);
+    if (e != hipSuccess) return fail_hip(e, "zero grad");
+    launch_embed(reinterpret_cast<const EmbedDesc*>(tables + p.emb_off_b), (int)h->emb.size(), grad, grad_x, false, stream);
+  }
   const bool el_any = el && p.elastic && warp_on;
   if (stats) launch_finish_stats(ws + p.mse, B, bg_on ? ws + p.bg_loss : nullptr, bg_on ? p.bgN : 0, bg_on ? bg->loss_weight : 0.f,
                                  el_any ? ws + p.el_sums : nullptr, el_any ? (el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]) : 0, el_any ? el->loss_weight : 0.f, stats,
@@ -969,10 +1021,12 @@ const char* nrf_last_error(void) { return g_err; }
 int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   if (!desc || !out) return fail(NRF_E_NULL, "desc / out is null");
   const nrf_model_desc& d = *desc;
-  if (d.nerf_trunk_width != TRUNK_W || d.nerf_trunk_depth != TRUNK_DEPTH || d.nerf_skip_layer != SKIP_LAYER)
-    return fail(NRF_E_UNSUPPORTED, "MFMA chain is built for an 8x256 trunk with the skip at layer 4");
-  if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width != RGB_W)
-    return fail(NRF_E_UNSUPPORTED, "rgb branch must be 1 x 128");
+  if (d.nerf_trunk_depth != TRUNK_DEPTH || d.nerf_skip_layer != SKIP_LAYER)
+    return fail(NRF_E_UNSUPPORTED, "MFMA chain is built for a depth-8 trunk with the skip at layer 4");
+  if (d.nerf_trunk_width < 1 || d.nerf_trunk_width > TRUNK_W)   // narrower trunks run zero-padded (test_vrig.gin: 128)
+    return fail(NRF_E_UNSUPPORTED, "nerf_trunk_width must be in [1,256]");
+  if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width < 1 || d.nerf_rgb_branch_width > RGB_W)
+    return fail(NRF_E_UNSUPPORTED, "rgb branch must be 1 layer of width <= 128");
   if (d.use_alpha_condition) return fail(NRF_E_UNSUPPORTED, "use_alpha_condition (alpha-branch conditioning) not built yet");
   if (d.use_warp) {
     if (d.num_warp_freqs < 0 || d.num_warp_freqs > 8) return fail(NRF_E_SHAPE, "num_warp_freqs must be in [0,8]");
@@ -1014,17 +1068,17 @@ int nrf_destroy(nrf_handle h) {
 
 int nrf_param_count(nrf_handle h, int64_t* n) {
   if (!h || !n) return fail(NRF_E_NULL, "null");
-  *n = h->nparams;
+  *n = h->xnparams;
   return NRF_OK;
 }
 
 int nrf_param_layout(nrf_handle h, nrf_tensor_info* out, int32_t* n) {
   if (!h || !n) return fail(NRF_E_NULL, "null");
   if (out) {
-    if (*n < (int32_t)h->layout.size()) return fail(NRF_E_SHAPE, "layout array too small");
-    memcpy(out, h->layout.data(), h->layout.size() * sizeof(nrf_tensor_info));
+    if (*n < (int32_t)h->xlayout.size()) return fail(NRF_E_SHAPE, "layout array too small");
+    memcpy(out, h->xlayout.data(), h->xlayout.size() * sizeof(nrf_tensor_info));
   }
-  *n = (int32_t)h->layout.size();
+  *n = (int32_t)h->xlayout.size();
   return NRF_OK;
 }
 
@@ -1148,7 +1202,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   hipStream_t st = (hipStream_t)stream;
   if (h->wp_pack.empty() || h->wp_pack_base != (int64_t)q.wpk_f) {
     h->wp_pack.clear();
-    const WarpParamOffsets& w = h->wpo;
+    const WarpParamOffsets& w = h->xwpo;   // the caller's buffer: external offsets
     const WarpPackOffsets& wk = h->wpk;
     auto addw = [&](int64_t src, int dst, int row0, int kvalid, int K) {
       PackDesc d;
@@ -1166,7 +1220,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   launch_pack(reinterpret_cast<const PackDesc*>(ws + q.desc_f), (int)h->wp_pack.size(), params, ws, st);
   WarpFwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.params = params; a.po = h->wpo; a.wpk = ws + q.wpk_f; a.pk = h->wpk;
+  a.params = params; a.po = h->xwpo; a.wpk = ws + q.wpk_f; a.pk = h->wpk;
   a.points_in = points; a.point_ids = warp_ids; a.points_out = ws + q.out_f;
   a.S = 1; a.B = num_points; a.rows = num_points; a.ntiles = q.ntiles;
   a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha;

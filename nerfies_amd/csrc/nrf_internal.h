@@ -266,6 +266,16 @@ void launch_background_loss(const float* points, const float* warped, int N, int
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
                  double b2, double eps, int64_t step, double gscale, hipStream_t stream);
 
+// Narrower models run on the 256-wide / 128-wide kernels by embedding: the caller's parameter leaves are copied into
+// a zero-filled internal image with the kernels' widths (zero weights and biases for the extra units: relu(0) = 0 and
+// zero outgoing weights make the padded network compute the same function), gradients are copied back out.
+// element (r, c) of the external leaf <-> (r < split ? r : r + shift, c) of the internal leaf.
+struct EmbedDesc {
+  long long ext_off, int_off;
+  int rows, ext_cols, int_cols, split, shift, pad_;
+};
+void launch_embed(const EmbedDesc* descs, int ndesc, const float* src, float* dst, bool to_internal, hipStream_t stream);
+
 // camera.hip -- Camera.pixels_to_rays / pixels_to_points / project (nerfies/camera.py)
 struct CameraArgs {
   float R[9], pos[3];

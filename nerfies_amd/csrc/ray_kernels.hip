@@ -523,4 +523,23 @@ void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double
                      (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, c1, c2, (float)gscale);
 }
 
+namespace {
+__global__ __launch_bounds__(256) void embed_kernel(const EmbedDesc* __restrict__ descs, const float* __restrict__ src,
+                                                    float* __restrict__ dst, int to_internal) {
+  const EmbedDesc d = descs[blockIdx.y];
+  const long n = (long)d.rows * d.ext_cols;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / d.ext_cols), c = (int)(i - (long)r * d.ext_cols);
+    const long ii = d.int_off + (long)(r < d.split ? r : r + d.shift) * d.int_cols + c;
+    if (to_internal) dst[ii] = src[d.ext_off + i];
+    else dst[d.ext_off + i] = src[ii];
+  }
+}
+}  // namespace
+
+void launch_embed(const EmbedDesc* descs, int ndesc, const float* src, float* dst, bool to_internal, hipStream_t stream) {
+  if (ndesc <= 0) return;
+  embed_kernel<<<dim3(64, ndesc), 256, 0, stream>>>(descs, src, dst, to_internal ? 1 : 0);
+}
+
 }  // namespace nrf

@@ -70,9 +70,11 @@ def test_create_validates_and_reports(lib):
   from nerfies_amd import lib as L
   h = C.c_void_p()
   assert lib.nrf_create(None, C.byref(h)) == -1
-  d = _desc(nerf_trunk_width=192)
+  d = _desc(nerf_trunk_width=320)
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
   assert b'256' in lib.nrf_last_error()
+  d = _desc(nerf_trunk_depth=6)
+  assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
   d = _desc(num_coarse_samples=2)
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -2
   with pytest.raises(L.NrfError):
@@ -100,4 +102,33 @@ def test_param_layout_uses_flax_paths(lib):
   per_mlp = sum(r * c for k, (r, c, _) in names.items() if k.startswith('nerf_mlps_coarse/'))
   assert per_mlp == 589956
   assert all(off % 4 == 0 for _, _, off in names.values())
+  assert lib.nrf_destroy(h) == 0
+
+
+def test_narrow_model_reports_its_own_shapes(lib):
+  """configs/test_vrig.gin trains a 128-wide trunk: the layout the caller sees has the model's shapes (the library
+  runs it on a zero-padded image internally)."""
+  from nerfies_amd import lib as L
+  h = C.c_void_p()
+  d = _desc(nerf_trunk_width=128, nerf_rgb_branch_width=64, use_warp=1, num_warp_freqs=8, num_warp_features=8,
+            num_warp_embeddings=4)
+  assert lib.nrf_create(C.byref(d), C.byref(h)) == 0
+  n = C.c_int32(0)
+  assert lib.nrf_param_layout(h, None, C.byref(n)) == 0
+  infos = (L.TensorInfo * n.value)()
+  assert lib.nrf_param_layout(h, infos, C.byref(n)) == 0
+  names = {t.name.decode(): (t.rows, t.cols, t.offset) for t in infos}
+  assert names['nerf_mlps_coarse/MLP_0/hidden_0/kernel'][:2] == (51, 128)
+  assert names['nerf_mlps_coarse/MLP_0/hidden_4/kernel'][:2] == (128 + 51, 128)
+  assert names['nerf_mlps_fine/bottleneck/kernel'][:2] == (128, 128)
+  assert names['nerf_mlps_fine/MLP_1/hidden_0/kernel'][:2] == (128 + 27, 64)
+  assert names['nerf_mlps_fine/MLP_1/logit/kernel'][:2] == (64, 3)
+  assert names['nerf_mlps_fine/MLP_2/logit/kernel'][:2] == (128, 1)
+  assert names['warp_field/trunk/hidden_4/kernel'][:2] == (128 + 59, 128)
+  total = C.c_int64(0)
+  assert lib.nrf_param_count(h, C.byref(total)) == 0
+  last = max(names.values(), key=lambda t: t[2])
+  assert total.value >= last[2] + last[0] * last[1] and total.value < 2 * sum(r * c for r, c, _ in names.values())
+  offs = sorted((o, r * c) for r, c, o in names.values())
+  assert all(a + na <= b for (a, na), (b, _) in zip(offs, offs[1:]))        # leaves do not overlap
   assert lib.nrf_destroy(h) == 0

@@ -175,3 +175,8 @@ def test_every_reference_preset_parses(monkeypatch):
       assert schedules.from_config(getattr(t, name))(1000) >= 0
     if f in expect:
       assert (m.num_coarse_samples, m.num_fine_samples, t.batch_size, m.num_warp_freqs) == expect[f], f
+    # every preset's model is accepted by the HIP library (nrf_create is host-only) and reports its own leaf shapes
+    from nerfies_amd import models
+    model, fp = models.construct_nerf(0, m, t.batch_size, [0, 1, 2], [0, 1], [0, 1, 2], 0.1, 1.0, device='cpu')
+    k = fp['nerf_mlps_fine']['MLP_0']['hidden_4']['kernel']
+    assert k.shape == (m.nerf_trunk_width + 3 + 6 * m.num_nerf_point_freqs, m.nerf_trunk_width), f

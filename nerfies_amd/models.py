@@ -245,7 +245,8 @@ class NerfModel:
     if metadata_encoded:
       raise L.NrfError('metadata_encoded=True is not built yet')
     if return_warp_jacobian or self.use_warp_jacobian:
-      raise L.NrfError('warp Jacobian (elastic regulariser, SURVEY 8f rank 1) is not built yet')
+      raise L.NrfError('the warp Jacobian is not returned as an output: the elastic regulariser consumes it inside the '
+                       'library (loss_and_grad(..., elastic=...) -> nrf_train_step_loss_grad_ex)')
     warp_on = bool(self.use_warp and use_warp)
     if return_points and not warp_on:
       raise L.NrfError('return_points is only built together with the warp field')

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 100 /* 0.1.0 */
+#define NRF_VERSION 101 /* 0.1.1: nrf_model_desc.warp_field_type, nrf_camera_* */
 
 enum {
   NRF_OK = 0,
@@ -41,6 +41,7 @@ enum {
 };
 
 enum { NRF_ACT_RELU = 0, NRF_ACT_SOFTPLUS = 1 };
+enum { NRF_WARP_SE3 = 0, NRF_WARP_TRANSLATION = 1 };   /* ModelConfig.warp_field_type (configs.py:99-100) */
 
 /* Every NerfModel attribute that reaches the hot path (models.py:75-119), as
  * POD.  Defaults are those of configs.ModelConfig (configs.py:35-105). */
@@ -77,6 +78,8 @@ typedef struct nrf_model_desc {
   int32_t num_warp_freqs;
   int32_t num_warp_embeddings;
   int32_t num_warp_features;
+  int32_t warp_field_type;         /* NRF_WARP_SE3 (warping.py:202-389, every preset) or NRF_WARP_TRANSLATION
+                                      (warping.py:62-199, the dataclass default): leaves warp_field/mlp/... */
 } nrf_model_desc;
 
 typedef struct nrf_handle_s* nrf_handle;

@@ -148,8 +148,10 @@ namespace {
 
 // Appends a leaf to the internal layout (rows x cols = what the kernels index) and to the external one
 // (xrows x xcols = what the model owns; defaults to the same).  External rows >= split sit `shift` rows lower inside.
+// xname: the leaf's path in the caller's tree when it differs from the internal one; "" = internal only (no external
+// leaf: stays zero in the padded image, its gradient is dropped).
 void add_leaf(nrf_handle h, const std::string& name, int rows, int cols, int64_t* off_out, int xrows = -1, int xcols = -1,
-              int split = -1, int64_t* xoff_out = nullptr) {
+              int split = -1, int64_t* xoff_out = nullptr, const char* xname = nullptr) {
   if (xrows < 0) xrows = rows;
   if (xcols < 0) xcols = cols;
   nrf_tensor_info t;
@@ -162,7 +164,9 @@ void add_leaf(nrf_handle h, const std::string& name, int rows, int cols, int64_t
   h->nparams += (int64_t)rows * cols;
   h->nparams = (int64_t)align_up((size_t)h->nparams, 4);   // keep every leaf 16-byte aligned
   h->layout.push_back(t);
+  if (xname && !*xname) { h->embed = true; return; }
   nrf_tensor_info x = t;
+  if (xname) { snprintf(x.name, sizeof(x.name), "%s", xname); h->embed = true; }
   x.offset = h->xnparams;
   x.rows = xrows;
   x.cols = xcols;
@@ -205,16 +209,24 @@ void build_layout(nrf_handle h) {
     WarpParamOffsets& x = h->xwpo;
     add_leaf(h, "warp_field/metadata_encoder/embed/embedding", d.num_warp_embeddings, d.num_warp_features, &w.embed, -1, -1, -1,
              &x.embed);
+    // TranslationField (warping.py:62-199) = the same 6x128 trunk with ONE 3-channel output layer and x' = x + t:
+    // exactly the SE3 field with a zero rotation head (theta = 0: R = I, p = v; the closed forms are series in
+    // theta^2 there).  Its leaves 'warp_field/mlp/hidden_i' / 'mlp/logit' map onto trunk / branches_v; branches_w
+    // exists only internally and stays zero.
+    const bool tr = d.warp_field_type == NRF_WARP_TRANSLATION;
     for (int i = 0; i < WARP_DEPTH; ++i) {
       int fin = i == 0 ? h->Win : WARP_W;
       if (i == WARP_SKIP) fin += h->Win;
-      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", fin, WARP_W, &w.trunk_k[i], -1, -1, -1, &x.trunk_k[i]);
-      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/bias", 1, WARP_W, &w.trunk_b[i], -1, -1, -1, &x.trunk_b[i]);
+      const std::string xk = "warp_field/mlp/hidden_" + std::to_string(i) + "/kernel", xb = "warp_field/mlp/hidden_" + std::to_string(i) + "/bias";
+      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", fin, WARP_W, &w.trunk_k[i], -1, -1, -1, &x.trunk_k[i],
+               tr ? xk.c_str() : nullptr);
+      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/bias", 1, WARP_W, &w.trunk_b[i], -1, -1, -1, &x.trunk_b[i],
+               tr ? xb.c_str() : nullptr);
     }
-    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k, -1, -1, -1, &x.w_k);
-    add_leaf(h, "warp_field/branches_w/logit/bias", 1, 3, &w.w_b, -1, -1, -1, &x.w_b);
-    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k, -1, -1, -1, &x.v_k);
-    add_leaf(h, "warp_field/branches_v/logit/bias", 1, 3, &w.v_b, -1, -1, -1, &x.v_b);
+    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k, -1, -1, -1, &x.w_k, tr ? "" : nullptr);
+    add_leaf(h, "warp_field/branches_w/logit/bias", 1, 3, &w.w_b, -1, -1, -1, &x.w_b, tr ? "" : nullptr);
+    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k, -1, -1, -1, &x.v_k, tr ? "warp_field/mlp/logit/kernel" : nullptr);
+    add_leaf(h, "warp_field/branches_v/logit/bias", 1, 3, &w.v_b, -1, -1, -1, &x.v_b, tr ? "warp_field/mlp/logit/bias" : nullptr);
   }
   if (d.use_appearance_metadata)
     add_leaf(h, "appearance_encoder/embed/embedding", d.num_appearance_embeddings, d.num_appearance_features, &h->app_off);
@@ -1029,6 +1041,7 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
     return fail(NRF_E_UNSUPPORTED, "rgb branch must be 1 layer of width <= 128");
   if (d.use_alpha_condition) return fail(NRF_E_UNSUPPORTED, "use_alpha_condition (alpha-branch conditioning) not built yet");
   if (d.use_warp) {
+    if (d.warp_field_type != NRF_WARP_SE3 && d.warp_field_type != NRF_WARP_TRANSLATION) return fail(NRF_E_UNSUPPORTED, "warp_field_type");
     if (d.num_warp_freqs < 0 || d.num_warp_freqs > 8) return fail(NRF_E_SHAPE, "num_warp_freqs must be in [0,8]");
     if (d.num_warp_features < 1 || d.num_warp_features > 8) return fail(NRF_E_SHAPE, "num_warp_features must be in [1,8]");
     if (d.num_warp_embeddings < 1) return fail(NRF_E_SHAPE, "num_warp_embeddings must be positive");
@@ -1167,7 +1180,7 @@ int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32
 // field training.compute_background_loss applies, training.py:127-130).  Mini workspace:
 // [pack descriptors | packed trunk weights | padded output].
 namespace {
-struct WarpPointsPlan { size_t desc_f, wpk_f, out_f, ctr_f, total_f; int ntiles; };
+struct WarpPointsPlan { size_t desc_f, wpk_f, out_f, ctr_f, emb_f, ip_f, total_f; int ntiles; };
 WarpPointsPlan warp_points_plan(nrf_handle h, int n) {
   WarpPointsPlan q;
   q.ntiles = (n + TILE_ROWS - 1) / TILE_ROWS;
@@ -1177,6 +1190,11 @@ WarpPointsPlan warp_points_plan(nrf_handle h, int n) {
   q.wpk_f = take(h->wpk.total);
   q.out_f = take((size_t)q.ntiles * TILE_ROWS * 3);
   q.ctr_f = take(16);
+  q.emb_f = q.ip_f = 0;
+  if (h->d.warp_field_type == NRF_WARP_TRANSLATION) {   // no rotation head in the caller's tree: run on the padded image
+    q.emb_f = take((h->emb.size() + 1) * sizeof(EmbedDesc) / 4);
+    q.ip_f = take((size_t)h->nparams);
+  }
   q.total_f = o;
   return q;
 }
@@ -1200,9 +1218,19 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   if (workspace_bytes < q.total_f * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (nrf_warp_points_workspace_bytes)");
   float* ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
+  const bool padded = q.ip_f != 0;
+  if (padded) {
+    hipError_t e0 = hipMemcpyAsync(ws + q.emb_f, h->emb.data(), h->emb.size() * sizeof(EmbedDesc), hipMemcpyHostToDevice, st);
+    if (e0 != hipSuccess) return fail_hip(e0, "upload embed table");
+    e0 = hipMemsetAsync(ws + q.ip_f, 0, (size_t)h->nparams * sizeof(float), st);
+    if (e0 != hipSuccess) return fail_hip(e0, "zero padded params");
+    launch_embed(reinterpret_cast<const EmbedDesc*>(ws + q.emb_f), (int)h->emb.size(), params, ws + q.ip_f, true, st);
+    params = ws + q.ip_f;
+  }
+  const WarpParamOffsets& wo = padded ? h->wpo : h->xwpo;   // else the caller's buffer: external offsets
   if (h->wp_pack.empty() || h->wp_pack_base != (int64_t)q.wpk_f) {
     h->wp_pack.clear();
-    const WarpParamOffsets& w = h->xwpo;   // the caller's buffer: external offsets
+    const WarpParamOffsets& w = wo;
     const WarpPackOffsets& wk = h->wpk;
     auto addw = [&](int64_t src, int dst, int row0, int kvalid, int K) {
       PackDesc d;
@@ -1220,7 +1248,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   launch_pack(reinterpret_cast<const PackDesc*>(ws + q.desc_f), (int)h->wp_pack.size(), params, ws, st);
   WarpFwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.params = params; a.po = h->xwpo; a.wpk = ws + q.wpk_f; a.pk = h->wpk;
+  a.params = params; a.po = wo; a.wpk = ws + q.wpk_f; a.pk = h->wpk;
   a.points_in = points; a.point_ids = warp_ids; a.points_out = ws + q.out_f;
   a.S = 1; a.B = num_points; a.rows = num_points; a.ntiles = q.ntiles;
   a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha;

@@ -9,6 +9,7 @@ LIB_PATH = os.path.join(HERE, '_lib', 'libnerfies_amd.so')
 NRF_FLAG_TRAIN = 1
 NRF_FLAG_NO_WARP = 2
 ACT = {'relu': 0, 'softplus': 1}
+WARP_FIELD = {'se3': 0, 'translation': 1}
 
 
 class NrfError(RuntimeError):
@@ -29,7 +30,7 @@ class ModelDesc(C.Structure):
       ('num_camera_embeddings', C.c_int32), ('num_camera_features', C.c_int32),
       ('use_alpha_condition', C.c_int32), ('use_rgb_condition', C.c_int32), ('use_trunk_condition', C.c_int32),
       ('use_warp', C.c_int32), ('num_warp_freqs', C.c_int32), ('num_warp_embeddings', C.c_int32),
-      ('num_warp_features', C.c_int32),
+      ('num_warp_features', C.c_int32), ('warp_field_type', C.c_int32),
   ]
 
 

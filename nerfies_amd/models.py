@@ -145,14 +145,15 @@ class NerfModel:
     d.use_alpha_condition = int(self.use_alpha_condition)
     d.use_rgb_condition = int(self.use_rgb_condition)
     d.use_trunk_condition = int(self.use_trunk_condition)
-    if self.use_warp and self.warp_field_type != 'se3':
-      raise L.NrfError("only warp_field_type='se3' is built (every shipped preset uses it, warp_defaults.gin)")
+    if self.use_warp and self.warp_field_type not in L.WARP_FIELD:
+      raise L.NrfError(f"warp_field_type must be one of {sorted(L.WARP_FIELD)} (warping.py:36-44)")
     if self.use_warp and self.warp_metadata_encoder_type != 'glo':
       raise L.NrfError("only the 'glo' warp metadata encoder is built")
     d.use_warp = int(self.use_warp)
     d.num_warp_freqs = self.num_warp_freqs
     d.num_warp_embeddings = self.num_warp_embeddings if self.use_warp else 0
     d.num_warp_features = self.num_warp_features
+    d.warp_field_type = L.WARP_FIELD[self.warp_field_type] if self.use_warp else 0
     return d
 
   @property

@@ -88,7 +88,7 @@ def init_flat(layout: ParamLayout, seed: int, device) -> torch.Tensor:
   flat = torch.zeros(layout.total, dtype=torch.float32)
   for name, off, shape in layout.entries:
     n = math.prod(shape)
-    if name.startswith('warp_field/branches_') and name.endswith('/kernel'):
+    if (name.startswith('warp_field/branches_') and name.endswith('/kernel')) or name == 'warp_field/mlp/logit/kernel':
       flat[off:off + n] = torch.rand(n, generator=g) * 1e-4   # initializers.uniform(scale=1e-4), one-sided (warping.py:238-239)
     elif name.endswith('/kernel'):
       lim = math.sqrt(6.0 / (shape[0] + shape[1]))

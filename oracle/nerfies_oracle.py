@@ -184,9 +184,20 @@ def se3_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, alpha,
   return from_homogenous(warped)
 
 
+def translation_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, alpha,
+                     num_warp_freqs: int) -> Tensor:
+  """TranslationField.warp (warping.py:155-164): points + MLP([annealed posenc, code]); the MLP is 6 x 128 with the
+  skip at 4 and a 3-channel 'logit' output layer (warping.py:129-137)."""
+  points_embed = annealed_sinusoidal_encode(points, num_warp_freqs, alpha)
+  inputs = torch.cat([points_embed, metadata_embed], -1)
+  return points + mlp(p['mlp'], inputs, 6, (4,), True)
+
+
 def se3_field(p, points, metadata, warp_alpha, num_warp_freqs,
               return_jacobian=False, metadata_encoded=False):
-  """warping.py:355-389.  metadata: int ids (...,1)/(...) or encoded (...,G)."""
+  """warping.py:355-389 (SE3Field) and :166-199 (TranslationField; selected by the parameter tree: 'mlp' instead of
+  'trunk' + 'branches_*').  metadata: int ids (...,1)/(...) or encoded (...,G)."""
+  se3_warp = globals()['translation_warp' if 'mlp' in p else 'se3_warp']
   if metadata_encoded:
     embed = metadata
   else:
@@ -375,6 +386,7 @@ class ModelSpec:
     self.use_appearance_metadata = False
     self.use_camera_metadata = False
     self.use_warp = False
+    self.warp_field_type = 'se3'         # warp_defaults.gin; 'translation' = the ModelConfig dataclass default
     self.use_alpha_condition = False
     self.use_rgb_condition = False
     for k, v in kw.items():
@@ -463,13 +475,20 @@ def init_params(spec: ModelSpec, seed=0, trained_like=False, dtype=torch.float64
         fin += Ww
       trunk[f'hidden_{i}'] = dense_p(fin, 128)
     head_scale = 0.3 if trained_like else 1e-4
-    params['warp_field'] = {
-        'metadata_encoder': {'embed': {'embedding': torch.tensor(
-            rng.uniform(0, 0.05, size=(spec.num_warp_embeddings, spec.num_warp_features)), dtype=dtype)}},
-        'trunk': trunk,
-        'branches_w': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
-        'branches_v': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
-    }
+    if spec.warp_field_type == 'translation':     # warping.py:62-137: one MLP with a 3-channel output layer
+      params['warp_field'] = {
+          'metadata_encoder': {'embed': {'embedding': torch.tensor(
+              rng.uniform(0, 0.05, size=(spec.num_warp_embeddings, spec.num_warp_features)), dtype=dtype)}},
+          'mlp': dict(trunk, logit=dense_p(128, 3, rng.uniform(0, head_scale / 3, size=(128, 3)))),
+      }
+    else:
+      params['warp_field'] = {
+          'metadata_encoder': {'embed': {'embedding': torch.tensor(
+              rng.uniform(0, 0.05, size=(spec.num_warp_embeddings, spec.num_warp_features)), dtype=dtype)}},
+          'trunk': trunk,
+          'branches_w': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
+          'branches_v': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
+      }
   if spec.use_appearance_metadata:
     params['appearance_encoder'] = {'embed': {'embedding': torch.tensor(
         rng.uniform(0, 0.05, size=(spec.num_appearance_embeddings, spec.num_appearance_features)), dtype=dtype)}}

@@ -132,6 +132,18 @@ def se3_field():
   save('se3_field', **out)
 
 
+def translation_field():
+  """warping.TranslationField (the ModelConfig dataclass default warp_field_type) on the oracle's parameters."""
+  rng = np.random.default_rng(15)
+  spec = O.ModelSpec(use_warp=True, warp_field_type='translation', num_warp_freqs=5, num_warp_features=8, num_warp_embeddings=4)
+  wp = tree_np(O.init_params(spec, seed=16, trained_like=True))['warp_field']
+  field = ref_warping.TranslationField(num_freqs=5, num_embeddings=4, num_embedding_features=8)
+  pts = rng.uniform(-0.5, 0.5, (7, 3)); ids = rng.integers(0, 4, (7, 1))
+  outs = [field.apply({'params': wp}, pts[i], ids[i], {'alpha': 3.25, 'time_alpha': 0.0}, True, False) for i in range(7)]
+  save('translation_field', points=pts, ids=ids, alpha=3.25, warped=np.stack([o['warped_points'] for o in outs]),
+       jacobian_fd=np.stack([o['jacobian'] for o in outs]))
+
+
 NERF_CASES = {
     'nowarp': (dict(num_coarse_samples=10, num_fine_samples=7, num_nerf_point_freqs=6, use_stratified_sampling=True), 0.0),
     'camera': (dict(num_coarse_samples=8, num_fine_samples=8, num_nerf_point_freqs=4, use_stratified_sampling=False,
@@ -236,6 +248,7 @@ if __name__ == '__main__':
   model_utils()
   encoders_and_mlps()
   se3_field()
+  translation_field()
   nerf_model()
   losses_and_schedules()
   cameras()

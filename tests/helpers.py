@@ -21,7 +21,7 @@ def config_from_spec(spec):
       use_appearance_metadata=spec.use_appearance_metadata, use_camera_metadata=spec.use_camera_metadata,
       appearance_metadata_dims=spec.num_appearance_features, camera_metadata_dims=spec.num_camera_features,
       use_warp=spec.use_warp, num_warp_freqs=spec.num_warp_freqs, num_warp_features=spec.num_warp_features,
-      warp_field_type='se3', use_alpha_condition=spec.use_alpha_condition, use_rgb_condition=spec.use_rgb_condition)
+      warp_field_type=spec.warp_field_type, use_alpha_condition=spec.use_alpha_condition, use_rgb_condition=spec.use_rgb_condition)
 
 
 def gpu_model(spec, oparams, batch_size=0):

@@ -314,7 +314,8 @@ def _make_warp(B, seed=0, alpha=3.5, **kw):
 # (configs/test_vrig.gin trains a 128-wide trunk)
 @pytest.mark.parametrize('kw', [dict(), dict(num_warp_freqs=6, num_warp_features=3), dict(num_warp_freqs=4),
                                 dict(nerf_trunk_width=128, use_camera_metadata=True),
-                                dict(nerf_trunk_width=72, nerf_rgb_branch_width=40, num_warp_freqs=5)])
+                                dict(nerf_trunk_width=72, nerf_rgb_branch_width=40, num_warp_freqs=5),
+                                dict(warp_field_type='translation'), dict(warp_field_type='translation', num_warp_freqs=5, nerf_trunk_width=128)])
 def test_warp_forward_parity(kw):
   spec, model, fp, gb, p64, b64, alpha = _make_warp(7, **kw)
   out = model.apply({'params': fp}, gb, {'alpha': alpha}, return_points=True, return_weights=True)
@@ -355,7 +356,9 @@ def test_warp_can_be_disabled_per_call():
                                        (dict(num_nerf_point_freqs=3, num_warp_features=3, use_stratified_sampling=True), 1.25),
                                        (dict(num_nerf_point_freqs=2, num_coarse_samples=48, num_fine_samples=80), 8.0),
                                        (dict(num_nerf_point_freqs=3, nerf_trunk_width=128, use_camera_metadata=True), 3.5),
-                                       (dict(num_nerf_point_freqs=2, nerf_trunk_width=72, nerf_rgb_branch_width=40), 2.0)])
+                                       (dict(num_nerf_point_freqs=2, nerf_trunk_width=72, nerf_rgb_branch_width=40), 2.0),
+                                       (dict(num_nerf_point_freqs=3, warp_field_type='translation'), 3.5),
+                                       (dict(num_nerf_point_freqs=2, warp_field_type='translation', num_warp_freqs=6, use_camera_metadata=True), 6.0)])
 def test_warp_loss_and_grad_parity(kw, alpha):
   """Gradients of every leaf (NeRF MLPs, SE3 trunk + heads, GLO tables) with the warp on.  Low NeRF
   posenc frequencies keep the fp32 rounding of the warped points from being amplified into ReLU
@@ -395,7 +398,7 @@ def test_warp_loss_and_grad_parity(kw, alpha):
     assert min(err64, err32) < 2e-3, (path, err64, err32, scale)
   assert n64 > 0   # heads above the first flipped layer agree with fp64 directly
   # the warp leaves must actually carry gradient (both passes feed the shared field)
-  assert got['warp_field']['trunk']['hidden_0']['kernel'].abs().max().item() > 0
+  assert got['warp_field']['mlp' if spec.warp_field_type == 'translation' else 'trunk']['hidden_0']['kernel'].abs().max().item() > 0
   assert got['warp_field']['metadata_encoder']['embed']['embedding'].abs().max().item() > 0
 
 
@@ -414,7 +417,7 @@ def test_warp_train_step_runs_and_reduces_loss():
 # ---------------------------------------------------------------------------------------------
 # background regulariser + stand-alone warp (training.py:117-135; models.py:165-184)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize('kw', [dict(), dict(nerf_trunk_width=128)])
+@pytest.mark.parametrize('kw', [dict(), dict(nerf_trunk_width=128), dict(warp_field_type='translation')])
 def test_warp_points_matches_oracle(kw):
   spec, model, fp, gb, p64, b64, alpha = _make_warp(3, num_warp_freqs=6, **kw)
   g = torch.Generator().manual_seed(0)
@@ -426,10 +429,10 @@ def test_warp_points_matches_oracle(kw):
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), atol=2e-6)
 
 
-@pytest.mark.parametrize('nbg,weight', [(100, 1.0), (300, 0.25)])
-def test_background_loss_and_grad_parity(nbg, weight):
+@pytest.mark.parametrize('nbg,weight,kw', [(100, 1.0, {}), (300, 0.25, {}), (100, 1.0, dict(warp_field_type='translation'))])
+def test_background_loss_and_grad_parity(nbg, weight, kw):
   from nerfies_amd import params as P
-  spec, model, fp, gb, p64, b64, alpha = _make_warp(6, seed=5, num_nerf_point_freqs=3)
+  spec, model, fp, gb, p64, b64, alpha = _make_warp(6, seed=5, num_nerf_point_freqs=3, **kw)
   g = torch.Generator().manual_seed(1)
   pts = ((torch.rand(nbg, 3, generator=g) - 0.5) * 0.8).double()
   ids = torch.randint(0, 4, (nbg, 1), generator=g)
@@ -503,7 +506,8 @@ def test_graphed_chunk_renderer_matches_direct_apply():
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize('kw,alpha,weight,method', [(dict(num_nerf_point_freqs=2), 3.5, 0.01, 'weight'),
                                                      (dict(num_nerf_point_freqs=3, num_warp_freqs=6), 6.0, 0.001, 'weight'),
-                                                     (dict(num_nerf_point_freqs=2, num_coarse_samples=48), 8.0, 0.01, 'median')])
+                                                     (dict(num_nerf_point_freqs=2, num_coarse_samples=48), 8.0, 0.01, 'median'),
+                                                     (dict(num_nerf_point_freqs=2, warp_field_type='translation'), 3.5, 0.01, 'weight')])
 def test_elastic_loss_and_grad_parity(kw, alpha, weight, method):
   from nerfies_amd import params as P
   spec, model, fp, gb, p64, b64, _ = _make_warp(5, seed=11, **kw)

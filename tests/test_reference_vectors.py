@@ -94,6 +94,18 @@ def test_se3_field_and_jacobian():
   close(out['jacobian'], r['jacobian_fd'], 2e-6)   # reference side: central differences of ITS warp (jax.jacfwd in the original)
 
 
+def test_translation_field_and_jacobian():
+  """warping.TranslationField (warping.py:62-199), run by the reference on the oracle's parameter tree."""
+  r = ref('translation_field')
+  spec = O.ModelSpec(use_warp=True, warp_field_type='translation', num_warp_freqs=5, num_warp_features=8, num_warp_embeddings=4)
+  wp = O.init_params(spec, seed=16, trained_like=True)['warp_field']
+  assert set(wp) == {'metadata_encoder', 'mlp'} and set(wp['mlp']) == {f'hidden_{i}' for i in range(6)} | {'logit'}
+  out = O.se3_field(wp, T(r['points']), torch.tensor(r['ids']), float(r['alpha']), 5, return_jacobian=True)
+  close(out['warped_points'], r['warped'], 1e-10)
+  close(out['jacobian'], r['jacobian_fd'], 2e-6)
+  assert (out['warped_points'] - T(r['points'])).abs().max() > 1e-3      # the field actually moves the points
+
+
 @pytest.mark.parametrize('name', ['nowarp', 'camera', 'warp'])
 def test_nerf_model_apply_end_to_end(name):
   import sys

@@ -210,10 +210,18 @@ def main():
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  # Debug hooks for exercising the N>1 code path on a ONE-GPU box (never set by the driver): BENCH_DIST_BACKEND=gloo
+  # swaps RCCL for gloo, BENCH_SAME_DEVICE=1 puts every rank on cuda:0 (RCCL refuses two ranks on one device).
+  backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+  if os.environ.get('BENCH_SAME_DEVICE'):
+    local_rank = 0
   if world > 1:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     torch.cuda.set_device(local_rank)
-    dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    else:
+      dist.init_process_group(backend)
   elif args.gpus > 1:
     raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
   dev = torch.device('cuda', local_rank if world > 1 else 0)

@@ -4,7 +4,8 @@ path in chunks (hipGraph-captured forward, rays generated on the GPU), writes rg
 
   python eval.py --base_folder EXP --data_dir CAPTURE --gin_configs EXP/config.gin [--gin_bindings "EvalConfig.eval_once = True"]
 
-Multiscale SSIM (tf.image.ssim_multiscale in the reference) is not built."""
+Multiscale SSIM is reported for frames of at least 176 px per side (five scales), from a restatement of
+tf.image.ssim_multiscale's published algorithm (nerfies_amd/evaluation.py)."""
 import functools
 import os
 import shutil
@@ -36,8 +37,8 @@ def process_batch(*, batch, rng, state, tag, item_id, step, writer, render_fn, s
   out = {}
   if 'rgb' in batch:
     m = evaluation.image_metrics(render['rgb'], batch['rgb'])
-    out = {'mse': float(m['mse']), 'psnr': float(m['psnr'])}
-    print(f'\t[{tag}] {item_id}: mse={out["mse"]:.04f}, psnr={out["psnr"]:.02f}', flush=True)
+    out = {k: float(v) for k, v in m.items()}
+    print(f'\t[{tag}] {item_id}: ' + ', '.join(f'{k}={v:.04f}' for k, v in out.items()), flush=True)
   return out
 
 

@@ -121,8 +121,56 @@ def compute_psnr(mse):
   return -10.0 * torch.log10(torch.as_tensor(mse))
 
 
+_MSSSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def compute_multiscale_ssim(image1: torch.Tensor, image2: torch.Tensor, max_val: float = 1.0, filter_size: int = 11,
+                            filter_sigma: float = 1.5, k1: float = 0.01, k2: float = 0.03) -> torch.Tensor:
+  """MS-SSIM of two [H, W, C] images (eval.py:60-62 calls tf.image.ssim_multiscale(image1, image2, max_val=1.0)).
+
+  TensorFlow is a third-party dependency that is absent here, so its published algorithm (Wang, Simoncelli & Bovik 2003,
+  with TF's defaults) is restated and is UNPINNED against TF itself: per channel, 5 scales; at each scale an
+  11x11 sigma-1.5 Gaussian window (VALID) gives the local means / variances / covariance, the contrast-structure term
+  cs = (2 s12 + c2) / (s1 + s2 + c2) and the full ssim = cs * (2 m1 m2 + c1) / (m1^2 + m2^2 + c1) are averaged over
+  the window positions; images are halved by 2x2 average pooling between scales (odd sizes padded symmetrically);
+  result = prod_i relu(cs_i)^w_i over the first 4 scales times relu(ssim_5)^w_5, averaged over channels.  Needs
+  H, W >= 11 * 2^4 = 176."""
+  x = image1.to(torch.float32).permute(2, 0, 1)[None]
+  y = image2.to(x.device, torch.float32).permute(2, 0, 1)[None]
+  c = x.shape[1]
+  if min(x.shape[-2:]) < filter_size * 2 ** (len(_MSSSIM_WEIGHTS) - 1):
+    raise ValueError(f'MS-SSIM needs images of at least {filter_size * 2 ** (len(_MSSSIM_WEIGHTS) - 1)} px per side')
+  r = torch.arange(filter_size, dtype=torch.float32, device=x.device) - (filter_size - 1) / 2
+  g = torch.exp(-0.5 * (r / filter_sigma) ** 2)
+  g = g / g.sum()
+  win = (g[:, None] * g[None, :])[None, None].repeat(c, 1, 1, 1)
+  blur = lambda t: torch.nn.functional.conv2d(t, win, groups=c)
+  c1, c2 = (k1 * max_val) ** 2, (k2 * max_val) ** 2
+  terms = []
+  for i, w in enumerate(_MSSSIM_WEIGHTS):
+    if i:
+      ph, pw = x.shape[-2] % 2, x.shape[-1] % 2
+      if ph or pw:
+        x = torch.nn.functional.pad(x, (0, pw, 0, ph), mode='replicate')     # symmetric padding of one pixel
+        y = torch.nn.functional.pad(y, (0, pw, 0, ph), mode='replicate')
+      x = torch.nn.functional.avg_pool2d(x, 2)
+      y = torch.nn.functional.avg_pool2d(y, 2)
+    m1, m2 = blur(x), blur(y)
+    num0, den0 = m1 * m2 * 2.0, m1 * m1 + m2 * m2
+    cs = (blur(x * y) * 2.0 - num0 + c2) / (blur(x * x + y * y) - den0 + c2)
+    if i + 1 < len(_MSSSIM_WEIGHTS):
+      terms.append(torch.relu(cs.mean(dim=(-2, -1))) ** w)
+    else:
+      terms.append(torch.relu((cs * (num0 + c1) / (den0 + c1)).mean(dim=(-2, -1))) ** w)
+  return torch.stack(terms, 0).prod(0).mean()
+
+
 def image_metrics(rgb: torch.Tensor, target: torch.Tensor) -> Dict[str, torch.Tensor]:
-  """mse / psnr of a rendered frame against its target (eval.py:121-125).  The multiscale SSIM of eval.py:60-62 is
-  tf.image.ssim_multiscale, a third-party routine outside this path: not rebuilt."""
-  mse = ((rgb - target.to(rgb.device)) ** 2).mean()
-  return {'mse': mse, 'psnr': compute_psnr(mse)}
+  """mse / psnr (/ multiscale ssim when the frame is large enough for 5 scales) of a rendered frame against its
+  target (eval.py:121-128)."""
+  target = target.to(rgb.device)
+  mse = ((rgb - target) ** 2).mean()
+  out = {'mse': mse, 'psnr': compute_psnr(mse)}
+  if min(rgb.shape[:2]) >= 176:
+    out['ssim'] = compute_multiscale_ssim(target, rgb)
+  return out

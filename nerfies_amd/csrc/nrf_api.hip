@@ -33,7 +33,6 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct LevelWs {   // float offsets from the workspace base, per level (0 = coarse, 1 = fine)
   size_t wpk, z, out4, rgb, depth, med, acc, weights, condterm;
-  size_t rc_wpk = 0;   // weight panels of the register-resident forward (inference plans, NRF_REGCHAIN)
   size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
   // SE3 warp field (per level: the field is evaluated on the coarse and on the fine samples)
@@ -48,10 +47,7 @@ struct WsPlan {
   int S[4], rows[4], ntiles[4];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
   size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b, emb_off_b;
-  size_t iparams = 0, igrad = 0;
-  size_t rc_desc = 0;
-  std::vector<RcPackDesc> rcpack;
-  RcOffsets rc;   // zero-padded parameter image / its gradient (models narrower than the kernels)
+  size_t iparams = 0, igrad = 0;   // zero-padded parameter image / its gradient (models narrower than the kernels)
   std::vector<WgradSegment> segs;
   std::vector<int> seg_begin;
   int wgrad_nwg = 0;
@@ -436,48 +432,6 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     p.iparams = take((size_t)h->nparams);
     if (train) p.igrad = take((size_t)h->nparams);
   }
-  static const bool regchain = getenv("NRF_REGCHAIN") != nullptr;
-  if (regchain && !train) {   // register-resident forward: panels [tg][o][lane] float4, one padding group each
-    // stream layout in execution order: per GEMM [bias group] + 4 NIN weight groups of NOUT KiB per lane-row
-    p.rcpack.clear();
-    size_t stream_floats = 0;
-    for (int pass = 0; pass < 2; ++pass) {          // pass 0 sizes the stream, pass 1 emits descriptors per level
-      for (int lv = 0; lv < (pass ? h->nlevels : 1); ++lv) {
-        if (pass) p.L[lv].rc_wpk = take(stream_floats + 9 * 256);   // + one group of slack for the wrap-around prefetch
-        const MlpParamOffsets& po = h->po[lv];
-        size_t at = 0;                                // floats from the level's stream base
-        auto emit = [&](int kind, int64_t src, int ld, int row0, int krows, int ncols, int ngroups, int nout, int npanel, int o0) {
-          if (!pass) return;
-          RcPackDesc e;
-          e.src_off = src; e.dst_off = (long long)(p.L[lv].rc_wpk + at); e.kind = kind; e.src_ld = ld; e.row0 = row0; e.krows = krows;
-          e.ncols = ncols; e.ngroups = ngroups; e.nout = nout; e.nout_panel = npanel; e.o0 = o0;
-          p.rcpack.push_back(e);
-        };
-        auto gemm = [&](int64_t wk, int ld, int row0, int krows, int ncols, int nin, int nout, int64_t bias) {
-          if (bias >= 0) { emit(1, bias, 0, 0, 0, ncols, 1, nout, nout, 0); at += (size_t)nout * 256; }
-          emit(0, wk, ld, row0, krows, ncols, nin * 4, nout, nout, 0);
-          at += (size_t)nin * 4 * nout * 256;
-        };
-        gemm(po.trunk_k[0], TRUNK_W, 0, h->P, TRUNK_W, 2, 8, po.trunk_b[0]);
-        for (int l = 1; l < TRUNK_DEPTH; ++l) {
-          gemm(po.trunk_k[l], TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, po.trunk_b[l]);
-          if (l == SKIP_LAYER) gemm(po.trunk_k[l], TRUNK_W, TRUNK_W, h->P, TRUNK_W, 2, 8, -1);
-        }
-        // bottleneck (8 blocks) + alpha head (block 8) share one 9-wide GEMM
-        emit(1, po.bn_b, 0, 0, 0, TRUNK_W, 1, 8, 9, 0);
-        emit(1, po.alpha_b, 0, 0, 0, 1, 1, 1, 9, 8);
-        at += 9 * 256;
-        emit(0, po.bn_k, TRUNK_W, 0, TRUNK_W, TRUNK_W, 32, 8, 9, 0);
-        emit(0, po.alpha_k, 1, 0, TRUNK_W, 1, 32, 1, 9, 8);
-        at += (size_t)32 * 9 * 256;
-        gemm(po.rgbh_k, RGB_W, 0, TRUNK_W, RGB_W, 8, 4, -1);
-        gemm(po.logit_k, 3, 0, RGB_W, 3, 4, 1, po.logit_b);
-        stream_floats = at;
-      }
-    }
-    p.rc.total = (int)(stream_floats + 9 * 256);
-    p.rc_desc = take(p.rcpack.size() * sizeof(RcPackDesc) / 4 + 16);
-  }
 
   auto alloc_warp = [&](LevelWs& L, size_t nt) {
     L.wpoints = take(nt * TILE_ROWS * 3);
@@ -688,10 +642,6 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
     e = hipMemcpyAsync(base + p.segbegin_off_b, p.seg_begin.data(), p.seg_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload wgrad segment index");
   }
-  if (!p.rcpack.empty()) {
-    e = hipMemcpyAsync(ws + p.rc_desc, p.rcpack.data(), p.rcpack.size() * sizeof(RcPackDesc), hipMemcpyHostToDevice, stream);
-    if (e != hipSuccess) return fail_hip(e, "upload regchain pack table");
-  }
   if (h->embed) {
     e = hipMemcpyAsync(base + p.emb_off_b, h->emb.data(), h->emb.size() * sizeof(EmbedDesc), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload embed table");
@@ -831,8 +781,6 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   Prof& pf = h->prof;
   pf.begin("pack_prep_sample", 0, stream);
   launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
-  const bool regchain = !train && !p.rcpack.empty();
-  if (regchain) launch_rc_pack(reinterpret_cast<const RcPackDesc*>(ws + p.rc_desc), (int)p.rcpack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
   launch_ray_prep(params, viewdirs, rays->appearance_ids, rays->camera_ids, B, d.num_nerf_viewdir_freqs, d.use_viewdirs,
                   h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
@@ -874,13 +822,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       }
     }
     pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
-    if (regchain) {   // register-resident chain: one wave per SIMD, 32 samples per wave
-      a.wpk = ws + L.rc_wpk; a.rc = p.rc;
-      const int ngrp = (p.rows[lv] + 127) / 128;
-      launch_chain_fwd_reg(a, ngrp < h->num_cus ? ngrp : h->num_cus, stream);
-    } else {
-      launch_chain_fwd(a, train, grid, stream);
-    }
+    launch_chain_fwd(a, train, grid, stream);
     pf.end(stream);
     pf.begin("composite_fwd", 0, stream);
     launch_composite_fwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],

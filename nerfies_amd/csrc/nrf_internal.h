@@ -61,20 +61,9 @@ struct WarpPackOffsets {
   int total;
 };
 
-// Register-resident forward chain (mlp_regchain.hip): float offsets of the weight panels in its pack buffer.
-struct RcOffsets { int total; };   // the weight stream is consumed sequentially: only its length is needed
-struct RcPackDesc {
-  long long src_off, dst_off;   // params leaf / first group written, in floats from the workspace base
-  int kind;                     // 0: weight groups, 1: bias group
-  int src_ld, row0, krows, ncols;   // leaf column count, first row, valid rows (K) and columns
-  int ngroups, nout, nout_panel, o0;   // groups written, output blocks written, stream width, first output block
-};
-void launch_rc_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream);
-
 struct ChainFwdArgs {
   const float* params;       // flat canonical parameters
   MlpParamOffsets po;
-  RcOffsets rc;              // (register-resident kernel only; wpk then points at its pack buffer)
   const float* wpk;          // packed weights of this MLP
   PackOffsets pk;
   const float* condterm;     // [B][128]: rgb-branch per-ray term incl. bias
@@ -285,7 +274,6 @@ struct EmbedDesc {
   long long ext_off, int_off;
   int rows, ext_cols, int_cols, split, shift, pad_;
 };
-void launch_chain_fwd_reg(const struct ChainFwdArgs& a, int grid, hipStream_t stream);
 void launch_embed(const EmbedDesc* descs, int ndesc, const float* src, float* dst, bool to_internal, hipStream_t stream);
 
 // camera.hip -- Camera.pixels_to_rays / pixels_to_points / project (nerfies/camera.py)

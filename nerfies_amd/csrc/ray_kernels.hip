@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(
   for (int jx = lane; jx < Nf; jx += 64) {
     float u;
     if (stratified) u = u_in ? u_in[(size_t)ray * Nf + jx] : philox_uniform(seed, offset, 1u, (uint32_t)(ray * Nf + jx));
-    else u = (jx == Nf - 1) ? 1.0f : (float)jx / (float)(Nf - 1);
+    else u = Nf == 1 ? 0.0f : (jx == Nf - 1) ? 1.0f : (float)jx / (float)(Nf - 1);   // linspace(0, 1, Nf); Nf = 1 -> [0]
     int lo_i = 0, hi_i = n;   // idx = #{i : cdf_i <= u}
     while (lo_i < hi_i) { const int mid = (lo_i + hi_i) >> 1; if (cdf[mid] <= u) lo_i = mid + 1; else hi_i = mid; }
     const int idx = lo_i;

@@ -118,7 +118,7 @@ def test_volumetric_rendering(S, white, inf):
     assert ((cum - 0.5).abs().min(-1).values[bad] < 1e-5).all()
 
 
-@pytest.mark.parametrize('Nc,Nf', [(64, 128), (128, 128), (3, 5), (256, 256), (65, 31)])
+@pytest.mark.parametrize('Nc,Nf', [(64, 128), (128, 128), (3, 5), (256, 256), (65, 31), (16, 1), (3, 1)])
 @pytest.mark.parametrize('stratified', [0, 1])
 def test_sample_pdf(Nc, Nf, stratified):
   L, lib = _lib()

@@ -31,7 +31,7 @@ def _case(i):
   return kw, B, float(rng.uniform(0, 8))
 
 
-@pytest.mark.parametrize('i', range(24))
+@pytest.mark.parametrize('i', range(int(__import__('os').environ.get('SWEEP_FROM', 0)), int(__import__('os').environ.get('SWEEP_TO', 24))))
 def test_random_configuration(i):
   kw, B, alpha = _case(i)
   spec = O.ModelSpec(**kw)

@@ -377,11 +377,12 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   // measured with scripts/wgrad_calib.py (per-segment wall clocks, least squares), relative to a 256x256 tile
   const double c_vec256 = env_cost("NRF_COST_VEC256", 0.157), c_vec128 = env_cost("NRF_COST_VEC128", 0.121),
                c_pe = env_cost("NRF_COST_PE", 0.335), c_rgbh = env_cost("NRF_COST_RGBH", 0.571),
+               c_pe128 = env_cost("NRF_COST_PE128", 0.201),   // SE3 trunk input rows: 64 x 128 (scripts/wgrad_calib_vrig.py)
                c_seg = env_cost("NRF_COST_SEG", 0.5);   // fixed cost of opening a segment (pipeline fill + slab flush), in tiles
   auto tile_cost = [&](const GroupSpec& sp) -> double {
     if (sp.Nb == 0) return sp.Kb == 8 ? c_vec256 : c_vec128;   // vector columns only (VALU + HBM stream)
     const double mm = (double)sp.Kb * sp.Nb / 64.0;
-    return mm < 0.3 ? c_pe : (mm < 0.6 ? c_rgbh : 1.0);
+    return mm < 0.2 ? c_pe128 : mm < 0.3 ? c_pe : (mm < 0.6 ? c_rgbh : 1.0);
   };
   std::vector<int> nsplit(specs.size(), 0);
   if (!specs.empty()) {

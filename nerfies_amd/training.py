@@ -37,7 +37,11 @@ class Optimizer:
     self.target = target
     self.m = torch.zeros_like(target.flat)
     self.v = torch.zeros_like(target.flat)
-    self.grad = torch.zeros_like(target.flat)
+    # gradient + the 8 step statistics in ONE buffer: a single all-reduce per step carries both (training.py:266-267)
+    n = target.flat.numel()
+    self._gs = torch.zeros(n + 8, dtype=torch.float32, device=target.flat.device)
+    self.grad = self._gs[:n]
+    self.stats = self._gs[n:]
     self.step = 0
     self.beta1, self.beta2, self.eps = beta1, beta2, eps
 
@@ -73,15 +77,18 @@ def _world():
   return 1
 
 
-def psum_gradients(grad: torch.Tensor, stats: torch.Tensor):
-  """lax.pmean(grad) / lax.pmean(stats) (training.py:266-267) over the ray shards: ONE all-reduce of
-  the flat gradient buffer (RCCL over xGMI on GPUs, gloo in the CPU tests) plus one of the 8 stats.
+def psum_gradients(grad: torch.Tensor, stats: torch.Tensor, fused: Optional[torch.Tensor] = None):
+  """lax.pmean(grad) / lax.pmean(stats) (training.py:266-267) over the ray shards.  `fused`: the buffer both are views
+  of (Optimizer._gs) -> ONE all-reduce (RCCL over xGMI on GPUs, gloo in the CPU tests); otherwise one each.
   The gradient is left as the SUM -- the 1/world factor is folded into the Adam kernel
   (`grad_scale`) -- and the stats are returned averaged.  Returns (grad, stats, world)."""
   n = _world()
   if n > 1:
-    dist.all_reduce(grad, op=dist.ReduceOp.SUM)
-    dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+    if fused is not None:
+      dist.all_reduce(fused, op=dist.ReduceOp.SUM)
+    else:
+      dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+      dist.all_reduce(stats, op=dist.ReduceOp.SUM)
     stats = stats / n
   return grad, stats, n
 
@@ -110,10 +117,11 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
     noise = scalar_params.background_noise_std * torch.randn(pts.shape, generator=g, device=pts.device)
     background = {'points': pts + noise, 'warp_ids': ids, 'weight': scalar_params.background_loss_weight}
   grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
-                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad, background=background,
+                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad, stats_out=opt.stats,
+                                    background=background,
                                     elastic={'weight': scalar_params.elastic_loss_weight, 'reduce_method': elastic_reduce_method}
                                     if use_elastic_loss else None)
-  grad, stats, n = psum_gradients(grad, stats)
+  grad, stats, n = psum_gradients(grad, stats, fused=opt._gs)
   opt.apply_gradient(grad, learning_rate=scalar_params.learning_rate, grad_scale=1.0 / n)
   out = {
       'coarse': {'loss/rgb': stats[0], 'loss/total': stats[0], 'metric/psnr': stats[2]},

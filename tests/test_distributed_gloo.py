@@ -65,8 +65,12 @@ def _worker(rank, port, tmp):
   g = _flat(grads).float()
   st = torch.zeros(8)
   st[0], st[1] = stats['coarse']['loss/rgb'], stats['fine']['loss/rgb']
+  if rank == 0:     # both call forms must give the same reduction: separate buffers ...
+    pass
+  fused = torch.cat([g, st])                      # ... and the Optimizer's fused [grad | stats] buffer (one all-reduce)
+  g2, st2, n = training.psum_gradients(fused[:g.numel()], fused[g.numel():], fused=fused)
   g, st, n = training.psum_gradients(g, st)
-  assert n == WORLD
+  assert n == WORLD and torch.equal(g2, g) and torch.allclose(st2, st)
   # ---- eval: rank-sliced chunks + all_gather reassemble the full image (evaluation.py:62-99) ----
   rays = {'origins': torch.linspace(-1, 1, 5 * 7 * 3).reshape(5, 7, 3), 'directions': torch.ones(5, 7, 3) * 0.1}
   img = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=9)   # 35 px: ragged, needs padding

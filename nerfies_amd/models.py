@@ -147,6 +147,9 @@ class NerfModel:
     d.use_trunk_condition = int(self.use_trunk_condition)
     if self.use_warp and self.warp_field_type not in L.WARP_FIELD:
       raise L.NrfError(f"warp_field_type must be one of {sorted(L.WARP_FIELD)} (warping.py:36-44)")
+    if self.use_warp and dict(self.warp_kwargs or {}):
+      raise L.NrfError(f'warp_kwargs {dict(self.warp_kwargs)} are not supported: the warp kernels are built for the '
+                       'default field (6 x 128 trunk, skip at 4; warping.py:228-239)')
     if self.use_warp and self.warp_metadata_encoder_type != 'glo':
       raise L.NrfError("only the 'glo' warp metadata encoder is built")
     d.use_warp = int(self.use_warp)

@@ -129,10 +129,11 @@ def side_mode(args, world, rank, dev):
     n = 8192
     model, fp = models.construct_nerf(0, C, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
     rays = {k: v for k, v in synthetic_batch(n, 100 + rank, dev).items() if k != 'rgb'}
-    fn = evaluation.GraphedChunkRenderer(model)
+    bf16 = bool(os.environ.get('BENCH_BF16'))   # opt-in bfloat16-operand inference mode (never the default line)
+    fn = evaluation.GraphedChunkRenderer(model, bf16=bf16)
     step = lambda: fn(0, 1, fp, rays, {})
-    prof_step = lambda: model.apply({'params': fp}, rays, {})   # HIP events cannot be recorded inside a graph replay
-    per_step, name, flops = n, 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)', None
+    prof_step = lambda: model.apply({'params': fp}, rays, {}, bf16=bf16)   # HIP events cannot be recorded inside a graph replay
+    per_step, name, flops = n, 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [bf16 MLP operands]' if bf16 else ''), None
     workload = 'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, warp off, deterministic, forward only'
   else:
     class C(Cfg):

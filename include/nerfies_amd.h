@@ -143,6 +143,8 @@ typedef struct nrf_outputs {
 /* flags for nrf_forward / nrf_workspace_bytes */
 #define NRF_FLAG_TRAIN 1u   /* keep the activation stash nrf_backward needs */
 #define NRF_FLAG_NO_WARP 2u /* NerfModel.__call__(use_warp=False) (models.py:296) */
+#define NRF_FLAG_BF16 4u    /* inference only: NeRF-MLP operands in bfloat16 (fp32 accumulate, fp32 composite); an opt-in
+                               mode with no reference counterpart (BASELINE config D) -- ~1e-2 on rendered colour */
 
 int nrf_version(void);
 const char* nrf_last_error(void);

@@ -1,0 +1,315 @@
+// bf16-operand forward chain of the NeRF MLP (inference / rendering; BASELINE config D "bf16 MLP with fp32 composite").
+//
+// Opt-in mode (NRF_FLAG_BF16): activations and weights are rounded to bfloat16 (RNE) as MFMA operands, accumulation,
+// biases (hi + lo bf16 pair), the per-ray condition term, the activations' ReLU and everything outside the MLP
+// (sampling, compositing) stay fp32.  Not bit-comparable with the fp32 path: tests bound it at ~1e-2 on rendered colour.
+//
+// Dataflow: transposed GEMMs  H^T[feature][sample] = W^T . X^T  with v_mfma_f32_32x32x16_bf16; a wave owns 64 samples
+// (two 32-sample groups sharing every weight fragment) and ALL output features.  In the D layout lane (n, h) holds
+// feature 32o + 8j + 4h + i of sample n in accumulator register 4j+i; packed to bf16 pairs these are, for k-step
+// (b, s) of the next layer, exactly the B operand of lane (n, h) (k-slots 8h .. 8h+7 <-> features 32b + 8(2s+jj) + 4h + i,
+// slot e = 4jj + i) -- so activations stay in registers across layers (128 packed VGPRs).  Weights (A operand) are
+// packed in that K order, streamed global -> LDS by LDS-DMA in chunks of 4 k-steps (double buffered, one barrier per
+// chunk) and shared by the workgroup's four waves: 16 B/clk per wave of LDS reads at the MFMA peak.
+#include "chain_common.h"
+
+namespace nrf {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+namespace {
+
+constexpr int BF_BUF_BYTES = 5 * 9 * 1024;   // largest chunk: bias step + 4 k-steps of a 9-block GEMM
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  const bf16x2 p = __builtin_convertvector(v, bf16x2);
+  return __builtin_bit_cast(unsigned, p);
+}
+
+__device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
+  const u32x4v v = {a, b, c, d};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+struct BfStream {   // scalars only (kept in SGPRs / VGPRs by SROA)
+  const char* src;  // weight stream in global memory (this lane's byte address: base + lane * 16)
+  int soff;         // byte offset of the chunk currently in LDS
+  int cur;          // LDS buffer holding it
+};
+
+// Starts the LDS-DMA of `nbytes` (a multiple of 4 KiB) at stream offset `off` into buffer `buf`; piece p (1 KiB) is issued
+// by wave p % 4.
+__device__ __forceinline__ void bf_dma(const char* src_lane, int off, int nbytes, char* lds, int buf, int wave) {
+  const int npieces = nbytes >> 10;
+  for (int p = wave; p < npieces; p += 4)
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src_lane + off + p * 1024),
+                                     (lds_void_t*)(lds + buf * BF_BUF_BYTES + p * 1024), 16, 0, 0);
+}
+
+// acc[g][o] = sum over the NIN input blocks (+ bias), both sample groups.  Chunk 0 carries the bias k-step first when
+// BIAS.  The chunk that follows this GEMM's last one has NEXT_BYTES bytes (first chunk of the next GEMM; WRAP: of the
+// chain's first GEMM at offset 0).
+template <int NIN, int NOUT, bool BIAS, int NEXT_BYTES, bool WRAP = false, bool INIT = true>
+__device__ __forceinline__ void bf_gemm(f32x16 (&acc)[2][NOUT], const unsigned (&in)[2][NIN][8], BfStream& st, char* lds, int lane,
+                                        int wave) {
+  constexpr int NCHUNK = NIN / 2;   // 4 k-steps = 2 input blocks per chunk
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (INIT) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) acc[g][o] = zero;
+  }
+#pragma unroll
+  for (int c = 0; c < NCHUNK; ++c) {
+    const int this_bytes = (4 + (BIAS && c == 0 ? 1 : 0)) * NOUT * 1024;
+    const bool last = c == NCHUNK - 1;
+    const int next_off = (last && WRAP) ? 0 : st.soff + this_bytes;
+    bf_dma(st.src, next_off, last ? NEXT_BYTES : 4 * NOUT * 1024, lds, st.cur ^ 1, wave);
+    const char* wb = lds + st.cur * BF_BUF_BYTES + lane * 16;
+    constexpr int NB = BIAS ? 1 : 0;
+    const int nrows = 4 + ((BIAS && c == 0) ? 1 : 0);   // k-step rows of this chunk (bias row first)
+    // A fragments of row r+1 are read from LDS while row r is multiplied (two register sets)
+    bf16x8 af[2][NOUT];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) af[0][o] = *reinterpret_cast<const bf16x8*>(wb + o * 1024);
+#pragma unroll
+    for (int r = 0; r < 4 + NB; ++r) {
+      if (r < nrows) {
+        if (r + 1 < nrows) {
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) af[(r + 1) & 1][o] = *reinterpret_cast<const bf16x8*>(wb + ((r + 1) * NOUT + o) * 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool bias_row = BIAS && c == 0 && r == 0;
+        const int ks = r - (nrows - 4);            // k-step inside the chunk (bias row: -1)
+        const int b = 2 * c + ((ks < 0 ? 0 : ks) >> 1), s2 = (ks < 0 ? 0 : ks) & 1;
+        bf16x8 bop[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+          bop[g] = bias_row ? as_bf16x8(0x3F803F80u, 0u, 0u, 0u)   // B = 1 in k-slots 0, 1 (bias hi + lo)
+                            : as_bf16x8(in[g][b][4 * s2], in[g][b][4 * s2 + 1], in[g][b][4 * s2 + 2], in[g][b][4 * s2 + 3]);
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) acc[g][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r & 1][o], bop[g], acc[g][o], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next chunk has landed
+    __syncthreads();                      // ... everyone's has, and nobody still reads the buffer it will replace next
+    st.soff = next_off;
+    st.cur ^= 1;
+  }
+}
+
+// fp32 accumulators (+ optional ReLU) -> packed bf16 B operands: register pair (4j+i, 4j+i+1) -> packed 2j + i/2
+template <int NB, bool RELU>
+__device__ __forceinline__ void bf_pack(unsigned (&out)[2][NB][8], const f32x16 (&acc)[2][NB]) {
+#pragma unroll
+  for (int g = 0; g < 2; ++g)
+#pragma unroll
+    for (int o = 0; o < NB; ++o)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float a = acc[g][o][2 * q], b = acc[g][o][2 * q + 1];
+        if (RELU) { a = __builtin_amdgcn_fmed3f(a, 0.f, __builtin_inff()); b = __builtin_amdgcn_fmed3f(b, 0.f, __builtin_inff()); }
+        out[g][o][q] = pack_bf16(a, b);
+      }
+}
+
+__device__ __forceinline__ float bf_sigma(float x, int kind) {
+  return kind == 1 ? fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))) : fmaxf(x, 0.f);
+}
+
+// chunk-0 byte counts of each GEMM of the chain (what the GEMM before it prefetches)
+constexpr int BYTES_L0 = 5 * 8 * 1024, BYTES_TRUNK = 5 * 8 * 1024, BYTES_L4B = 4 * 8 * 1024, BYTES_BN = 5 * 9 * 1024,
+              BYTES_RGBH = 4 * 4 * 1024, BYTES_LOGIT = 5 * 1 * 1024;
+
+}  // namespace
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void nerf_mlp_fwd_bf16_kernel(const ChainFwdArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char bf_lds[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int niter = (A.rows + 255) / 256;   // 256 samples per workgroup iteration (4 waves x 2 groups x 32)
+
+  BfStream st;
+  st.src = reinterpret_cast<const char*>(A.wpk) + lane * 16;
+  st.soff = 0;
+  st.cur = 0;
+  bf_dma(st.src, 0, BYTES_L0, bf_lds, 0, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = blockIdx.x; it < niter; it += gridDim.x) {
+    int row[2];
+    float x[2][3];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      row[g] = it * 256 + wave * 64 + g * 32 + n;
+      const int r = row[g] < A.rows ? row[g] : A.rows - 1;
+      if (A.points) {
+        x[g][0] = A.points[3 * r]; x[g][1] = A.points[3 * r + 1]; x[g][2] = A.points[3 * r + 2];
+      } else {
+        const int ray = r / A.S;
+        const float z = A.zvals[r];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) x[g][c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
+      }
+    }
+    const float half_pi = 1.57079632679489661923f;
+    // SinusoidalEncoder (modules.py:213-228) in fp32, packed straight into B-operand registers
+    auto posenc = [&](unsigned (&pe)[2][2][8]) {
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            float v[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int r16 = 2 * q + t;                                  // accumulator-style register index 4j + i
+              const int e = 32 * b + 8 * (r16 >> 2) + 4 * h + (r16 & 3);   // posenc feature
+              float val = 0.f;
+              if (e < 3) {
+                val = e == 0 ? x[g][0] : e == 1 ? x[g][1] : x[g][2];
+              } else if (e < A.P) {
+                const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, c = rem >= 3 ? rem - 3 : rem;
+                const float a = __fmul_rn(c == 0 ? x[g][0] : c == 1 ? x[g][1] : x[g][2], (float)(1 << f));
+                val = sinf(rem >= 3 ? __fadd_rn(a, half_pi) : a);
+              }
+              v[t] = val;
+            }
+            pe[g][b][q] = pack_bf16(v[0], v[1]);
+          }
+    };
+
+    // ---- trunk ----
+    unsigned act[2][8][8];
+    {
+      unsigned pe[2][2][8];
+      posenc(pe);
+      f32x16 acc[2][8];
+      bf_gemm<2, 8, true, BYTES_TRUNK>(acc, pe, st, bf_lds, lane, wave);
+      bf_pack<8, true>(act, acc);
+    }
+#pragma unroll 1
+    for (int l = 1; l < TRUNK_DEPTH; ++l) {
+      f32x16 acc[2][8];
+      if (l == SKIP_LAYER) {
+        unsigned pe[2][2][8];
+        posenc(pe);   // before the accumulators come alive: the sin() temporaries would not fit next to 256 of them
+        bf_gemm<8, 8, true, BYTES_L4B>(acc, act, st, bf_lds, lane, wave);
+        bf_gemm<2, 8, false, BYTES_TRUNK, false, false>(acc, pe, st, bf_lds, lane, wave);   // accumulates onto the h part
+      } else if (l == TRUNK_DEPTH - 1) {
+        bf_gemm<8, 8, true, BYTES_BN>(acc, act, st, bf_lds, lane, wave);
+      } else {
+        bf_gemm<8, 8, true, BYTES_TRUNK>(acc, act, st, bf_lds, lane, wave);
+      }
+      bf_pack<8, true>(act, acc);
+    }
+
+    // ---- bottleneck (linear) + alpha head as the ninth output block ----
+    unsigned bn[2][8][8];
+    float alpha_raw[2];
+    {
+      f32x16 acc9[2][9];
+      bf_gemm<8, 9, true, BYTES_RGBH>(acc9, act, st, bf_lds, lane, wave);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        alpha_raw[g] = acc9[g][8][0];
+#pragma unroll
+        for (int o = 0; o < 8; ++o)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) bn[g][o][q] = pack_bf16(acc9[g][o][2 * q], acc9[g][o][2 * q + 1]);
+      }
+    }
+
+    // ---- rgb branch ----
+    unsigned rgbh[2][4][8];
+    {
+      f32x16 acc4[2][4];
+      bf_gemm<8, 4, false, BYTES_LOGIT>(acc4, bn, st, bf_lds, lane, wave);
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        const int r = row[g] < A.rows ? row[g] : A.rows - 1;
+        const float* ct = A.condterm + (size_t)min(r / A.S, A.B - 1) * RGB_W;   // fp32 per-ray term incl. bias
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 c4 = *reinterpret_cast<const float4*>(ct + 32 * o + 8 * j + 4 * h);
+            acc4[g][o][4 * j] += c4.x; acc4[g][o][4 * j + 1] += c4.y; acc4[g][o][4 * j + 2] += c4.z; acc4[g][o][4 * j + 3] += c4.w;
+          }
+      }
+      bf_pack<4, true>(rgbh, acc4);
+    }
+    f32x16 acc1[2][1];
+    bf_gemm<4, 1, true, BYTES_L0, true>(acc1, rgbh, st, bf_lds, lane, wave);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+      if (h == 0 && row[g] < A.rows) {
+        float4 o;
+        o.x = 1.f / (1.f + expf(-acc1[g][0][0]));
+        o.y = 1.f / (1.f + expf(-acc1[g][0][1]));
+        o.z = 1.f / (1.f + expf(-acc1[g][0][2]));
+        o.w = bf_sigma(alpha_raw[g], A.sigma_act);
+        A.out4[row[g]] = o;
+      }
+  }
+}
+
+namespace {
+// One descriptor fills rows of the weight stream.  kind 0: `nrows` k-step rows of a GEMM (row = 2b + s), out blocks
+// o0 .. o0 + nout of a GEMM that is nout_panel blocks wide; lane (m, h) gets 8 bf16: slot e <-> K index
+// 32b + 8(2s + e/4) + 4h + e%4.  kind 1: the bias row: slots 0/1 of the h = 0 lanes = bf16 hi / lo parts of bias[32o + m].
+__global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __restrict__ descs, const float* __restrict__ params,
+                                                        float* __restrict__ ws) {
+  const RcPackDesc d = descs[blockIdx.y];
+  const int total = d.ngroups * d.nout * 64;
+  uint4* dst = reinterpret_cast<uint4*>(ws + d.dst_off);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int lane = idx & 63, o = (idx >> 6) % d.nout, rowi = (idx >> 6) / d.nout;
+    const int m = lane & 31, h = lane >> 5, b = rowi >> 1, s = rowi & 1;
+    const int col = 32 * o + m;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (d.kind == 1) {
+      if (h == 0 && col < d.ncols) {
+        const float bias = params[d.src_off + col];
+        const float hi = __uint_as_float(pack_bf16(bias, 0.f) << 16);
+        v[0] = hi; v[1] = bias - hi;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = 32 * b + 8 * (2 * s + (e >> 2)) + 4 * h + (e & 3);
+        if (k < d.krows && col < d.ncols) v[e] = params[d.src_off + (int64_t)(d.row0 + k) * d.src_ld + col];
+      }
+    }
+    uint4 out;
+    out.x = pack_bf16(v[0], v[1]); out.y = pack_bf16(v[2], v[3]); out.z = pack_bf16(v[4], v[5]); out.w = pack_bf16(v[6], v[7]);
+    dst[(size_t)(rowi * d.nout_panel + d.o0 + o) * 64 + lane] = out;
+  }
+}
+}  // namespace
+
+void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream) {
+  if (ndesc > 0) bf16_pack_kernel<<<dim3(32, ndesc), 256, 0, stream>>>(descs, params, ws);
+}
+
+void launch_chain_fwd_bf16(const ChainFwdArgs& a, int grid, hipStream_t stream) {
+  const size_t lds = 2 * BF_BUF_BYTES;
+  (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(nerf_mlp_fwd_bf16_kernel, dim3(grid), dim3(256), lds, stream, a);
+}
+
+}  // namespace nrf

@@ -33,6 +33,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct LevelWs {   // float offsets from the workspace base, per level (0 = coarse, 1 = fine)
   size_t wpk, z, out4, rgb, depth, med, acc, weights, condterm;
+  size_t bf_wpk = 0;   // bf16 weight stream of the NRF_FLAG_BF16 forward (inference plans)
   size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
   // SE3 warp field (per level: the field is evaluated on the coarse and on the fine samples)
@@ -47,6 +48,8 @@ struct WsPlan {
   int S[4], rows[4], ntiles[4];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
   size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b, emb_off_b;
+  size_t bf_desc = 0;
+  std::vector<RcPackDesc> bfpack;
   size_t iparams = 0, igrad = 0;   // zero-padded parameter image / its gradient (models narrower than the kernels)
   std::vector<WgradSegment> segs;
   std::vector<int> seg_begin;
@@ -433,6 +436,40 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     p.iparams = take((size_t)h->nparams);
     if (train) p.igrad = take((size_t)h->nparams);
   }
+  p.bfpack.clear();
+  if (!train) {   // weight stream of the bf16 forward (mlp_bf16.hip), GEMMs in execution order, rows of nout KiB
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      const MlpParamOffsets& po = h->po[lv];
+      const size_t stream_floats = (size_t)(40 + 7 * 136 + 32 + 153 + 64 + 9 + 48) * 256;   // KiB -> floats, + slack
+      p.L[lv].bf_wpk = take(stream_floats);
+      size_t at = 0;   // floats from the level's stream base
+      auto emit = [&](int kind, int64_t src, int ld, int row0, int krows, int ncols, int nrows, int nout, int npanel, int o0) {
+        RcPackDesc e;
+        e.src_off = src; e.dst_off = (long long)(p.L[lv].bf_wpk + at); e.kind = kind; e.src_ld = ld; e.row0 = row0; e.krows = krows;
+        e.ncols = ncols; e.ngroups = nrows; e.nout = nout; e.nout_panel = npanel; e.o0 = o0;
+        p.bfpack.push_back(e);
+      };
+      auto gemm = [&](int64_t wk, int ld, int row0, int krows, int ncols, int nin, int nout, int64_t bias) {
+        if (bias >= 0) { emit(1, bias, 0, 0, 0, ncols, 1, nout, nout, 0); at += (size_t)nout * 256; }
+        emit(0, wk, ld, row0, krows, ncols, nin * 2, nout, nout, 0);
+        at += (size_t)nin * 2 * nout * 256;
+      };
+      gemm(po.trunk_k[0], TRUNK_W, 0, h->P, TRUNK_W, 2, 8, po.trunk_b[0]);
+      for (int l = 1; l < TRUNK_DEPTH; ++l) {
+        gemm(po.trunk_k[l], TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, po.trunk_b[l]);
+        if (l == SKIP_LAYER) gemm(po.trunk_k[l], TRUNK_W, TRUNK_W, h->P, TRUNK_W, 2, 8, -1);
+      }
+      emit(1, po.bn_b, 0, 0, 0, TRUNK_W, 1, 8, 9, 0);          // bottleneck (8 blocks) + alpha head (block 8)
+      emit(1, po.alpha_b, 0, 0, 0, 1, 1, 1, 9, 8);
+      at += 9 * 256;
+      emit(0, po.bn_k, TRUNK_W, 0, TRUNK_W, TRUNK_W, 16, 8, 9, 0);
+      emit(0, po.alpha_k, 1, 0, TRUNK_W, 1, 16, 1, 9, 8);
+      at += (size_t)16 * 9 * 256;
+      gemm(po.rgbh_k, RGB_W, 0, TRUNK_W, RGB_W, 8, 4, -1);
+      gemm(po.logit_k, 3, 0, RGB_W, 3, 4, 1, po.logit_b);
+    }
+    p.bf_desc = take(p.bfpack.size() * sizeof(RcPackDesc) / 4 + 16);
+  }
 
   auto alloc_warp = [&](LevelWs& L, size_t nt) {
     L.wpoints = take(nt * TILE_ROWS * 3);
@@ -643,6 +680,10 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
     e = hipMemcpyAsync(base + p.segbegin_off_b, p.seg_begin.data(), p.seg_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload wgrad segment index");
   }
+  if (!p.bfpack.empty()) {
+    e = hipMemcpyAsync(ws + p.bf_desc, p.bfpack.data(), p.bfpack.size() * sizeof(RcPackDesc), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload bf16 pack table");
+  }
   if (h->embed) {
     e = hipMemcpyAsync(base + p.emb_off_b, h->emb.data(), h->emb.size() * sizeof(EmbedDesc), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload embed table");
@@ -768,6 +809,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   const bool warp_on = h->warp && !(flags & NRF_FLAG_NO_WARP);   // models.py:296 use_warp argument
   if (warp_on && !scalars) return fail(NRF_E_NULL, "nrf_step_scalars (warp_alpha) required with the warp field");
   if (h->warp && !warp_on && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
+  if ((flags & NRF_FLAG_BF16) && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is an inference mode: no bf16 backward is built");
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
@@ -782,6 +824,8 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   Prof& pf = h->prof;
   pf.begin("pack_prep_sample", 0, stream);
   launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
+  const bool bf16 = flags & NRF_FLAG_BF16;
+  if (bf16) launch_bf16_pack(reinterpret_cast<const RcPackDesc*>(ws + p.bf_desc), (int)p.bfpack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
   launch_ray_prep(params, viewdirs, rays->appearance_ids, rays->camera_ids, B, d.num_nerf_viewdir_freqs, d.use_viewdirs,
                   h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
@@ -823,7 +867,13 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       }
     }
     pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
-    launch_chain_fwd(a, train, grid, stream);
+    if (bf16) {   // one workgroup per CU (90 KiB of weight staging), 256 samples per workgroup iteration
+      a.wpk = ws + L.bf_wpk;
+      const int nit = (p.rows[lv] + 255) / 256;
+      launch_chain_fwd_bf16(a, nit < h->num_cus ? nit : h->num_cus, stream);
+    } else {
+      launch_chain_fwd(a, train, grid, stream);
+    }
     pf.end(stream);
     pf.begin("composite_fwd", 0, stream);
     launch_composite_fwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],

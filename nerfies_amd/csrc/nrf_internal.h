@@ -61,6 +61,15 @@ struct WarpPackOffsets {
   int total;
 };
 
+// bf16 forward chain (mlp_bf16.hip): one descriptor fills rows of its weight stream
+struct RcPackDesc {
+  long long src_off, dst_off;   // params leaf / first row written, in floats from the workspace base
+  int kind;                     // 0: k-step rows of weights, 1: the bias row
+  int src_ld, row0, krows, ncols;   // leaf column count, first row, valid rows (K) and columns
+  int ngroups, nout, nout_panel, o0;   // rows written, output blocks written, GEMM width in blocks, first output block
+};
+void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream);
+
 struct ChainFwdArgs {
   const float* params;       // flat canonical parameters
   MlpParamOffsets po;
@@ -274,6 +283,7 @@ struct EmbedDesc {
   long long ext_off, int_off;
   int rows, ext_cols, int_cols, split, shift, pad_;
 };
+void launch_chain_fwd_bf16(const struct ChainFwdArgs& a, int grid, hipStream_t stream);
 void launch_embed(const EmbedDesc* descs, int ndesc, const float* src, float* dst, bool to_internal, hipStream_t stream);
 
 // camera.hip -- Camera.pixels_to_rays / pixels_to_points / project (nerfies/camera.py)

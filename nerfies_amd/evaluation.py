@@ -21,9 +21,10 @@ class GraphedChunkRenderer:
   static buffers, the graph is replayed and copies of the static outputs are returned.
   The graph is (re)captured whenever the chunk size, the parameter buffer or warp_alpha changes."""
 
-  def __init__(self, model, use_warp=True):
+  def __init__(self, model, use_warp=True, bf16=False):
     self.model = model
     self.use_warp = use_warp
+    self.bf16 = bf16   # NRF_FLAG_BF16 inference mode (bfloat16 MLP operands)
     self._key = None
     self._graph = None
     self._in = None
@@ -32,7 +33,7 @@ class GraphedChunkRenderer:
   def _capture(self, fp, rays, warp_extra):
     model = self.model
     self._in = _tree_map(lambda x: x.clone(), rays)
-    call = lambda out=None: model.apply({'params': fp}, self._in, warp_extra, use_warp=self.use_warp, out=out)
+    call = lambda out=None: model.apply({'params': fp}, self._in, warp_extra, use_warp=self.use_warp, out=out, bf16=self.bf16)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):

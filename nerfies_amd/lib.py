@@ -8,6 +8,7 @@ LIB_PATH = os.path.join(HERE, '_lib', 'libnerfies_amd.so')
 
 NRF_FLAG_TRAIN = 1
 NRF_FLAG_NO_WARP = 2
+NRF_FLAG_BF16 = 4
 ACT = {'relu': 0, 'softplus': 1}
 WARP_FIELD = {'se3': 0, 'translation': 1}
 

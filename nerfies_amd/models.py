@@ -240,11 +240,12 @@ class NerfModel:
   # ---- NerfModel.__call__ (models.py:289-375) ---------------------------------------------
   def apply(self, variables, rays_dict: Dict[str, Any], warp_extra: Dict[str, Any] = None, metadata_encoded=False,
             use_warp=True, return_points=False, return_weights=False, return_warp_jacobian=False,
-            deterministic=False, rngs=None, *, train=False, return_z_vals=False, out=None):
+            deterministic=False, rngs=None, *, train=False, return_z_vals=False, out=None, bf16=False):
     """Returns {'coarse': {...}, 'fine': {...}} like the reference.  `train=True` keeps the
     activation stash so `backward` can follow (used by training.train_step / autograd).  `out`: a dict
     returned by an earlier call with the same shapes/flags, to be overwritten in place (fixed output
-    addresses: what a captured hipGraph replay needs)."""
+    addresses: what a captured hipGraph replay needs).  `bf16=True` (inference only, no reference counterpart): the NeRF
+    MLPs take bfloat16 operands (NRF_FLAG_BF16), everything else stays fp32."""
     del deterministic   # accepted and unused, as in the reference (models.py:298)
     if metadata_encoded:
       raise L.NrfError('metadata_encoded=True is not built yet')
@@ -286,7 +287,8 @@ class NerfModel:
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
     ws = self.workspace(B, train, device)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
-    flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0)
+    flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0) | \
+        (L.NRF_FLAG_BF16 if bf16 else 0)
     L.check(self.lib.nrf_forward(self.handle, _ptr(fp.flat), C.byref(rays), C.byref(scal), C.byref(rnd), C.byref(out),
                                  flags, _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2

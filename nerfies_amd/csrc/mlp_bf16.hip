@@ -23,6 +23,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 namespace {
 
+// BF_NOSIN / BF_NOPACK / BF_NOMFMA: compile-time switches used once to attribute the kernel's time (results are wrong with
+// any of them defined): at 8192 rays x 256 samples the MFMA-free build takes 47 % of the full one, sin() 10 %, the
+// bf16 pack nothing measurable.
 constexpr int BF_BUF_BYTES = 5 * 9 * 1024;   // largest chunk: bias step + 4 k-steps of a 9-block GEMM
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -42,19 +45,39 @@ struct BfStream {   // scalars only (kept in SGPRs / VGPRs by SROA)
   int cur;          // LDS buffer holding it
 };
 
-// Starts the LDS-DMA of `nbytes` (a multiple of 4 KiB) at stream offset `off` into buffer `buf`; piece p (1 KiB) is issued
-// by wave p % 4.
-__device__ __forceinline__ void bf_dma(const char* src_lane, int off, int nbytes, char* lds, int buf, int wave) {
-  const int npieces = nbytes >> 10;
-  for (int p = wave; p < npieces; p += 4)
+// Starts the LDS-DMA of `nbytes` (whole KiB) at stream offset `off` into buffer `buf`.  Every wave issues the same
+// number of 1 KiB copies, ceil(KiB / 4) (the tail re-copies the last piece), so that "this wave's share of chunk c+1 has
+// landed" is the compile-time test  vmcnt <= copies of chunk c+2.
+__device__ __forceinline__ constexpr int bf_copies(int nbytes) { return ((nbytes >> 10) + 3) / 4; }
+template <int NBYTES>
+__device__ __forceinline__ void bf_dma(const char* src_lane, int off, char* lds, int buf, int wave) {
+  constexpr int npieces = NBYTES >> 10;
+#pragma unroll
+  for (int i = 0; i < bf_copies(NBYTES); ++i) {
+    const int p = min(wave + 4 * i, npieces - 1);
     __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src_lane + off + p * 1024),
                                      (lds_void_t*)(lds + buf * BF_BUF_BYTES + p * 1024), 16, 0, 0);
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void bf_wait_vm() {   // s_waitcnt vmcnt(K), K a compile-time constant <= 15 here
+  static_assert(K >= 0 && K <= 15, "vmcnt immediate");
+  if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (K == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (K == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (K == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else if constexpr (K == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else static_assert(K == 0, "add the immediate");
 }
 
 // acc[g][o] = sum over the NIN input blocks (+ bias), both sample groups.  Chunk 0 carries the bias k-step first when
-// BIAS.  The chunk that follows this GEMM's last one has NEXT_BYTES bytes (first chunk of the next GEMM; WRAP: of the
-// chain's first GEMM at offset 0).
-template <int NIN, int NOUT, bool BIAS, int NEXT_BYTES, bool WRAP = false, bool INIT = true>
+// BIAS.  Weights are prefetched TWO chunks ahead into a ring of three LDS buffers (an L2 -> LDS copy takes longer than one
+// chunk of MFMAs): NEXT1 / NEXT2 = byte counts of the two chunks that follow this GEMM's last one in the stream; WRAP:
+// they are the first two chunks of the chain (offsets 0 and NEXT1).
+template <int NIN, int NOUT, bool BIAS, int NEXT1, int NEXT2, bool WRAP = false, bool INIT = true>
 __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[2][NOUT], const unsigned (&in)[2][NIN][8], BfStream& st, char* lds, int lane,
                                         int wave) {
   constexpr int NCHUNK = NIN / 2;   // 4 k-steps = 2 input blocks per chunk
@@ -67,10 +90,16 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[2][NOUT], const unsigned (
   }
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c) {
-    const int this_bytes = (4 + (BIAS && c == 0 ? 1 : 0)) * NOUT * 1024;
-    const bool last = c == NCHUNK - 1;
-    const int next_off = (last && WRAP) ? 0 : st.soff + this_bytes;
-    bf_dma(st.src, next_off, last ? NEXT_BYTES : 4 * NOUT * 1024, lds, st.cur ^ 1, wave);
+    constexpr int BODY = 4 * NOUT * 1024;
+    const int this_bytes = BODY + ((BIAS && c == 0) ? NOUT * 1024 : 0);
+    // sizes / offsets of the next two chunks of the stream
+    const int n1 = c + 1 < NCHUNK ? BODY : NEXT1;
+    const int off1 = (WRAP && c + 1 == NCHUNK) ? 0 : st.soff + this_bytes;
+    const int off2 = (WRAP && c + 2 == NCHUNK) ? 0 : (WRAP && c + 2 == NCHUNK + 1) ? NEXT1 : off1 + n1;
+    const int buf2 = st.cur >= 1 ? st.cur - 1 : 2;   // (cur + 2) % 3
+    if (c + 2 < NCHUNK) bf_dma<BODY>(st.src, off2, lds, buf2, wave);
+    else if (c + 2 == NCHUNK) bf_dma<NEXT1>(st.src, off2, lds, buf2, wave);
+    else bf_dma<NEXT2>(st.src, off2, lds, buf2, wave);
     const char* wb = lds + st.cur * BF_BUF_BYTES + lane * 16;
     constexpr int NB = BIAS ? 1 : 0;
     const int nrows = 4 + ((BIAS && c == 0) ? 1 : 0);   // k-step rows of this chunk (bias row first)
@@ -97,14 +126,23 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[2][NOUT], const unsigned (
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
 #pragma unroll
-          for (int g = 0; g < 2; ++g) acc[g][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r & 1][o], bop[g], acc[g][o], 0, 0, 0);
+          for (int g = 0; g < 2; ++g) {
+#ifdef BF_NOMFMA
+            acc[g][o][0] += __builtin_bit_cast(u32x4v, af[r & 1][o]).x * 1e-30f + __builtin_bit_cast(u32x4v, bop[g]).x * 1e-30f;
+#else
+            acc[g][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r & 1][o], bop[g], acc[g][o], 0, 0, 0);
+#endif
+          }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next chunk has landed
-    __syncthreads();                      // ... everyone's has, and nobody still reads the buffer it will replace next
-    st.soff = next_off;
-    st.cur ^= 1;
+    // chunk c+1 (issued one chunk ago) must have landed; chunk c+2's copies (just issued) may stay in flight
+    if (c + 2 < NCHUNK) bf_wait_vm<bf_copies(BODY)>();
+    else if (c + 2 == NCHUNK) bf_wait_vm<bf_copies(NEXT1)>();
+    else bf_wait_vm<bf_copies(NEXT2)>();
+    __syncthreads();   // ... everyone's share has, and nobody still reads the buffer the next chunk's prefetch replaces
+    st.soff = off1;
+    st.cur = st.cur == 2 ? 0 : st.cur + 1;
   }
 }
 
@@ -118,6 +156,10 @@ __device__ __forceinline__ void bf_pack(unsigned (&out)[2][NB][8], const f32x16 
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float a = acc[g][o][2 * q], b = acc[g][o][2 * q + 1];
+#ifdef BF_NOPACK
+        out[g][o][q] = __float_as_uint(a) ^ __float_as_uint(b);
+        continue;
+#endif
         if (RELU) { a = __builtin_amdgcn_fmed3f(a, 0.f, __builtin_inff()); b = __builtin_amdgcn_fmed3f(b, 0.f, __builtin_inff()); }
         out[g][o][q] = pack_bf16(a, b);
       }
@@ -128,8 +170,11 @@ __device__ __forceinline__ float bf_sigma(float x, int kind) {
 }
 
 // chunk-0 byte counts of each GEMM of the chain (what the GEMM before it prefetches)
-constexpr int BYTES_L0 = 5 * 8 * 1024, BYTES_TRUNK = 5 * 8 * 1024, BYTES_L4B = 4 * 8 * 1024, BYTES_BN = 5 * 9 * 1024,
-              BYTES_RGBH = 4 * 4 * 1024, BYTES_LOGIT = 5 * 1 * 1024;
+constexpr int KB = 1024;
+constexpr int T0 = 40 * KB, T1 = 32 * KB;           // trunk GEMM: first chunk (bias row + 4 k-steps of 8 blocks), later chunks
+constexpr int BN0 = 45 * KB, BN1 = 36 * KB;         // bottleneck + alpha: 9 blocks
+constexpr int RG = 16 * KB;                         // rgb hidden: 4 blocks
+constexpr int LG0 = 20 * KB, LG1 = 16 * KB;         // rgb logits, padded to 4 blocks so that every chunk is whole 4-KiB groups
 
 }  // namespace
 
@@ -144,7 +189,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   st.src = reinterpret_cast<const char*>(A.wpk) + lane * 16;
   st.soff = 0;
   st.cur = 0;
-  bf_dma(st.src, 0, BYTES_L0, bf_lds, 0, wave);
+  bf_dma<T0>(st.src, 0, bf_lds, 0, wave);        // layer 0's only chunk
+  bf_dma<T0>(st.src, T0, bf_lds, 1, wave);       // layer 1, chunk 0
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -185,7 +231,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
               } else if (e < A.P) {
                 const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, c = rem >= 3 ? rem - 3 : rem;
                 const float a = __fmul_rn(c == 0 ? x[g][0] : c == 1 ? x[g][1] : x[g][2], (float)(1 << f));
+#ifdef BF_NOSIN
+                val = rem >= 3 ? __fadd_rn(a, half_pi) : a;
+#else
                 val = sinf(rem >= 3 ? __fadd_rn(a, half_pi) : a);
+#endif
               }
               v[t] = val;
             }
@@ -199,7 +249,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       unsigned pe[2][2][8];
       posenc(pe);
       f32x16 acc[2][8];
-      bf_gemm<2, 8, true, BYTES_TRUNK>(acc, pe, st, bf_lds, lane, wave);
+      bf_gemm<2, 8, true, T0, T1>(acc, pe, st, bf_lds, lane, wave);
       bf_pack<8, true>(act, acc);
     }
 #pragma unroll 1
@@ -208,12 +258,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       if (l == SKIP_LAYER) {
         unsigned pe[2][2][8];
         posenc(pe);   // before the accumulators come alive: the sin() temporaries would not fit next to 256 of them
-        bf_gemm<8, 8, true, BYTES_L4B>(acc, act, st, bf_lds, lane, wave);
-        bf_gemm<2, 8, false, BYTES_TRUNK, false, false>(acc, pe, st, bf_lds, lane, wave);   // accumulates onto the h part
+        bf_gemm<8, 8, true, T1, T0>(acc, act, st, bf_lds, lane, wave);     // then the skip rows (one 32 KiB chunk), then layer 5
+        bf_gemm<2, 8, false, T0, T1, false, false>(acc, pe, st, bf_lds, lane, wave);   // accumulates onto the h part
       } else if (l == TRUNK_DEPTH - 1) {
-        bf_gemm<8, 8, true, BYTES_BN>(acc, act, st, bf_lds, lane, wave);
+        bf_gemm<8, 8, true, BN0, BN1>(acc, act, st, bf_lds, lane, wave);
       } else {
-        bf_gemm<8, 8, true, BYTES_TRUNK>(acc, act, st, bf_lds, lane, wave);
+        bf_gemm<8, 8, true, T0, T1>(acc, act, st, bf_lds, lane, wave);
       }
       bf_pack<8, true>(act, acc);
     }
@@ -223,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     float alpha_raw[2];
     {
       f32x16 acc9[2][9];
-      bf_gemm<8, 9, true, BYTES_RGBH>(acc9, act, st, bf_lds, lane, wave);
+      bf_gemm<8, 9, true, RG, RG>(acc9, act, st, bf_lds, lane, wave);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         alpha_raw[g] = acc9[g][8][0];
@@ -238,7 +288,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     unsigned rgbh[2][4][8];
     {
       f32x16 acc4[2][4];
-      bf_gemm<8, 4, false, BYTES_LOGIT>(acc4, bn, st, bf_lds, lane, wave);
+      bf_gemm<8, 4, false, LG0, LG1>(acc4, bn, st, bf_lds, lane, wave);
 #pragma unroll
       for (int g = 0; g < 2; ++g) {
         const int r = row[g] < A.rows ? row[g] : A.rows - 1;
@@ -253,8 +303,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       }
       bf_pack<4, true>(rgbh, acc4);
     }
-    f32x16 acc1[2][1];
-    bf_gemm<4, 1, true, BYTES_L0, true>(acc1, rgbh, st, bf_lds, lane, wave);
+    f32x16 acc1[2][4];   // blocks 1..3 are padding (zero weights)
+    bf_gemm<4, 4, true, T0, T0, true>(acc1, rgbh, st, bf_lds, lane, wave);   // then the chain restarts: layer 0, layer 1
 #pragma unroll
     for (int g = 0; g < 2; ++g)
       if (h == 0 && row[g] < A.rows) {
@@ -307,7 +357,7 @@ void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, f
 }
 
 void launch_chain_fwd_bf16(const ChainFwdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = 2 * BF_BUF_BYTES;
+  const size_t lds = 3 * BF_BUF_BYTES;
   (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(nerf_mlp_fwd_bf16_kernel, dim3(grid), dim3(256), lds, stream, a);
 }

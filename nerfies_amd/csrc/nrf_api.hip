@@ -440,7 +440,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   if (!train) {   // weight stream of the bf16 forward (mlp_bf16.hip), GEMMs in execution order, rows of nout KiB
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
-      const size_t stream_floats = (size_t)(40 + 7 * 136 + 32 + 153 + 64 + 9 + 48) * 256;   // KiB -> floats, + slack
+      const size_t stream_floats = (size_t)(40 + 7 * 136 + 32 + 153 + 64 + 36 + 64) * 256;   // KiB -> floats, + slack
       p.L[lv].bf_wpk = take(stream_floats);
       size_t at = 0;   // floats from the level's stream base
       auto emit = [&](int kind, int64_t src, int ld, int row0, int krows, int ncols, int nrows, int nout, int npanel, int o0) {
@@ -466,7 +466,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       emit(0, po.alpha_k, 1, 0, TRUNK_W, 1, 16, 1, 9, 8);
       at += (size_t)16 * 9 * 256;
       gemm(po.rgbh_k, RGB_W, 0, TRUNK_W, RGB_W, 8, 4, -1);
-      gemm(po.logit_k, 3, 0, RGB_W, 3, 4, 1, po.logit_b);
+      gemm(po.logit_k, 3, 0, RGB_W, 3, 4, 4, po.logit_b);   // padded to 4 output blocks (whole 4-KiB chunk groups)
     }
     p.bf_desc = take(p.bfpack.size() * sizeof(RcPackDesc) / 4 + 16);
   }

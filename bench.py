@@ -185,12 +185,15 @@ def side_mode(args, world, rank, dev):
     achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
     step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / 5
     ms = 1e3 * elapsed / args.steps
+    # dense bf16 MFMA peak (MI355X_MICROARCH.md) for the opt-in bf16-operand mode, fp32 MFMA peak otherwise
+    peak = 2500.0 if (args.mode == 'eval' and os.environ.get('BENCH_BF16')) else PEAK_FP32_MFMA_TFLOPS
     print(json.dumps({
         'metric': name, 'value': world * per_step * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32',
+        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'bf16' if (args.mode == 'eval' and os.environ.get('BENCH_BF16')) else 'f32',
         'data': 'synthetic', 'config': {'workload': workload, 'rays_per_gpu': per_step, 'parallelism': f'ray-shard dp{world}'},
-        'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                     'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': None, 'kernel_ms': dom_ms},
+        'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                     'frac': achieved / peak, 'traffic': None, 'kernel_ms': dom_ms},
         'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernels}))
   if world > 1:
     dist.destroy_process_group()

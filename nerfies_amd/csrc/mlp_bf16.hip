@@ -140,7 +140,10 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[2][NOUT], const unsigned (
     if (c + 2 < NCHUNK) bf_wait_vm<bf_copies(BODY)>();
     else if (c + 2 == NCHUNK) bf_wait_vm<bf_copies(NEXT1)>();
     else bf_wait_vm<bf_copies(NEXT2)>();
-    __syncthreads();   // ... everyone's share has, and nobody still reads the buffer the next chunk's prefetch replaces
+    // ... everyone's share has, and nobody still reads the buffer the next chunk's prefetch replaces.  A bare s_barrier:
+    // __syncthreads() adds a workgroup fence, i.e. vmcnt(0), which would drain the two-ahead prefetch every chunk.
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     st.soff = off1;
     st.cur = st.cur == 2 ? 0 : st.cur + 1;
   }
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #ifdef BF_NOSIN
                 val = rem >= 3 ? __fadd_rn(a, half_pi) : a;
 #else
-                val = sinf(rem >= 3 ? __fadd_rn(a, half_pi) : a);
+                val = __sinf(rem >= 3 ? __fadd_rn(a, half_pi) : a);   // v_sin_f32: ~1e-6 abs, far below the bf16 rounding that follows
 #endif
               }
               v[t] = val;

@@ -91,7 +91,7 @@ def main(argv=None):
       camera_ids=datasource.camera_ids, warp_ids=datasource.warp_ids, near=datasource.near, far=datasource.far,
       use_warp_jacobian=False, use_weights=False, device=device)
   init_state = training.TrainState(optimizer=training.Optimizer(params))
-  renderer = evaluation.GraphedChunkRenderer(model)            # hipGraph replay per chunk
+  renderer = evaluation.GraphedChunkRenderer(model, bf16=flags.bf16)   # hipGraph replay per chunk
   render_fn = functools.partial(evaluation.render_image, model_fn=renderer, device_count=world, chunk=eval_config.chunk)
   writer = utils.ScalarLog(summary_dir)
   last_step, results = 0, {}

@@ -26,7 +26,7 @@ def parse_flags(argv=None):
   p.add_argument('--gin_bindings', action='append', default=None, help='Gin parameter bindings.')
   p.add_argument('--gin_configs', action='append', default=[], help='Gin config files.')
   p.add_argument('--max_steps', type=int, default=None, help='stop early (smoke runs); default TrainConfig.max_steps')
-  p.add_argument('--bf16', action='store_true', help='eval.py only: render with bfloat16 MLP operands (NRF_FLAG_BF16, ~4x faster, '
+  p.add_argument('--bf16', action='store_true', help='eval.py only: render with bfloat16 MLP operands (NRF_FLAG_BF16, ~5x faster, '
                  '~1e-2 on colour; no reference counterpart)')
   return p.parse_args(argv)
 

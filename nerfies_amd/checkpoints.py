@@ -102,14 +102,12 @@ def state_from_dict(state, d: Dict[str, Any]):
     st = d['optimizer']['state']
     ps = st['param_states']
     ps = ps.get('model', ps)
-    pick = lambda key: (lambda node: node[key])
     is_leaf = lambda node: isinstance(node, dict) and 'grad_ema' in node
 
     def split(node, key):
       return {k: (v[key] if is_leaf(v) else split(v, key)) for k, v in node.items()}
     P.flat_from_tree(split(ps, 'grad_ema'), layout, dev, out=opt.m)
     P.flat_from_tree(split(ps, 'grad_sq_ema'), layout, dev, out=opt.v)
-    del pick
   except KeyError as e:
     raise KeyError(f'checkpoint does not match the model: missing {e}') from None
   opt.step = int(np.asarray(st['step']))

@@ -4,8 +4,8 @@ import numpy as _np
 
 
 class Key:
-  def __init__(self, uniform=None, normal=None):
-    self.u, self.n = uniform, normal
+  def __init__(self, uniform=None, normal=None, choice=None):
+    self.u, self.n, self.c = uniform, normal, choice
 
 
 def PRNGKey(seed):
@@ -28,3 +28,11 @@ def normal(key, shape, dtype=None):
   n = _np.asarray(key.n, dtype=_np.float64)
   assert tuple(n.shape) == tuple(shape), (n.shape, shape)
   return n
+
+
+def choice(key, a, shape=(), replace=True, p=None):
+  """random.choice(key, a, shape): key.c holds the INDICES into `a` the call must pick."""
+  assert key.c is not None, 'this code path draws a choice: pass random.Key(choice=indices)'
+  idx = _np.asarray(key.c)
+  assert tuple(idx.shape) == tuple(shape), (idx.shape, shape)
+  return _np.asarray(a)[idx]

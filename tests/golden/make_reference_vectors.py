@@ -190,6 +190,22 @@ def nerf_model():
     save('nerf_' + name, **out)
 
 
+def background_loss():
+  """training.compute_background_loss (training.py:117-135) run by the reference on the oracle's warp parameters, with the
+  ids / noise it draws supplied through the key."""
+  import types
+  spec = O.ModelSpec(use_warp=True, num_warp_freqs=6, num_warp_features=8, num_warp_embeddings=4)
+  params = O.init_params(spec, seed=21, trained_like=True)
+  model = build_ref_model(spec)
+  rng = np.random.default_rng(22)
+  n = 9
+  pts = rng.uniform(-0.4, 0.4, (n, 3)); ids = rng.integers(0, 4, (n, 1)); noise = rng.normal(size=(n, 3))
+  state = types.SimpleNamespace(warp_extra={'alpha': 4.5, 'time_alpha': 0.0})
+  key = jrandom.Key(normal=noise, choice=ids)
+  loss = ref_training.compute_background_loss(model, state, tree_np(params), key, pts, 0.001, alpha=-2, scale=0.001)
+  save('background_loss', points=pts, ids=ids, noise=noise, alpha=4.5, noise_std=0.001, loss=np.asarray(loss))
+
+
 def losses_and_schedules():
   sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
   out = dict(sq=sq, gl_m2_c03=ref_utils.general_loss_with_squared_residual(sq, alpha=-2.0, scale=0.03),
@@ -250,5 +266,6 @@ if __name__ == '__main__':
   se3_field()
   translation_field()
   nerf_model()
+  background_loss()
   losses_and_schedules()
   cameras()

@@ -148,6 +148,18 @@ def test_losses_psnr_elastic():
   close(el, r['el_loss'], 1e-10); close(res, r['el_residual'], 1e-10)
 
 
+def test_background_loss():
+  """training.compute_background_loss (training.py:117-135): the reference run on the oracle's warp parameters with the
+  ids and the noise it draws supplied to it."""
+  r = ref('background_loss')
+  spec = O.ModelSpec(use_warp=True, num_warp_freqs=6, num_warp_features=8, num_warp_embeddings=4)
+  params = O.init_params(spec, seed=21, trained_like=True)
+  loss = O.compute_background_loss(params, spec, T(r['points']), torch.tensor(r['ids']), T(r['noise']) * float(r['noise_std']),
+                                   float(r['alpha']))
+  close(loss, r['loss'], 1e-12)
+  assert float(loss.mean()) > 0
+
+
 # ---- camera geometry and schedules (SURVEY.md 8f ranks 2-3) ----
 def _oracle_camera(r, tag, focal=None, pp=None, size=(320, 240), skew=None, par=None):
   from oracle import camera_oracle as CO

@@ -1,1 +1,1 @@
-from . import linen, optim, struct  # noqa: F401
+from . import jax_utils, linen, optim, struct  # noqa: F401

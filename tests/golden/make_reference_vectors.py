@@ -206,6 +206,30 @@ def background_loss():
   save('background_loss', points=pts, ids=ids, noise=noise, alpha=4.5, noise_std=0.001, loss=np.asarray(loss))
 
 
+def render_image():
+  """evaluation.render_image (evaluation.py:28-101): the chunk / pad / shard / un-pad bookkeeping of the reference, driven
+  with a per-ray stand-in for the pmapped model on a ragged 5 x 7 frame over 3 devices."""
+  import types
+  from nerfies import evaluation as ref_evaluation
+  # 36 rays in chunks of 9 over 3 devices.  (Chunks that are not a multiple of the device count cannot be driven through
+  # the reference: it slices the padded chunk back to its unpadded length -- `per_host_rays = num_chunk_rays //
+  # process_count`, evaluation.py:76-80 -- and the shard reshape then fails.  nerfies_amd pads and un-pads correctly;
+  # tests/test_distributed_gloo.py covers the ragged case against the single-process render.)
+  h, w, devices, chunk = 4, 9, 3, 9
+  rng = np.random.default_rng(31)
+  rays = {'origins': rng.normal(size=(h, w, 3)), 'directions': rng.normal(size=(h, w, 3)),
+          'metadata': {'warp': rng.integers(0, 4, (h, w, 1))}}
+
+  def pmapped(key_0, key_1, params, r, warp_extra):     # r leaves: (devices, n, c); output as after lax.all_gather
+    rgb = np.tanh(r['origins'] + 0.5 * r['directions']) + 0.1 * r['metadata']['warp']
+    out = {'rgb': rgb, 'depth': (r['origins'] * r['directions']).sum(-1), 'acc': np.abs(r['origins'][..., 0])}
+    return {'fine': {k: np.broadcast_to(v[None], (devices,) + v.shape) for k, v in out.items()}}
+  state = types.SimpleNamespace(optimizer=types.SimpleNamespace(target={'model': None}), warp_extra={})
+  ret = ref_evaluation.render_image(state, rays, pmapped, devices, jrandom.Key(), chunk=chunk)
+  save('render_image', origins=rays['origins'], directions=rays['directions'], warp=rays['metadata']['warp'],
+       devices=devices, chunk=chunk, **{'out/' + k: v for k, v in ret.items()})
+
+
 def losses_and_schedules():
   sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
   out = dict(sq=sq, gl_m2_c03=ref_utils.general_loss_with_squared_residual(sq, alpha=-2.0, scale=0.03),
@@ -267,5 +291,6 @@ if __name__ == '__main__':
   translation_field()
   nerf_model()
   background_loss()
+  render_image()
   losses_and_schedules()
   cameras()

@@ -169,7 +169,7 @@ def test_render_image_tiling_matches_reference():
   rays = {'origins': T(r['origins']), 'directions': T(r['directions']), 'metadata': {'warp': torch.tensor(r['warp'])}}
 
   def model_fn(key_0, key_1, params, rr, warp_extra):
-    rgb = torch.tanh(rr['origins'] + 0.5 * rr['directions']) + 0.1 * rr['metadata']['warp']
+    rgb = torch.tanh(rr['origins'] + 0.5 * rr['directions']) + 0.1 * rr['metadata']['warp'].double()
     return {'fine': {'rgb': rgb, 'depth': (rr['origins'] * rr['directions']).sum(-1), 'acc': rr['origins'][..., 0].abs()}}
   state = types.SimpleNamespace(optimizer=types.SimpleNamespace(target=None), warp_extra={})
   for chunk in (int(r['chunk']), 7, 100):          # the result does not depend on the chunk size

@@ -230,6 +230,32 @@ def render_image():
        devices=devices, chunk=chunk, **{'out/' + k: v for k, v in ret.items()})
 
 
+def dataset_items():
+  """nerfies.datasets.nerfies.NerfiesDataSource (the real class) reading a capture written by
+  nerfies_amd.datasets.write_synthetic_scene: ids, metadata vocabularies, per-item camera / rgb / metadata, points, and
+  datasets.core.camera_to_rays of one loaded camera.  (cv2.imdecode is stood in for by PIL; the tf.data iterators are
+  outside the shim.)"""
+  import tempfile
+  from nerfies.datasets import core as ref_core
+  from nerfies.datasets import nerfies as ref_ds
+  from nerfies_amd import datasets as mine
+  d = tempfile.mkdtemp()
+  ids = mine.write_synthetic_scene(d, num_frames=5, size=(16, 12), image_scale=2, seed=3)
+  src = ref_ds.NerfiesDataSource(d, image_scale=2, use_appearance_id=True, use_camera_id=True, use_warp_id=True, random_seed=5)
+  out = dict(train_ids=np.array(src.train_ids), val_ids=np.array(src.val_ids), appearance_ids=np.array(src.appearance_ids),
+             camera_ids=np.array(src.camera_ids), warp_ids=np.array(src.warp_ids), near=src.near, far=src.far,
+             points=src.load_points())
+  for i in ids:
+    item = src.get_item(i)
+    for k, v in item['camera_params'].items():
+      out[f'{i}/camera/{k}'] = np.asarray(v)
+    out[f'{i}/rgb'] = item['rgb']
+    out[f'{i}/metadata'] = np.array([item['metadata'][k] for k in ('appearance', 'camera', 'warp')])
+  rays = ref_core.camera_to_rays(src.load_camera(ids[2]))
+  out.update({'rays/' + k: v for k, v in rays.items()})
+  save('dataset_items', **out)
+
+
 def losses_and_schedules():
   sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
   out = dict(sq=sq, gl_m2_c03=ref_utils.general_loss_with_squared_residual(sq, alpha=-2.0, scale=0.03),
@@ -292,5 +318,6 @@ if __name__ == '__main__':
   nerf_model()
   background_loss()
   render_image()
+  dataset_items()
   losses_and_schedules()
   cameras()

@@ -180,6 +180,35 @@ def test_render_image_tiling_matches_reference():
       close(out[k], r['out/' + k], 1e-12)
 
 
+def test_dataset_reader_matches_reference_datasource(tmp_path):
+  """nerfies_amd.datasets.NerfiesDataSource against the reference's own NerfiesDataSource (run under the shim) on the
+  same synthetic capture: ids, metadata vocabularies and table rows, per-item camera (rescaled + scene-normalised),
+  decoded rgb, background points; and the oracle's camera_to_rays against datasets.core.camera_to_rays."""
+  from nerfies_amd import datasets
+  from oracle import camera_oracle as CO
+  r = ref('dataset_items')
+  d = str(tmp_path / 'cap')
+  ids = datasets.write_synthetic_scene(d, num_frames=5, size=(16, 12), image_scale=2, seed=3)
+  src = datasets.NerfiesDataSource(d, image_scale=2, use_appearance_id=True, use_camera_id=True, use_warp_id=True, random_seed=5)
+  assert src.train_ids == list(r['train_ids']) and src.val_ids == list(r['val_ids'])
+  assert src.appearance_ids == tuple(r['appearance_ids']) and src.camera_ids == tuple(r['camera_ids'])
+  assert src.warp_ids == tuple(r['warp_ids']) and (src.near, src.far) == (float(r['near']), float(r['far']))
+  np.testing.assert_array_equal(src.load_points(), r['points'])
+  for i in ids:
+    item = src.get_item(i)
+    for k, v in item['camera'].get_parameters().items():
+      np.testing.assert_allclose(np.asarray(v, np.float64), r[f'{i}/camera/{k}'].astype(np.float64), rtol=1e-6, atol=1e-7, err_msg=f'{i} {k}')
+    np.testing.assert_array_equal(item['rgb'], r[f'{i}/rgb'])
+    assert [item['metadata'][k] for k in ('appearance', 'camera', 'warp')] == list(r[f'{i}/metadata'])
+  cam = src.load_camera(ids[2])
+  ocam = CO.make_camera(cam.orientation, cam.position, cam.focal_length, cam.principal_point, [int(v) for v in cam.image_size],
+                        cam.skew, cam.pixel_aspect_ratio, cam.radial_distortion, cam.tangential_distortion)
+  rays = CO.camera_to_rays(ocam)
+  np.testing.assert_allclose(rays['origins'], r['rays/origins'], atol=1e-7)
+  np.testing.assert_allclose(rays['directions'], r['rays/directions'], atol=2e-6)      # the reference computes these in float32
+  np.testing.assert_array_equal(rays['pixels'], r['rays/pixels'])
+
+
 # ---- camera geometry and schedules (SURVEY.md 8f ranks 2-3) ----
 def _oracle_camera(r, tag, focal=None, pp=None, size=(320, 240), skew=None, par=None):
   from oracle import camera_oracle as CO

@@ -215,6 +215,25 @@ def test_adam_first_step_is_lr_sign():
   np.testing.assert_allclose(p1.numpy(), -1e-3 * np.sign(g.numpy()), rtol=1e-6)
 
 
+def test_adam_matches_an_independent_implementation_over_steps():
+  """flax.optim.Adam is absent here; torch.optim.Adam implements the same published rule (bias-corrected moments,
+  eps added to sqrt(v_hat)) independently: ten steps with changing gradients and a changing learning rate."""
+  g = torch.Generator().manual_seed(0)
+  p0 = torch.randn(50, dtype=F64, generator=g)
+  ref_p = p0.clone().requires_grad_(True)
+  opt = torch.optim.Adam([ref_p], lr=1e-3, betas=(0.9, 0.999), eps=1e-8)
+  p, m, v = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+  for step in range(10):
+    grad = torch.randn(50, dtype=F64, generator=g) * (1.0 + step)
+    lr = 1e-3 * 0.9 ** step
+    for group in opt.param_groups:
+      group['lr'] = lr
+    ref_p.grad = grad.clone()
+    opt.step()
+    p, m, v = O.adam_update(p, m, v, grad, step, lr)
+    np.testing.assert_allclose(p.numpy(), ref_p.detach().numpy(), rtol=0, atol=1e-14)
+
+
 def _small_spec(**kw):
   base = dict(num_coarse_samples=8, num_fine_samples=8, nerf_trunk_width=16,
               nerf_rgb_branch_width=8, num_nerf_point_freqs=3, num_nerf_viewdir_freqs=2,

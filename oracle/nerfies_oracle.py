@@ -8,7 +8,8 @@ stand-ins (oracle/_shim: jax.numpy -> numpy, a minimal eager flax.linen,
 jax.random -> supplied arrays, jax.jacfwd -> central differences).  Their outputs
 are committed as tests/golden/ref_*.npz (tests/golden/make_reference_vectors.py)
 and this restatement reproduces them to 1e-8..1e-12, including NerfModel.apply end
-to end with the warp field (tests/test_reference_vectors.py).  Not covered by that
+to end with the warp field, SE3Field / TranslationField with their Jacobians,
+compute_elastic_loss and compute_background_loss (tests/test_reference_vectors.py).  Not covered by that
 route: reverse-mode gradients (no autodiff in the shim) -- those are torch.autograd
 on the pinned forward, checked by finite differences
 (tests/test_oracle_known_answers.py) -- and XLA's float32 evaluation order.

@@ -15,7 +15,10 @@
  *     allocates, frees or synchronises per call (hipGraph-capture safe).
  *   - all work is enqueued on the caller's hipStream_t (passed as void*).
  *   - every entry returns 0 on success or a negative NRF_E_* code; nothing
- *     throws or aborts.  nrf_last_error() returns a static message.
+ *     throws or aborts.  nrf_last_error() returns the message of the last failing
+ *     call MADE BY THE CALLING THREAD (thread-local storage; valid until that thread's
+ *     next failing call).  Handles carry no error state, so one handle may be driven
+ *     from several threads (on distinct workspaces) without their errors mixing.
  *   - fp32 everywhere (the reference computes in fp32); ids are int32.
  */
 #ifndef NERFIES_AMD_H_
@@ -28,7 +31,8 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 101 /* 0.1.1: nrf_model_desc.warp_field_type, nrf_camera_* */
+#define NRF_VERSION 200 /* 0.2.0: alpha condition, pre-encoded metadata, warp Jacobian output, noise_std, warp_reg loss,
+                           elastic loss types, time metadata encoder, stats[16], bf16 training */
 
 enum {
   NRF_OK = 0,
@@ -42,6 +46,7 @@ enum {
 
 enum { NRF_ACT_RELU = 0, NRF_ACT_SOFTPLUS = 1 };
 enum { NRF_WARP_SE3 = 0, NRF_WARP_TRANSLATION = 1 };   /* ModelConfig.warp_field_type (configs.py:99-100) */
+enum { NRF_META_GLO = 0, NRF_META_TIME = 1 };           /* ModelConfig.warp_metadata_encoder_type (configs.py:101) */
 
 /* Every NerfModel attribute that reaches the hot path (models.py:75-119), as
  * POD.  Defaults are those of configs.ModelConfig (configs.py:35-105). */
@@ -80,6 +85,11 @@ typedef struct nrf_model_desc {
   int32_t num_warp_features;
   int32_t warp_field_type;         /* NRF_WARP_SE3 (warping.py:202-389, every preset) or NRF_WARP_TRANSLATION
                                       (warping.py:62-199, the dataclass default): leaves warp_field/mlp/... */
+  float noise_std;                 /* models.py:80, model_utils.noise_regularize (model_utils.py:266-282): N(0, noise_std) added to
+                                      the raw density when > 0 and use_stratified_sampling; 0 = off (every preset) */
+  int32_t warp_metadata_encoder_type; /* NRF_META_GLO (every preset) or NRF_META_TIME: modules.TimeEncoder on
+                                      metadata['time'] (modules.py:297-322, warping.py:256-259, models.py:252-254) */
+  int32_t num_time_encoder_freqs;  /* metadata_encoder_num_freqs (warping.py:234): 1 */
 } nrf_model_desc;
 
 typedef struct nrf_handle_s* nrf_handle;
@@ -104,12 +114,18 @@ typedef struct nrf_rays {
   const int32_t* warp_ids;       /* (B,) metadata['warp'] or NULL */
   const int32_t* appearance_ids; /* (B,) or NULL */
   const int32_t* camera_ids;     /* (B,) or NULL */
+  /* metadata_encoded=True (models.py:198-199, 210-211, 251; warping.py:378-381): the per-ray codes themselves instead
+   * of ids into the embedding tables.  A non-NULL *_codes pointer replaces the matching *_ids.  Inference only. */
+  const float* warp_codes;       /* (B, num_warp_features) */
+  const float* appearance_codes; /* (B, num_appearance_features) */
+  const float* camera_codes;     /* (B, num_camera_features) */
+  const float* time;             /* (B,) metadata['time'] in [-1,1] (datasets/core.py:272-274); NRF_META_TIME only */
 } nrf_rays;
 
 /* warp_extra + the per-step scalars of training.ScalarParams (training.py:35-43). */
 typedef struct nrf_step_scalars {
   float warp_alpha; /* warp_extra['alpha'] */
-  float time_alpha; /* accepted, unused (no preset selects the time encoder) */
+  float time_alpha; /* warp_extra['time_alpha']: annealing of the TimeEncoder's posenc (NRF_META_TIME) */
 } nrf_step_scalars;
 
 /* Stand-in for the flax RNG streams 'coarse' / 'fine' (models.py:333,355).
@@ -120,6 +136,10 @@ typedef struct nrf_rand {
   const float* u;      /* (B,N_f) in [0,1) or NULL */
   uint64_t seed;
   uint64_t offset;
+  /* noise_std > 0: explicit standard normals for model_utils.noise_regularize, (B,N_c) and (B,N_c+N_f), or NULL ->
+   * Philox (streams 2, 3) + Box-Muller */
+  const float* noise_coarse;
+  const float* noise_fine;
 } nrf_rand;
 
 /* One level of the NerfModel output dict (models.py:278-287). Any pointer may
@@ -133,6 +153,8 @@ typedef struct nrf_level_out {
   float* z_vals;    /* (B,S)  (extra: the sample depths of this level) */
   float* points;        /* (B,S,3) sample points before the warp (return_points, models.py:250-251) */
   float* warped_points; /* (B,S,3) after SE3Field (models.py:266-267); both need use_warp */
+  float* warp_jacobian; /* (B,S,3,3) jax.jacfwd(SE3Field.warp) per sample, row-major d x'_i / d x_j (warping.py:385-387,
+                           models.py:264-265); needs NRF_FLAG_WARP_JACOBIAN in flags and in nrf_workspace_bytes */
 } nrf_level_out;
 
 typedef struct nrf_outputs {
@@ -143,8 +165,10 @@ typedef struct nrf_outputs {
 /* flags for nrf_forward / nrf_workspace_bytes */
 #define NRF_FLAG_TRAIN 1u   /* keep the activation stash nrf_backward needs */
 #define NRF_FLAG_NO_WARP 2u /* NerfModel.__call__(use_warp=False) (models.py:296) */
-#define NRF_FLAG_BF16 4u    /* inference only: NeRF-MLP operands in bfloat16 (fp32 accumulate, fp32 composite); an opt-in
-                               mode with no reference counterpart (BASELINE config D) -- ~1e-2 on rendered colour */
+#define NRF_FLAG_BF16 4u    /* NeRF-MLP operands in bfloat16 (fp32 accumulate, fp32 master weights / posenc / warp / composite /
+                               loss / Adam); an opt-in mode with no reference counterpart (BASELINE config D) -- ~1e-2 on
+                               rendered colour */
+#define NRF_FLAG_WARP_JACOBIAN 8u /* return_warp_jacobian (models.py:297): forward-mode tangent pass of the warp per level */
 
 int nrf_version(void);
 const char* nrf_last_error(void);
@@ -178,8 +202,9 @@ int nrf_backward(nrf_handle h, const float* params, const nrf_rays* rays,
 
 /* training.train_step up to (excluding) pmean + Adam (training.py:168-265):
  * forward, loss = MSE_coarse + MSE_fine (training.py:172,261), backward.
- * target_rgb (B,3).  stats[8] (device): {mse_coarse, mse_fine, psnr_coarse,
- * psnr_fine, loss_total, 0,0,0}.  grad_params is OVERWRITTEN. */
+ * target_rgb (B,3).  stats[NRF_NUM_STATS] (device): {mse_coarse, mse_fine, psnr_coarse,
+ * psnr_fine, loss_total, 0...}.  grad_params is OVERWRITTEN. */
+#define NRF_NUM_STATS 16
 int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* rays,
                              const float* target_rgb, const nrf_step_scalars* scalars,
                              const nrf_rand* rnd, float* grad_params, float* stats,
@@ -206,22 +231,38 @@ typedef struct nrf_background {
  * model_utils.compute_depth_index) -> mean over rays, times loss_weight.  The gradient
  * (reverse over the forward-mode Jacobian, incl. exp_se3's second derivatives) is added to grad_params. */
 enum { NRF_ELASTIC_WEIGHT = 0, NRF_ELASTIC_MEDIAN = 1 };
+/* elastic_loss_type (training.py:86-109): sq_residual = sum log(max(s,eps))^2 | sum (s-1)^2 | sum((J J^T - I)^2)/4 |
+ * div(J)^2 | (det J - 1)^2 | log(max(det J, eps))^2.  'nr' (nearest rotation) is not built: the reference marks it as
+ * producing NaNs (training.py:58). */
+enum { NRF_ELASTIC_LOG_SVALS = 0, NRF_ELASTIC_SVALS = 1, NRF_ELASTIC_JTJ = 2, NRF_ELASTIC_DIV = 3, NRF_ELASTIC_DET = 4,
+       NRF_ELASTIC_LOG_DET = 5 };
 typedef struct nrf_elastic {
   float loss_weight;      /* scalar_params.elastic_loss_weight */
-  int32_t reduce_method;  /* NRF_ELASTIC_* */
+  int32_t reduce_method;  /* NRF_ELASTIC_WEIGHT / NRF_ELASTIC_MEDIAN */
   float eps;              /* 1e-6 */
   float loss_alpha;       /* -2 (training.py:112-113) */
   float loss_scale;       /* 0.03 */
+  int32_t loss_type;      /* NRF_ELASTIC_LOG_SVALS ... */
 } nrf_elastic;
 
-/* nrf_train_step_loss_grad + the regularisers (bg and/or el may be NULL).  stats[5] = mean background loss
+/* use_warp_reg_loss (training.py:199-212), both levels: general_loss(|points - warped_points|^2 at the sample of
+ * model_utils.compute_depth_index(stop_gradient(weights)), alpha, scale), mean over rays, times loss_weight. */
+typedef struct nrf_warp_reg {
+  float loss_weight;      /* scalar_params.warp_reg_loss_weight */
+  float loss_alpha;       /* scalar_params.warp_reg_loss_alpha (-2) */
+  float loss_scale;       /* scalar_params.warp_reg_loss_scale (0.001) */
+} nrf_warp_reg;
+
+/* nrf_train_step_loss_grad + the regularisers (bg, el, wr may each be NULL).  stats[5] = mean background loss
  * (unweighted, training.py:259), stats[6] = elastic loss (unweighted, training.py:195), stats[7] = mean elastic
- * residual (training.py:196); stats[4] includes the weighted terms.  The workspace must come from
- * nrf_workspace_bytes_ex with the same num_background_points / use_elastic_loss. */
+ * residual (training.py:196), stats[8], stats[9] = warp_reg loss coarse / fine (training.py:210), stats[10], stats[11] =
+ * mean warp_reg residual coarse / fine (:211), stats[12..14] = mean det / div / |curl| of the coarse warp Jacobian
+ * (training.py:214-222, with el); stats[4] includes the weighted terms.  The workspace must come from
+ * nrf_workspace_bytes_ex with the same num_background_points / use_elastic_loss.  flags: 0 or NRF_FLAG_BF16. */
 int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
                                 const nrf_step_scalars* scalars, const nrf_rand* rnd, const nrf_background* bg,
-                                const nrf_elastic* el, float* grad_params, float* stats, void* workspace,
-                                size_t workspace_bytes, void* stream);
+                                const nrf_elastic* el, const nrf_warp_reg* wr, uint32_t flags, float* grad_params,
+                                float* stats, void* workspace, size_t workspace_bytes, void* stream);
 int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points,
                            int32_t use_elastic_loss, size_t* bytes);
 
@@ -259,10 +300,13 @@ int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n);
  * tiles, wall-clock ticks (100 MHz)}.  Synchronous (hipMemcpy); out may be NULL to query *n. */
 int nrf_debug_wgrad_segments(nrf_handle h, const void* workspace, double* out, int32_t* n);
 
-/* Test aid: float offset inside the workspace of an internal buffer of `level` (0 coarse, 1 fine) for the
- * last planned (num_rays, flags): "st_pe", "st_h", "st_bn", "st_rgbh", "dy_trunk", "dy_bn", "dy_rgbh",
- * "d_raw4", "z", "out4", "wpoints", "d_points", "w_st_win", "w_st_h", "w_st_wv", "w_dy", "w_dw4", "w_dv4".
- * Stash tiles are [features][64 rows] in fragment order (csrc/chain_common.h frag_index). */
+/* Test aid: float offset inside the workspace of an internal buffer of `level` (0 coarse, 1 fine, 2 background
+ * points, 3 Jacobian tangents) for the last planned (num_rays, flags): "st_pe", "st_h", "st_bn", "st_rgbh",
+ * "dy_trunk", "dy_bn", "dy_rgbh", "d_raw4", "z", "out4", "wpoints", "d_points", "w_st_win", "w_st_h", "w_st_wv",
+ * "w_dy", "w_dw4", "w_dv4", "bits_trunk", "bits_rgbh", "w_bits".
+ * Stash tiles are [features][64 rows] in fragment order (csrc/chain_common.h frag_index); the ReLU sign bits are one
+ * uint32 per (tile, wave, lane, column block): nibble q, bit e <-> tile row 4 * ((q&1) + 2*(lane>>5) + 4*(q>>1)) + e of
+ * feature wave * 32 * NCB + 32 * cb + (lane & 31)  (NCB = 2 for the 256-wide trunk, 1 otherwise). */
 int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* float_offset);
 
 /* ---- individual operators (same device code the fused path runs), exposed so

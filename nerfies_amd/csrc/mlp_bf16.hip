@@ -14,6 +14,7 @@
 #include <stdlib.h>
 
 #include "chain_common.h"
+#include "philox.h"
 
 namespace nrf {
 
@@ -323,7 +324,10 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         o.x = 1.f / (1.f + expf(-acc1[g][0][0]));
         o.y = 1.f / (1.f + expf(-acc1[g][0][1]));
         o.z = 1.f / (1.f + expf(-acc1[g][0][2]));
-        o.w = bf_sigma(alpha_raw[g], A.sigma_act);
+        float araw = alpha_raw[g];
+        if (A.noise_std > 0.f)   // model_utils.noise_regularize (model_utils.py:266-282)
+          araw += A.noise_std * (A.noise ? A.noise[row[g]] : philox_normal(A.noise_seed, A.noise_offset, A.noise_stream, (uint32_t)row[g]));
+        o.w = bf_sigma(araw, A.sigma_act);
         A.out4[row[g]] = o;
       }
   }

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "chain_common.h"
+#include "philox.h"
 
 namespace nrf {
 
@@ -135,9 +136,10 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
       STAMP();   // epilogue of layer l done
     }
 
-    // ---- alpha head: Dense(256->1) on the trunk output (modules.py:152-157) ----
+    // ---- alpha head: Dense(256->1) on the trunk output, or -- use_alpha_condition -- Dense(256+A->1) on
+    //      [bottleneck, appearance code] with the per-ray code term from ray_prep (modules.py:152-157) ----
     float sigma_raw = 0.f;
-    {
+    auto alpha_head = [&]() {
       // weights in chunks of 16 (wave-uniform -> one s_load_dwordx16 per chunk instead of a scalar load and a
       // wait per k), activations as 16 independent LDS reads
       const float4* __restrict__ wa4 = reinterpret_cast<const float4*>(prm + A.po.alpha_k) + part * 16;
@@ -161,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
       __syncthreads();
       if (part == 0)
         sigma_raw = (pe[p] + pe[TILE_ROWS + p]) + (pe[2 * TILE_ROWS + p] + pe[3 * TILE_ROWS + p]) + prm[A.po.alpha_b];
-    }
+    };
+    if (!A.alpha_ct) alpha_head();
 
     STAMP();   // alpha head done
     // ---- bottleneck: Dense(256), no activation (modules.py:149-150) ----
@@ -173,6 +176,10 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     fwd_epilogue<2, EPI_LINEAR, STASH>(
         acc, wave * 64, act,
         make_rsrc(STASH ? A.st_bn + (size_t)tile * FRAG_TILE_256 : nullptr, FRAG_TILE_256 * 4), wv_soff, nullptr, lane);
+    if (A.alpha_ct) {
+      alpha_head();   // the scratch is next written by the rgb logits, two barriers further on
+      if (part == 0) sigma_raw += A.alpha_ct[min((tile * TILE_ROWS + p) / A.S, A.B - 1)];
+    }
 
     STAMP();   // bottleneck done
     // ---- rgb branch hidden: Dense(256+R -> 128)+ReLU; the R per-ray condition columns are
@@ -244,6 +251,11 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
                  prm[A.po.logit_b + c];
         float4 o;
         o.x = 1.f / (1.f + expf(-t[0])); o.y = 1.f / (1.f + expf(-t[1])); o.z = 1.f / (1.f + expf(-t[2]));
+        if (A.noise_std > 0.f) {   // model_utils.noise_regularize (model_utils.py:266-282)
+          const int row = tile * TILE_ROWS + p;
+          const float nz = A.noise ? A.noise[min(row, A.rows - 1)] : philox_normal(A.noise_seed, A.noise_offset, A.noise_stream, (uint32_t)row);
+          sigma_raw = __fadd_rn(sigma_raw, __fmul_rn(nz, A.noise_std));
+        }
         o.w = sigma_activation(sigma_raw, A.sigma_act);
         A.out4[(size_t)tile * TILE_ROWS + p] = o;
       }
@@ -380,10 +392,15 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const int n = wave * 64 + 32 * cb + j;
+        const float wab = A.alpha_on_bn ? prm[A.po.alpha_k + n] : 0.f;   // use_alpha_condition: the alpha head reads the bottleneck
         float bsum = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          const float4 v = acc_piece<2>(acc, cb, q);
+          float4 v = acc_piece<2>(acc, cb, q);
+          if (A.alpha_on_bn) {
+            const float4 ds = *reinterpret_cast<const float4*>(dr + 3 * TILE_ROWS + 4 * q_granule(q, h));
+            v.x = fmaf(ds.x, wab, v.x); v.y = fmaf(ds.y, wab, v.y); v.z = fmaf(ds.z, wab, v.z); v.w = fmaf(ds.w, wab, v.w);
+          }
           bsum += (v.x + v.y) + (v.z + v.w);
           *reinterpret_cast<float4*>(act + act_addr(n, q_granule(q, h))) = v;
           buf_store4(v, dy, lane * 16, wv + (cb * 8 + q) * 1024);
@@ -412,7 +429,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const int n = wave * 64 + 32 * cb + j;
-        const float wa = (l == TRUNK_DEPTH) ? prm[A.po.alpha_k + n] : 0.f;
+        const float wa = (l == TRUNK_DEPTH && !A.alpha_on_bn) ? prm[A.po.alpha_k + n] : 0.f;
         float bsum = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

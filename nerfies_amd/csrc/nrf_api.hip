@@ -33,6 +33,7 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 struct LevelWs {   // float offsets from the workspace base, per level (0 = coarse, 1 = fine)
   size_t wpk, z, out4, rgb, depth, med, acc, weights, condterm;
+  size_t alpha_ct = 0, dsig_ray = 0;   // use_alpha_condition: per-ray code term of the alpha head / per-ray sum of d raw sigma
   size_t bf_wpk = 0;   // bf16 weight stream of the NRF_FLAG_BF16 forward (inference plans)
   size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
@@ -59,6 +60,8 @@ struct WsPlan {
   size_t bg_loss;       // [64] background-loss accumulator
   size_t el_sums;       // [64] elastic-loss / residual accumulators
   size_t el_coef;       // [B][N_c] one-hot sample selector of elastic_reduce_method 'median'
+  size_t wr_sums = 0;   // [64] warp_reg loss / residual accumulators (coarse: 0, 1; fine: 2, 3)
+  size_t t_codes = 0, t_dcodes = 0, t_in = 0, t_h = 0, t_dpre = 0;   // TimeEncoder: codes [B][G], their gradient, stashes
   size_t counters;      // [64] ints: dynamic tile counters of the chain kernels, zeroed at the start of forward / backward
   size_t timeline;      // [2 levels][4 waves][64] uint64 debug stamps of workgroup 0 of the forward chain kernel
   size_t seg_clock;     // [nsegs] uint64 wall-clock ticks per wgrad segment (cost-model calibration)
@@ -67,6 +70,7 @@ struct WsPlan {
   LevelWs L[4];          // 0 coarse, 1 fine, 2 background points (SE3 field only, training.py:117-135),
                          // 3 tangent pass of the coarse warp Jacobian (elastic regulariser, 3 x coarse tiles)
   int elastic = 0;       // plan built with the elastic regulariser's buffers
+  int tg_tiles_per = 0;  // primal tiles one tangent pass covers (elastic: coarse level; Jacobian output: the larger level)
   int bgN = 0;           // number of background points the plan was built for
   size_t total_floats;
   std::vector<PackDesc> pack;
@@ -127,10 +131,14 @@ struct nrf_handle_s {
   PackOffsets pk;
   int64_t app_off = -1, cam_off = -1;
   int P, PK, R, V, app_in_cond, nlevels;
+  int A = 0;   // width of the alpha condition (use_appearance_metadata && use_alpha_condition: the appearance code)
   bool warp = false;
   WarpParamOffsets wpo;
   WarpPackOffsets wpk;
   int Fw = 0, G = 0, Win = 0, PKw = 0;
+  bool time_enc = false;   // warp_metadata_encoder_type 'time': the codes come from modules.TimeEncoder instead of a GLO table
+  int Ft = 0, Tin = 0;
+  TimeParamOffsets tpo;
   int num_cus = 256;
   bool cu_queried = false;
   WsPlan plan;
@@ -204,14 +212,25 @@ void build_layout(nrf_handle h) {
     add_leaf(h, base + "/MLP_1/hidden_0/bias", 1, RW, &po.rgbh_b, 1, XRW);
     add_leaf(h, base + "/MLP_1/logit/kernel", RW, 3, &po.logit_k, XRW, 3);
     add_leaf(h, base + "/MLP_1/logit/bias", 1, 3, &po.logit_b);
-    add_leaf(h, base + "/MLP_2/logit/kernel", W, 1, &po.alpha_k, XW, 1);
+    add_leaf(h, base + "/MLP_2/logit/kernel", W + h->A, 1, &po.alpha_k, XW + h->A, 1, XW);   // [bottleneck | appearance code] (modules.py:152-157)
     add_leaf(h, base + "/MLP_2/logit/bias", 1, 1, &po.alpha_b);
   }
   if (h->warp) {   // warping.SE3Field (warping.py:202-320); flax names per SURVEY.md A.2
     WarpParamOffsets& w = h->wpo;
     WarpParamOffsets& x = h->xwpo;
-    add_leaf(h, "warp_field/metadata_encoder/embed/embedding", d.num_warp_embeddings, d.num_warp_features, &w.embed, -1, -1, -1,
-             &x.embed);
+    if (h->time_enc) {   // modules.TimeEncoder (modules.py:297-322): self.mlp = MLP(depth 6, width 64, skips (4,), output G)
+      w.embed = x.embed = -1;
+      for (int i = 0; i < TIME_DEPTH; ++i) {
+        const int fin = i == 0 ? h->Tin : i == TIME_SKIP ? TIME_W + h->Tin : TIME_W;
+        add_leaf(h, "warp_field/metadata_encoder/mlp/hidden_" + std::to_string(i) + "/kernel", fin, TIME_W, &h->tpo.k[i]);
+        add_leaf(h, "warp_field/metadata_encoder/mlp/hidden_" + std::to_string(i) + "/bias", 1, TIME_W, &h->tpo.b[i]);
+      }
+      add_leaf(h, "warp_field/metadata_encoder/mlp/logit/kernel", TIME_W, d.num_warp_features, &h->tpo.lk);
+      add_leaf(h, "warp_field/metadata_encoder/mlp/logit/bias", 1, d.num_warp_features, &h->tpo.lb);
+    } else {
+      add_leaf(h, "warp_field/metadata_encoder/embed/embedding", d.num_warp_embeddings, d.num_warp_features, &w.embed, -1, -1, -1,
+               &x.embed);
+    }
     // TranslationField (warping.py:62-199) = the same 6x128 trunk with ONE 3-channel output layer and x' = x + t:
     // exactly the SE3 field with a zero rotation head (theta = 0: R = I, p = v; the closed forms are series in
     // theta^2 there).  Its leaves 'warp_field/mlp/hidden_i' / 'mlp/logit' map onto trunk / branches_v; branches_w
@@ -279,11 +298,16 @@ int* tile_counter_or_null(float* base, int idx) {
 constexpr int BG = 2;   // level index of the background-point batch
 constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coarse tiles)
 
+constexpr uint32_t PLAN_FLAGS = NRF_FLAG_TRAIN | NRF_FLAG_WARP_JACOBIAN;   // the flags a workspace layout depends on
+
 void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 0) {
   WsPlan& p = h->plan;
+  flags &= PLAN_FLAGS;
   if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic) return;
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
+  const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) && h->warp;   // tangent pass in an inference plan
+  const bool wstash = train || jac;                                // the warp kernels keep their input / sign-bit stash
   p = WsPlan();
   p.B = B;
   p.flags = flags;
@@ -297,7 +321,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     p.rows[lv] = lv == BG ? bgN : B * p.S[lv];
     p.ntiles[lv] = (p.rows[lv] + TILE_ROWS - 1) / TILE_ROWS;
   }
-  p.ntiles[TG] = elastic ? 3 * p.ntiles[0] : 0;
+  p.tg_tiles_per = jac ? p.ntiles[h->nlevels - 1] : elastic ? p.ntiles[0] : 0;   // Jacobian output: levels run one after the other
+  p.ntiles[TG] = 3 * p.tg_tiles_per;
   p.rows[TG] = p.ntiles[TG] * TILE_ROWS;
   const int G = h->num_cus;
 
@@ -357,8 +382,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       specs.push_back({lv, SRC_FRAG256, &L.st_bn, FRAG_TILE_256, 256, 8, SRC_FRAG128, &L.dy_rgbh, FRAG_TILE_128, 4, 0,
                        po.rgbh_k, 128, 256, 128, 32, 0, 0});
       // narrow heads on the VALU: alpha (X = h8, vec.w) and rgb logits (X = rgb hidden, vec.xyz)
-      specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, 0, nullptr, 0, 0, 1,
-                       po.alpha_k, 1, 256, 1, 12, (size_t)7 * layer, 0});
+      if (h->A > 0)   // use_alpha_condition: the alpha head reads the bottleneck
+        specs.push_back({lv, SRC_FRAG256, &L.st_bn, FRAG_TILE_256, 256, 8, 0, nullptr, 0, 0, 1, po.alpha_k, 1, 256, 1, 12, 0, 0});
+      else
+        specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, 0, nullptr, 0, 0, 1,
+                         po.alpha_k, 1, 256, 1, 12, (size_t)7 * layer, 0});
       specs.push_back({lv, SRC_FRAG128, &L.st_rgbh, FRAG_TILE_128, 128, 4, 0, nullptr, 0, 0, 3,
                        po.logit_k, 3, 128, 3, 6, 0, 0});
       if (h->warp) add_warp_groups(lv, lv > 0 ? 1 : 0);   // the field is shared by both passes: level 1 accumulates
@@ -474,12 +502,14 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   auto alloc_warp = [&](LevelWs& L, size_t nt) {
     L.wpoints = take(nt * TILE_ROWS * 3);
     L.points_raw = take(nt * TILE_ROWS * 3);
-    if (train) {
-      L.d_points = take(nt * TILE_ROWS * 3);
+    if (wstash) {
       L.w_st_win = take(nt * ((h->PKw + 31) / 32 * 32) * TILE_ROWS);
       L.w_st_h = take(nt * FRAG_TILE_128 * WARP_DEPTH);
       L.w_st_wv = take(nt * TILE_ROWS * 8);
       L.w_bits = take(nt * 4 * 64 * WARP_DEPTH);
+    }
+    if (train) {
+      L.d_points = take(nt * TILE_ROWS * 3);
       L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
       L.w_dw4 = take(nt * TILE_ROWS * 4);
       L.w_dv4 = take(nt * TILE_ROWS * 4);
@@ -501,6 +531,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     L.acc = take(B);
     L.weights = take((size_t)p.rows[lv]);
     L.condterm = take((size_t)B * RGB_W);
+    if (h->A > 0) { L.alpha_ct = take(B); L.dsig_ray = take(B); }
     if (train) {
       L.st_pe = take(nt * PKS * TILE_ROWS);
       L.st_h = take(nt * FRAG_TILE_256 * TRUNK_DEPTH);
@@ -522,6 +553,17 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     alloc_warp(p.L[BG], p.ntiles[BG]);
     p.bg_loss = take(64);
   }
+  if (h->time_enc) {
+    p.t_codes = take((size_t)B * h->G);
+    if (train) {
+      p.t_dcodes = take((size_t)B * h->G);
+      p.t_in = take((size_t)B * TIME_MAX_IN);
+      p.t_h = take((size_t)B * TIME_DEPTH * TIME_W);
+      p.t_dpre = take((size_t)B * TIME_DEPTH * TIME_W);
+    }
+  }
+  if (jac && !train) alloc_warp(p.L[TG], p.ntiles[TG]);
+  if (h->warp && train) p.wr_sums = take(64);
   if (h->warp && elastic && train) {
     alloc_warp(p.L[TG], p.ntiles[TG]);
     p.L[0].el_dw4 = take((size_t)p.ntiles[0] * TILE_ROWS * 4);
@@ -724,13 +766,15 @@ int check_launch(const char* where) {
 int validate_rays(nrf_handle h, const nrf_rays* rays) {
   if (!rays || !rays->origins || !rays->directions) return fail(NRF_E_NULL, "rays / origins / directions is null");
   if (rays->num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
-  if (h->d.use_camera_metadata && !rays->camera_ids) return fail(NRF_E_NULL, "camera_ids required (use_camera_metadata)");
-  if (h->app_in_cond && !rays->appearance_ids) return fail(NRF_E_NULL, "appearance_ids required");
-  if (h->warp && !rays->warp_ids) return fail(NRF_E_NULL, "warp_ids required (use_warp)");
+  if (h->d.use_camera_metadata && !rays->camera_ids && !rays->camera_codes)
+    return fail(NRF_E_NULL, "camera_ids (or camera_codes) required (use_camera_metadata)");
+  if (h->app_in_cond && !rays->appearance_ids && !rays->appearance_codes) return fail(NRF_E_NULL, "appearance_ids (or appearance_codes) required");
+  if (h->warp && !h->time_enc && !rays->warp_ids && !rays->warp_codes) return fail(NRF_E_NULL, "warp_ids (or warp_codes) required (use_warp)");
+  if (h->warp && h->time_enc && !rays->time && !rays->warp_codes) return fail(NRF_E_NULL, "time (or warp_codes) required (warp_metadata_encoder_type 'time')");
   return NRF_OK;
 }
 
-ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train) {
+ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train, const nrf_rand* rnd) {
   const WsPlan& p = h->plan;
   const LevelWs& L = p.L[lv];
   ChainFwdArgs a;
@@ -742,6 +786,12 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
   a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation;
   a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_FWD + lv);
   a.timeline = getenv("NRF_TIMELINE") ? reinterpret_cast<unsigned long long*>(ws + p.timeline) + lv * (256 + 512 + 4 * 2048) : nullptr;
+  a.alpha_ct = h->A > 0 ? ws + L.alpha_ct : nullptr;
+  if (h->d.noise_std > 0.f && h->d.use_stratified_sampling) {   // model_utils.noise_regularize (model_utils.py:266-282)
+    a.noise_std = h->d.noise_std;
+    a.noise = rnd ? (lv == 0 ? rnd->noise_coarse : rnd->noise_fine) : nullptr;
+    a.noise_seed = rnd ? rnd->seed : 0; a.noise_offset = rnd ? rnd->offset : 0; a.noise_stream = 2u + (unsigned)lv;
+  }
   if (train) {
     a.st_pe = ws + L.st_pe; a.st_h = ws + L.st_h; a.st_bn = ws + L.st_bn; a.st_rgbh = ws + L.st_rgbh;
     a.bits_trunk = reinterpret_cast<uint32_t*>(ws + L.bits_trunk);
@@ -782,16 +832,38 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
   WarpFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.params = params; a.po = h->wpo; a.wpk = ws + p.warp_wpk; a.pk = h->wpk;
-  a.zvals = ws + L.z; a.origins = rays->origins; a.directions = rays->directions; a.warp_ids = rays->warp_ids;
+  a.zvals = ws + L.z; a.origins = rays->origins; a.directions = rays->directions;
+  // metadata_encoded (warping.py:378-381): the caller's per-ray codes stand in for the table, row = ray
+  // the same for the TimeEncoder's per-ray output
+  const bool per_ray = rays->warp_codes || h->time_enc;
+  a.warp_ids = per_ray ? nullptr : rays->warp_ids;
+  a.embed_table = rays->warp_codes ? rays->warp_codes : h->time_enc ? ws + p.t_codes : params + h->wpo.embed;
   a.points_out = ws + L.wpoints; a.points_raw = ws + L.points_raw;
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
   a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = alpha;
   a.tile_counter = tile_counter_or_null(ws + p.counters, CT_WARP_FWD + lv);
-  if (train) {
+  if (train) {   // train: here "keep the stash" (training plan, or an inference plan that returns the Jacobian)
     a.st_win = ws + L.w_st_win; a.st_h = ws + L.w_st_h; a.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
     a.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
   }
   return a;
+}
+
+// forward-mode pass of the warp Jacobian of level lv (warping.py:385-387): 3 tangent tiles per primal tile
+void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float alpha, float* ws, int gmul, hipStream_t stream) {
+  const WsPlan& p = h->plan;
+  const LevelWs& L = p.L[lv];
+  const LevelWs& T = p.L[TG];
+  WarpFwdArgs ta = warp_fwd_args(h, lv, params, rays, alpha, ws, true);
+  ta.nt_prim = p.ntiles[lv]; ta.prim_win = ws + L.w_st_win; ta.prim_bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
+  ta.ntiles = 3 * p.ntiles[lv]; ta.rows = ta.ntiles * TILE_ROWS;
+  ta.st_win = ws + T.w_st_win; ta.st_h = ws + T.w_st_h; ta.st_wv = reinterpret_cast<float4*>(ws + T.w_st_wv);
+  ta.bits = nullptr; ta.points_out = ws + T.wpoints; ta.points_raw = nullptr;
+  ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_FWD);
+  const int tgrid = ta.ntiles < gmul * h->num_cus ? ta.ntiles : gmul * h->num_cus;
+  h->prof.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[lv], stream);
+  launch_warp_fwd(ta, true, tgrid, stream);
+  h->prof.end(stream);
 }
 
 int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
@@ -801,7 +873,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   if (!params_x || !ws) return fail(NRF_E_NULL, "params / workspace is null");
   query_device(h);
   const int B = rays->num_rays;
-  build_plan(h, B, flags & NRF_FLAG_TRAIN, bgN, elastic);
+  build_plan(h, B, flags, bgN, elastic);
   WsPlan& p = h->plan;
   if (ws_bytes < p.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (see nrf_workspace_bytes)");
   const nrf_model_desc& d = h->d;
@@ -810,7 +882,13 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   if (warp_on && !scalars) return fail(NRF_E_NULL, "nrf_step_scalars (warp_alpha) required with the warp field");
   if (h->warp && !warp_on && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
   if ((flags & NRF_FLAG_BF16) && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is an inference mode: no bf16 backward is built");
+  if ((flags & NRF_FLAG_BF16) && h->A > 0) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is not built for use_alpha_condition");
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
+  const bool encoded = rays->warp_codes || rays->appearance_codes || rays->camera_codes;
+  if (encoded && train) return fail(NRF_E_UNSUPPORTED, "pre-encoded metadata (metadata_encoded) is an inference input: no gradient flows to the codes");
+  const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) != 0;
+  if (jac && (!warp_on || train)) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_JACOBIAN needs the warp field and an inference call (training consumes the Jacobian through nrf_elastic)");
+  if (!jac && out && (out->coarse.warp_jacobian || out->fine.warp_jacobian)) return fail(NRF_E_STATE, "warp_jacobian outputs need NRF_FLAG_WARP_JACOBIAN");
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
   if (hipMemsetAsync(ws + p.counters, 0, 64 * sizeof(int), stream) != hipSuccess) return fail(NRF_E_HIP, "zero tile counters");
@@ -827,14 +905,34 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   const bool bf16 = flags & NRF_FLAG_BF16;
   if (bf16) launch_bf16_pack(reinterpret_cast<const RcPackDesc*>(ws + p.bf_desc), (int)p.bfpack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
-  launch_ray_prep(params, viewdirs, rays->appearance_ids, rays->camera_ids, B, d.num_nerf_viewdir_freqs, d.use_viewdirs,
-                  h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
-                  d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->R, h->po[0].rgbh_k, h->po[0].rgbh_b,
-                  h->po[h->nlevels - 1].rgbh_k, h->po[h->nlevels - 1].rgbh_b, ws + p.cond, ws + p.L[0].condterm,
-                  h->nlevels > 1 ? ws + p.L[1].condterm : nullptr, stream);
+  {
+    RayPrepArgs ra;
+    memset(&ra, 0, sizeof(ra));
+    ra.params = params; ra.viewdirs = viewdirs;
+    ra.app_ids = rays->appearance_codes ? nullptr : rays->appearance_ids; ra.app_codes = rays->appearance_codes;
+    ra.cam_ids = rays->camera_codes ? nullptr : rays->camera_ids; ra.cam_codes = rays->camera_codes;
+    ra.B = B; ra.Fv = d.num_nerf_viewdir_freqs; ra.use_viewdirs = d.use_viewdirs;
+    ra.app_feat = h->app_in_cond ? d.num_appearance_features : 0; ra.app_off = h->app_off;
+    ra.cam_feat = d.use_camera_metadata ? d.num_camera_features : 0; ra.cam_off = h->cam_off; ra.R = h->R;
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      ra.rgbh_k[lv] = h->po[lv].rgbh_k; ra.rgbh_b[lv] = h->po[lv].rgbh_b; ra.alpha_k[lv] = h->po[lv].alpha_k;
+      ra.condterm[lv] = ws + p.L[lv].condterm;
+      ra.alpha_ct[lv] = h->A > 0 ? ws + p.L[lv].alpha_ct : nullptr;
+    }
+    ra.cond = ws + p.cond;
+    launch_ray_prep(ra, stream);
+  }
   launch_sample_coarse(rnd ? rnd->t_rand : nullptr, B, p.S[0], d.near_plane, d.far_plane, d.use_stratified_sampling,
                        d.use_linear_disparity, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0, ws + p.L[0].z, stream);
   pf.end(stream);
+  if (warp_on && h->time_enc && !rays->warp_codes) {   // modules.TimeEncoder once per ray (warping.py:311-313, models.py:252-254)
+    TimeEncArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.params = params; ta.po = h->tpo; ta.time = rays->time; ta.B = B; ta.F = h->Ft; ta.Tin = h->Tin; ta.G = h->G;
+    ta.alpha = scalars->time_alpha; ta.codes = ws + p.t_codes;
+    if (train) { ta.st_in = ws + p.t_in; ta.st_h = ws + p.t_h; }
+    launch_time_encoder_fwd(ta, stream);
+  }
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
     if (lv == 1) {
@@ -844,26 +942,24 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
                          ws + L.z, stream);
       pf.end(stream);
     }
-    ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train);
+    ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train, rnd);
     const int gmul = getenv("NRF_GRID_MUL") ? atoi(getenv("NRF_GRID_MUL")) : 2;
     const int grid = p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus;   // two workgroups per CU
     if (warp_on) {
       pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * p.rows[lv], stream);
-      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train), train, grid, stream);
+      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train || jac), train || jac, grid, stream);
       pf.end(stream);
       a.points = ws + L.wpoints;
-      if (lv == 0 && train && p.elastic) {   // forward-mode Jacobian of the warp on the coarse samples (models.py:345)
-        const LevelWs& T = p.L[TG];
-        WarpFwdArgs ta = warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, true);
-        ta.nt_prim = p.ntiles[0]; ta.prim_win = ws + L.w_st_win; ta.prim_bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
-        ta.ntiles = p.ntiles[TG]; ta.rows = p.rows[TG];
-        ta.st_win = ws + T.w_st_win; ta.st_h = ws + T.w_st_h; ta.st_wv = reinterpret_cast<float4*>(ws + T.w_st_wv);
-        ta.bits = nullptr; ta.points_out = ws + T.wpoints; ta.points_raw = nullptr;
-        ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_FWD);
-        const int tgrid = p.ntiles[TG] < gmul * h->num_cus ? p.ntiles[TG] : gmul * h->num_cus;
-        pf.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[0], stream);
-        launch_warp_fwd(ta, true, tgrid, stream);
-        pf.end(stream);
+      // forward-mode Jacobian of the warp: on the coarse samples for the elastic regulariser (models.py:345), per level
+      // as an output (return_warp_jacobian, models.py:345-346, 367-368)
+      float* jout = !out ? nullptr : lv == 0 ? out->coarse.warp_jacobian : out->fine.warp_jacobian;
+      if ((lv == 0 && train && p.elastic) || (jac && jout)) launch_tangent_fwd(h, lv, params, rays, scalars->warp_alpha, ws, gmul, stream);
+      if (jac && jout) {
+        JacobianArgs ja;
+        ja.prim_win = ws + L.w_st_win; ja.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+        ja.tan_wv = reinterpret_cast<const float4*>(ws + p.L[TG].w_st_wv); ja.out = jout;
+        ja.rows = p.rows[lv]; ja.rows_pad = p.ntiles[lv] * TILE_ROWS; ja.PKS = (h->PKw + 31) / 32 * 32;
+        launch_jacobian(ja, stream);
       }
     }
     pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
@@ -905,7 +1001,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
 // d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
 int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
                   float* grad_x, float* stats, float* ws, hipStream_t stream, const nrf_background* bg = nullptr,
-                  const nrf_step_scalars* scalars = nullptr, const nrf_elastic* el = nullptr) {
+                  const nrf_step_scalars* scalars = nullptr, const nrf_elastic* el = nullptr, const nrf_warp_reg* wr = nullptr) {
   WsPlan& p = h->plan;
   const nrf_model_desc& d = h->d;
   const int B = p.B;
@@ -921,6 +1017,15 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   if (e != hipSuccess) return fail_hip(e, "zero mse");
   e = hipMemsetAsync(reinterpret_cast<int*>(ws + p.counters) + CT_MLP_BWD, 0, (64 - CT_MLP_BWD) * sizeof(int), stream);
   if (e != hipSuccess) return fail_hip(e, "zero tile counters");
+  if (warp_on && h->time_enc) {
+    e = hipMemsetAsync(ws + p.t_dcodes, 0, (size_t)B * h->G * sizeof(float), stream);
+    if (e != hipSuccess) return fail_hip(e, "zero time-code gradient");
+  }
+  const bool wr_on = wr && warp_on;
+  if (wr_on) {
+    e = hipMemsetAsync(ws + p.wr_sums, 0, 64 * sizeof(float), stream);
+    if (e != hipSuccess) return fail_hip(e, "zero warp_reg sums");
+  }
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
     e = hipMemsetAsync(ws + L.dray, 0, (size_t)B * RGB_W * sizeof(float), stream);
@@ -930,7 +1035,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     launch_composite_bwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
                          d.use_white_background, d.use_sample_at_infinity, d.sigma_activation, ws + L.rgb, target,
                          target ? nullptr : d_rgb[lv], loss_scale, reinterpret_cast<float4*>(ws + L.d_raw4),
-                         p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, stream);
+                         p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, h->A > 0 ? ws + L.dsig_ray : nullptr, stream);
     h->prof.end(stream);
     ChainBwdArgs a;
     memset(&a, 0, sizeof(a));
@@ -943,6 +1048,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     a.small_part = ws + L.small_part;
     if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
     a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
+    a.alpha_on_bn = h->A > 0 ? 1 : 0;
     a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_BWD + lv);
     const int grid = p.ntiles[lv] < 2 * h->num_cus ? p.ntiles[lv] : 2 * h->num_cus;   // two workgroups per CU
     h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
@@ -966,10 +1072,14 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       ea.sums = ws + p.el_sums;
       ea.rows = p.rows[0]; ea.rows_pad = p.ntiles[0] * TILE_ROWS; ea.PKS = (h->PKw + 31) / 32 * 32;
       ea.eps = el->eps; ea.alpha = el->loss_alpha; ea.scale = el->loss_scale; ea.gscale = el->loss_weight / (float)B;
+      ea.loss_type = el->loss_type;
       h->prof.begin("elastic", 0, stream);
       launch_elastic(ea, stream);
       h->prof.end(stream);
     }
+    if (wr_on)   // use_warp_reg_loss (training.py:199-212): + d loss / d warped point at the median-depth sample of each ray
+      launch_warp_reg(ws + L.weights, ws + L.points_raw, ws + L.wpoints, B, p.S[lv], wr->loss_alpha, wr->loss_scale,
+                      wr->loss_weight / (float)B, ws + L.d_points, ws + p.wr_sums + 2 * lv, stream);
     if (warp_on) {
       WarpBwdArgs wa;
       memset(&wa, 0, sizeof(wa));
@@ -980,11 +1090,11 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
       wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
       wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
-      wa.warp_ids = rays->warp_ids;
+      wa.warp_ids = h->time_enc ? nullptr : rays->warp_ids;   // TimeEncoder: the code gradient is per ray
       wa.S = p.S[lv]; wa.B = B; wa.rows = p.rows[lv]; wa.ntiles = p.ntiles[lv];
       wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
       wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
-      wa.grad_embed = grad + h->wpo.embed; wa.small_part = ws + L.w_small_part;
+      wa.grad_embed = h->time_enc ? ws + p.t_dcodes : grad + h->wpo.embed; wa.small_part = ws + L.w_small_part;
       h->prof.begin(lv == 0 ? "warp_dgrad_coarse" : "warp_dgrad_fine", warp_dgrad_flops_row(h) * p.rows[lv], stream);
       launch_warp_bwd(wa, grid, stream);
       h->prof.end(stream);
@@ -1008,7 +1118,18 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     launch_cond_embed_grad(params, ws + L.dray, rays->appearance_ids, rays->camera_ids, B, h->V,
                            h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
                            d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->po[lv].rgbh_k, grad, stream);
+    if (h->A > 0)   // appearance-code rows of the alpha head and the codes' gradient through it (modules.py:152-157)
+      launch_alpha_cond_grad(params, ws + p.cond, ws + L.dsig_ray, rays->appearance_ids, B, h->R, h->V, h->A, h->app_off,
+                             h->po[lv].alpha_k, grad, stream);
     h->prof.end(stream);
+  }
+  if (warp_on && h->time_enc) {   // reverse of the TimeEncoder: d codes -> its six layers' weight gradients
+    TimeEncArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.params = params; ta.po = h->tpo; ta.time = rays->time; ta.B = B; ta.F = h->Ft; ta.Tin = h->Tin; ta.G = h->G;
+    ta.d_codes = ws + p.t_dcodes; ta.st_in = ws + p.t_in; ta.st_h = ws + p.t_h; ta.st_dpre = ws + p.t_dpre;
+    launch_time_encoder_bwd(ta, stream);
+    launch_time_encoder_wgrad(ta, grad, stream);
   }
   // ---- background regulariser (training.compute_background_loss, training.py:117-135): the SE3 field on the
   //      (already noised) background points with one warp id per point; general loss of |x' - x|^2 ----
@@ -1020,6 +1141,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     memset(&fa, 0, sizeof(fa));
     fa.params = params; fa.po = h->wpo; fa.wpk = ws + p.warp_wpk; fa.pk = h->wpk;
     fa.points_in = bg->points; fa.point_ids = bg->warp_ids; fa.points_out = ws + L.wpoints;
+    fa.embed_table = params + h->wpo.embed;
     fa.S = 1; fa.B = p.bgN; fa.rows = p.bgN; fa.ntiles = p.ntiles[BG];
     fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = scalars->warp_alpha;
     fa.st_win = ws + L.w_st_win; fa.st_h = ws + L.w_st_h; fa.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
@@ -1067,9 +1189,19 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     launch_embed(reinterpret_cast<const EmbedDesc*>(tables + p.emb_off_b), (int)h->emb.size(), grad, grad_x, false, stream);
   }
   const bool el_any = el && p.elastic && warp_on;
-  if (stats) launch_finish_stats(ws + p.mse, B, bg_on ? ws + p.bg_loss : nullptr, bg_on ? p.bgN : 0, bg_on ? bg->loss_weight : 0.f,
-                                 el_any ? ws + p.el_sums : nullptr, el_any ? (el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]) : 0, el_any ? el->loss_weight : 0.f, stats,
-                                 stream);
+  if (stats) {
+    StatsArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.mse_sums = ws + p.mse; sa.B = B;
+    if (bg_on) { sa.bg_sum = ws + p.bg_loss; sa.bgN = p.bgN; sa.bg_weight = bg->loss_weight; }
+    if (el_any) {
+      sa.el_sums = ws + p.el_sums; sa.el_rows = el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]; sa.el_jac_rows = p.rows[0];
+      sa.el_weight = el->loss_weight;
+    }
+    if (wr_on) { sa.wr_sums = ws + p.wr_sums; sa.wr_weight = wr->loss_weight; }
+    sa.stats = stats;
+    launch_finish_stats(sa, stream);
+  }
   h->prof.end(stream);
   return check_launch("nrf_backward");
 }
@@ -1090,12 +1222,20 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
     return fail(NRF_E_UNSUPPORTED, "nerf_trunk_width must be in [1,256]");
   if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width < 1 || d.nerf_rgb_branch_width > RGB_W)
     return fail(NRF_E_UNSUPPORTED, "rgb branch must be 1 layer of width <= 128");
-  if (d.use_alpha_condition) return fail(NRF_E_UNSUPPORTED, "use_alpha_condition (alpha-branch conditioning) not built yet");
+  if (d.use_trunk_condition)   // models.py:203-204: never forwarded by construct_nerf, no preset; a silent no-op would change the layout
+    return fail(NRF_E_UNSUPPORTED, "use_trunk_condition (trunk conditioning) is not built");
+  if (d.use_alpha_condition && d.use_appearance_metadata && (d.num_appearance_features < 1 || d.num_appearance_features > 16))
+    return fail(NRF_E_SHAPE, "num_appearance_features must be in [1,16]");
+  if (!(d.noise_std >= 0.f)) return fail(NRF_E_SHAPE, "noise_std must be >= 0");
+  if (d.use_warp && d.warp_metadata_encoder_type != NRF_META_GLO && d.warp_metadata_encoder_type != NRF_META_TIME)
+    return fail(NRF_E_UNSUPPORTED, "warp_metadata_encoder_type must be glo or time ('blend' exists only for the TranslationField, no preset)");
+  if (d.use_warp && d.warp_metadata_encoder_type == NRF_META_TIME && (d.num_time_encoder_freqs < 0 || d.num_time_encoder_freqs > 8))
+    return fail(NRF_E_SHAPE, "num_time_encoder_freqs must be in [0,8]");
   if (d.use_warp) {
     if (d.warp_field_type != NRF_WARP_SE3 && d.warp_field_type != NRF_WARP_TRANSLATION) return fail(NRF_E_UNSUPPORTED, "warp_field_type");
     if (d.num_warp_freqs < 0 || d.num_warp_freqs > 8) return fail(NRF_E_SHAPE, "num_warp_freqs must be in [0,8]");
     if (d.num_warp_features < 1 || d.num_warp_features > 8) return fail(NRF_E_SHAPE, "num_warp_features must be in [1,8]");
-    if (d.num_warp_embeddings < 1) return fail(NRF_E_SHAPE, "num_warp_embeddings must be positive");
+    if (d.num_warp_embeddings < 1 && d.warp_metadata_encoder_type != NRF_META_TIME) return fail(NRF_E_SHAPE, "num_warp_embeddings must be positive");
   }
   if (!d.use_viewdirs && !d.use_camera_metadata) return fail(NRF_E_UNSUPPORTED, "rgb branch needs at least one condition");
   if (d.num_coarse_samples < 3 || d.num_coarse_samples > 256) return fail(NRF_E_SHAPE, "num_coarse_samples must be in [3,256]");
@@ -1111,8 +1251,11 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   h->PK = (h->P + 15) / 16 * 16;                  // K of the posenc GEMMs: whole 16-k quads of the MFMA loop
   h->V = d.use_viewdirs ? 3 + 6 * d.num_nerf_viewdir_freqs : 0;
   h->app_in_cond = (d.use_appearance_metadata && d.use_alpha_condition) ? 1 : 0;   // models.py:206
+  h->A = h->app_in_cond ? d.num_appearance_features : 0;                              // models.py:204-205
   h->warp = d.use_warp != 0;
   if (h->warp) {
+    h->time_enc = d.warp_metadata_encoder_type == NRF_META_TIME;
+    h->Ft = d.num_time_encoder_freqs; h->Tin = 1 + 2 * h->Ft;   // AnnealedSinusoidalEncoder of the scalar time stamp
     h->Fw = d.num_warp_freqs; h->G = d.num_warp_features;
     h->Win = 3 + 6 * h->Fw + h->G;                 // [annealed posenc, GLO code] (warping.py:326-327)
     h->PKw = (h->Win + 15) / 16 * 16;
@@ -1150,7 +1293,7 @@ int nrf_workspace_bytes(nrf_handle h, int32_t num_rays, uint32_t flags, size_t* 
   if (!h || !bytes) return fail(NRF_E_NULL, "null");
   if (num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
   query_device(h);
-  build_plan(h, num_rays, flags & NRF_FLAG_TRAIN);
+  build_plan(h, num_rays, flags);
   *bytes = h->plan.total_floats * sizeof(float);
   return NRF_OK;
 }
@@ -1191,27 +1334,32 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
 
 int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_rays* rays, const float* target_rgb,
                                 const nrf_step_scalars* scalars, const nrf_rand* rnd, const nrf_background* bg,
-                                const nrf_elastic* el, float* grad_params, float* stats, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                const nrf_elastic* el, const nrf_warp_reg* wr, uint32_t flags, float* grad_params, float* stats,
+                                void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
+  if (flags & ~(uint32_t)NRF_FLAG_BF16) return fail(NRF_E_UNSUPPORTED, "nrf_train_step_loss_grad_ex flags: 0 or NRF_FLAG_BF16");
   int bgN = 0;
   if (el) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the elastic regulariser needs the warp field");
     if (el->reduce_method != NRF_ELASTIC_WEIGHT && el->reduce_method != NRF_ELASTIC_MEDIAN)
       return fail(NRF_E_UNSUPPORTED, "unknown elastic reduce_method");
+    if (el->loss_type < NRF_ELASTIC_LOG_SVALS || el->loss_type > NRF_ELASTIC_LOG_DET)
+      return fail(NRF_E_UNSUPPORTED, "unknown elastic loss_type ('nr' is not built: the reference marks it as producing NaNs)");
     if (!scalars) return fail(NRF_E_NULL, "nrf_step_scalars required");
   }
+  if (wr && !h->warp) return fail(NRF_E_UNSUPPORTED, "the warp_reg loss needs the warp field");
   if (bg && bg->num_points > 0) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the background regulariser needs the warp field");
+    if (h->time_enc) return fail(NRF_E_UNSUPPORTED, "the background regulariser draws warp IDS (training.py:121-123): not defined for the time encoder");
     if (!bg->points || !bg->warp_ids) return fail(NRF_E_NULL, "background points / warp_ids is null");
     if (!scalars) return fail(NRF_E_NULL, "nrf_step_scalars required");
     bgN = bg->num_points;
   }
-  CK(forward_impl(h, params, rays, scalars, rnd, nullptr, NRF_FLAG_TRAIN, (float*)workspace, workspace_bytes,
+  CK(forward_impl(h, params, rays, scalars, rnd, nullptr, NRF_FLAG_TRAIN | flags, (float*)workspace, workspace_bytes,
                   (hipStream_t)stream, bgN, el ? 1 : 0));
   const float* dr[2] = {nullptr, nullptr};
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream,
-                       bgN > 0 ? bg : nullptr, scalars, el);
+                       bgN > 0 ? bg : nullptr, scalars, el, wr);
 }
 
 int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points,
@@ -1222,7 +1370,7 @@ int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32
     return fail(NRF_E_UNSUPPORTED, "the background / elastic regularisers need the warp field");
   query_device(h);
   const bool tr = flags & NRF_FLAG_TRAIN;
-  build_plan(h, num_rays, flags & NRF_FLAG_TRAIN, tr ? num_background_points : 0, tr && use_elastic_loss ? 1 : 0);
+  build_plan(h, num_rays, flags, tr ? num_background_points : 0, tr && use_elastic_loss ? 1 : 0);
   *bytes = h->plan.total_floats * sizeof(float);
   return NRF_OK;
 }
@@ -1263,6 +1411,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
                     const nrf_step_scalars* scalars, float* warped, void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !params || !points || !warp_ids || !scalars || !warped || !workspace) return fail(NRF_E_NULL, "null argument");
   if (!h->warp) return fail(NRF_E_UNSUPPORTED, "model has no warp field");
+  if (h->time_enc) return fail(NRF_E_UNSUPPORTED, "nrf_warp_points takes warp ids: not built for the time encoder");
   if (num_points <= 0) return fail(NRF_E_SHAPE, "num_points must be positive");
   query_device(h);
   const WarpPointsPlan q = warp_points_plan(h, num_points);
@@ -1301,6 +1450,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   memset(&a, 0, sizeof(a));
   a.params = params; a.po = wo; a.wpk = ws + q.wpk_f; a.pk = h->wpk;
   a.points_in = points; a.point_ids = warp_ids; a.points_out = ws + q.out_f;
+  a.embed_table = params + wo.embed;
   a.S = 1; a.B = num_points; a.rows = num_points; a.ntiles = q.ntiles;
   a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha;
   const int grid = q.ntiles < 2 * h->num_cus ? q.ntiles : 2 * h->num_cus;
@@ -1340,7 +1490,7 @@ int nrf_profile_read(nrf_handle h, nrf_profile_entry* out, int32_t* n) {
 
 int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* float_offset) {
   if (!h || !name || !float_offset) return fail(NRF_E_NULL, "null");
-  if (level < 0 || level > 1 || h->plan.B < 0) return fail(NRF_E_STATE, "no workspace plan yet / bad level");
+  if (level < 0 || level > 3 || h->plan.B < 0) return fail(NRF_E_STATE, "no workspace plan yet / bad level");
   const LevelWs& L = h->plan.L[level];
   const struct { const char* n; size_t v; } tab[] = {
       {"st_pe", L.st_pe}, {"st_h", L.st_h}, {"st_bn", L.st_bn}, {"st_rgbh", L.st_rgbh}, {"dy_trunk", L.dy_trunk},
@@ -1348,7 +1498,7 @@ int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* 
       {"wpoints", L.wpoints}, {"d_points", L.d_points}, {"w_st_win", L.w_st_win}, {"w_st_h", L.w_st_h},
       {"w_st_wv", L.w_st_wv}, {"w_dy", L.w_dy}, {"w_dw4", L.w_dw4}, {"w_dv4", L.w_dv4},
       {"w_bits", L.w_bits}, {"bits_trunk", L.bits_trunk}, {"bits_rgbh", L.bits_rgbh},
-      {"timeline", h->plan.timeline + (size_t)level * 2 * (256 + 512 + 4 * 2048)}};
+      {"timeline", h->plan.timeline + (size_t)(level & 1) * 2 * (256 + 512 + 4 * 2048)}};
   for (const auto& t : tab)
     if (!strcmp(t.n, name)) { *float_offset = (int64_t)t.v; return NRF_OK; }
   return fail(NRF_E_SHAPE, "unknown workspace buffer name");

@@ -61,6 +61,31 @@ struct WarpPackOffsets {
   int total;
 };
 
+// modules.TimeEncoder (modules.py:297-322): depth 6, width 64, skip at 4 -- the warp field's 'time' metadata encoder
+constexpr int TIME_W = 64;
+constexpr int TIME_DEPTH = 6;
+constexpr int TIME_SKIP = 4;
+constexpr int TIME_MAX_IN = 20;   // 1 + 2 * num_freqs <= 17, padded
+struct TimeParamOffsets {
+  int64_t k[TIME_DEPTH], b[TIME_DEPTH];   // hidden_i kernel [in,64] / bias
+  int64_t lk, lb;                         // logit kernel [64,G] / bias [G]
+};
+struct TimeEncArgs {
+  const float* params;
+  TimeParamOffsets po;
+  const float* time;       // [B] time stamps (metadata['time'])
+  int B, F, Tin, G;        // rays, posenc freqs, 1 + 2F, code width
+  float alpha;             // warp_extra['time_alpha']
+  float* codes;            // [B][G] out
+  const float* d_codes;    // [B][G] (backward)
+  float* st_in;            // [B][TIME_MAX_IN] encoder input (training stash) or nullptr
+  float* st_h;             // [B][6][64] post-ReLU activations or nullptr
+  float* st_dpre;          // [B][6][64] (backward)
+};
+void launch_time_encoder_fwd(const TimeEncArgs& a, hipStream_t stream);
+void launch_time_encoder_bwd(const TimeEncArgs& a, hipStream_t stream);
+void launch_time_encoder_wgrad(const TimeEncArgs& a, float* grad, hipStream_t stream);
+
 // bf16 forward chain (mlp_bf16.hip): one descriptor fills rows of its weight stream
 struct RcPackDesc {
   long long src_off, dst_off;   // params leaf / first row written, in floats from the workspace base
@@ -86,6 +111,15 @@ struct ChainFwdArgs {
   int sigma_act;
   int* tile_counter;         // zeroed before the launch: dynamic tile hand-out (chain_common.h next_tile)
   unsigned long long* timeline;   // debug: [4 waves][64] shader-clock stamps of workgroup 0 (or nullptr)
+  // use_alpha_condition (modules.py:152-157): the alpha head reads [bottleneck, appearance code]; alpha_ct[ray] =
+  // code . W_alpha[256:] (ray_prep), nullptr -> the head reads the trunk output
+  const float* alpha_ct;
+  // model_utils.noise_regularize (model_utils.py:266-282): raw density += noise_std * N(0,1); explicit normals [rows] or
+  // Philox stream `noise_stream` of (seed, offset)
+  const float* noise;
+  float noise_std;
+  unsigned long long noise_seed, noise_offset;
+  unsigned noise_stream;
   // activation stash (training only)
   float* st_pe;              // [ntiles][PK][128]
   float* st_h;               // [8][ntiles][256*128]  h1..h8, fragment-native
@@ -115,6 +149,7 @@ struct ChainBwdArgs {
   const float* st_pe;        // posenc stash of the forward pass
   int F, P, PK;
   int* tile_counter;
+  int alpha_on_bn;           // use_alpha_condition: d raw sigma enters at the bottleneck instead of the trunk output
 };
 
 // SE3Field forward (warping.py:322-353): x = o + z d (or explicit points) -> warped points.
@@ -126,7 +161,8 @@ struct WarpFwdArgs {
   const float* zvals;        // [B*S]
   const float* origins;      // [B][3]
   const float* directions;   // [B][3]
-  const int32_t* warp_ids;   // [B]
+  const int32_t* warp_ids;   // [B], or nullptr: row `ray` of the table (pre-encoded per-ray codes)
+  const float* embed_table;  // [*][G] GLO table inside the parameters, or the per-ray codes (metadata_encoded / TimeEncoder)
   const float* points_in;    // [rows][3] explicit points (then ids are per point) or nullptr
   const int32_t* point_ids;  // [rows] with points_in
   float* points_out;         // [ntiles*128][3] warped points
@@ -154,14 +190,14 @@ struct WarpBwdArgs {
   const float* st_win;
   const float4* st_wv;
   const uint32_t* bits;
-  const int32_t* warp_ids;   // [B]
+  const int32_t* warp_ids;   // [B], or nullptr: row `ray` (per-ray codes of the TimeEncoder)
   const int32_t* point_ids;  // [rows] or nullptr
   int S, B, rows, ntiles;
   int F, G, Win, PKw;
   float* dy;                 // [6][ntiles][128*128] dpre_0..dpre_5
   float4* d_w4;              // [ntiles*128] (dw, 0)
   float4* d_v4;              // [ntiles*128] (dv, 0)
-  float* grad_embed;         // flat gradient + embedding offset (atomics)
+  float* grad_embed;         // embedding-table gradient, or the per-ray code gradient [B][G] (atomics)
   float* small_part;         // [gridDim.x][WARP_SMALL_PART]
   const float4* extra_dw4;   // primal pass: + dL/d(w, v) of the elastic regulariser, or nullptr
   const float4* extra_dv4;
@@ -180,11 +216,21 @@ struct ElasticArgs {
   float4* tan_dv4;
   float4* prim_dw4;          // out [rows_pad]: dL/dw, dL/dv through exp_se3's second derivatives
   float4* prim_dv4;
-  float* sums;               // [2] += sum coef*rho, sum residual
+  float* sums;               // [5] += sum coef*rho, sum residual, sum det J, sum div J, sum |curl J|
   int rows, rows_pad, PKS;
   float eps, alpha, scale;
   float gscale;              // elastic_loss_weight / num_rays
   int res_selected;          // 'median': the residual statistic only counts the selected sample of each ray
+  int loss_type;             // NRF_ELASTIC_LOG_SVALS ...
+};
+
+// warp Jacobian as an output (return_warp_jacobian, models.py:264-265): J = I + d/dx [exp_se3(w, v) x - x]
+struct JacobianArgs {
+  const float* prim_win;
+  const float4* prim_wv;
+  const float4* tan_wv;
+  float* out;                // [rows][3][3]
+  int rows, rows_pad, PKS;
 };
 
 // One split-K slice of a weight-gradient GEMM  dW[k][n] = sum_rows X[row][k] dY[row][n].
@@ -240,16 +286,28 @@ void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
 void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream);
 void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream);
 void launch_elastic(const ElasticArgs& a, hipStream_t stream);
+void launch_jacobian(const JacobianArgs& a, hipStream_t stream);
 void launch_median_coef(const float* weights, int B, int S, float* coef, hipStream_t stream);
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   unsigned long long* seg_clock, hipStream_t stream);
 void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
 
-void launch_ray_prep(const float* params, const float* viewdirs, const int32_t* app_ids,
-                     const int32_t* cam_ids, int B, int Fv, int use_viewdirs, int app_feat,
-                     int64_t app_off, int cam_feat, int64_t cam_off, int R,
-                     int64_t rgbh_k_c, int64_t rgbh_b_c, int64_t rgbh_k_f, int64_t rgbh_b_f,
-                     float* cond, float* condterm_c, float* condterm_f, hipStream_t stream);
+struct RayPrepArgs {
+  const float* params;
+  const float* viewdirs;
+  const int32_t* app_ids;    // [B] or nullptr (then app_codes)
+  const int32_t* cam_ids;
+  const float* app_codes;    // [B][app_feat] pre-encoded (metadata_encoded) or nullptr
+  const float* cam_codes;
+  int B, Fv, use_viewdirs, app_feat, cam_feat, R;
+  int64_t app_off, cam_off;
+  int64_t rgbh_k[2], rgbh_b[2];   // per level (coarse, fine)
+  int64_t alpha_k[2];             // use_alpha_condition: rows 256.. of MLP_2/logit/kernel hold the appearance-code weights
+  float* cond;               // [B][R]
+  float* condterm[2];        // [B][128]; [1] may be nullptr
+  float* alpha_ct[2];        // [B] or nullptr
+};
+void launch_ray_prep(const RayPrepArgs& a, hipStream_t stream);
 void launch_sample_coarse(const float* t_rand, int B, int N, float near_p, float far_p,
                           int stratified, int lindisp, uint64_t seed, uint64_t offset,
                           float* z, hipStream_t stream);
@@ -259,7 +317,13 @@ void launch_composite_fwd(const float4* out4, const float* z, const float* dirs,
 void launch_composite_bwd(const float4* out4, const float* z, const float* dirs, int B, int S,
                           int white_bkgd, int sample_at_inf, int sigma_act, const float* rgb_out,
                           const float* target, const float* d_rgb, float loss_scale,
-                          float4* d_raw4, int rows_pad, float* mse_sum, hipStream_t stream);
+                          float4* d_raw4, int rows_pad, float* mse_sum, float* dsig_ray, hipStream_t stream);
+// use_alpha_condition: gradient of the appearance-code rows of the alpha head and of the codes through it
+void launch_alpha_cond_grad(const float* params, const float* cond, const float* dsig_ray, const int32_t* app_ids, int B, int R,
+                            int V, int app_feat, int64_t app_off, int64_t alpha_k, float* grad, hipStream_t stream);
+// use_warp_reg_loss (training.py:199-212) of one level: adds d loss / d warped point into d_points, sums[0] += loss, sums[1] += residual
+void launch_warp_reg(const float* weights, const float* points, const float* warped, int B, int S, float alpha, float scale,
+                     float gscale, float* d_points, float* sums, hipStream_t stream);
 void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int Nf, int stratified,
                         const float* u, uint64_t seed, uint64_t offset, float* z_out,
                         hipStream_t stream);
@@ -268,8 +332,14 @@ void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float
 void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
                             int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
                             float* grad, hipStream_t stream);
-void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, const float* el_sums,
-                         int el_rows, float el_weight, float* stats, hipStream_t stream);
+struct StatsArgs {
+  const float* mse_sums; int B;
+  const float* bg_sum; int bgN; float bg_weight;
+  const float* el_sums; int el_rows, el_jac_rows; float el_weight;
+  const float* wr_sums; float wr_weight;   // [4]: loss coarse, residual coarse, loss fine, residual fine
+  float* stats;
+};
+void launch_finish_stats(const StatsArgs& a, hipStream_t stream);
 void launch_background_loss(const float* points, const float* warped, int N, int rows_pad, float alpha, float scale,
                             float weight, float* d_points, float* loss_sum, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,

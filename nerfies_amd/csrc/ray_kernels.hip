@@ -9,26 +9,9 @@
 //   training._compute_loss_and_stats MSE/psnr   training.py:172,225 ; utils.py:94-103
 //   flax.optim.Adam.apply_gradient        training.py:268-269
 #include "nrf_internal.h"
+#include "philox.h"
 
 namespace nrf {
-
-// ------------------------------------------------------------------ Philox4x32-10
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-  c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
-}
-
-// uniform in [0,1) for element `idx` of stream `stream_id`
-__device__ __forceinline__ float philox_uniform(uint64_t seed, uint64_t offset, uint32_t stream_id, uint32_t idx) {
-  uint32_t c[4] = {idx, stream_id, (uint32_t)offset, (uint32_t)(offset >> 32)};
-  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-  for (int r = 0; r < 10; ++r) { philox_round(c, k0, k1); k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
-  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);
-}
 
 // ------------------------------------------------------------------ wave helpers (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
@@ -49,51 +32,53 @@ __device__ __forceinline__ float wave_incl_prod(float v, int lane) {
 
 // ------------------------------------------------------------------ ray prep
 // cond[ray] = [posenc(viewdir) | appearance code (only with use_alpha_condition, models.py:206) |
-// camera code]; condterm_{c,f}[ray][n] = cond . W_rgbh[256:, n] + b_rgbh[n].
-__global__ __launch_bounds__(128) void ray_prep_kernel(
-    const float* __restrict__ params, const float* __restrict__ viewdirs, const int32_t* __restrict__ app_ids,
-    const int32_t* __restrict__ cam_ids, int B, int Fv, int use_viewdirs, int app_feat, int64_t app_off,
-    int cam_feat, int64_t cam_off, int R, int64_t kc, int64_t bc, int64_t kf, int64_t bf,
-    float* __restrict__ cond, float* __restrict__ ct_c, float* __restrict__ ct_f) {
+// camera code]; condterm_{c,f}[ray][n] = cond . W_rgbh[256:, n] + b_rgbh[n]; with use_alpha_condition also
+// alpha_ct_{c,f}[ray] = appearance code . W_alpha[256:] (modules.py:152-157).  Codes come from the embedding tables
+// (glo.py:50-53) or, pre-encoded, straight from the caller (metadata_encoded, models.py:198-199, 210-211).
+__global__ __launch_bounds__(128) void ray_prep_kernel(const RayPrepArgs A) {
   __shared__ float s_cond[64];
   const int ray = blockIdx.x, t = threadIdx.x;
-  const int V = use_viewdirs ? 3 + 6 * Fv : 0;
-  if (t < R) {
+  const float* __restrict__ params = A.params;
+  const int V = A.use_viewdirs ? 3 + 6 * A.Fv : 0;
+  if (t < A.R) {
     float v;
     if (t < V) {
-      if (t < 3) v = viewdirs[3 * ray + t];
+      if (t < 3) v = A.viewdirs[3 * ray + t];
       else {
         const int q = t - 3, f = q / 6, rem = q - 6 * f, is_cos = rem / 3, c = rem - 3 * is_cos;
-        float a = __fmul_rn(viewdirs[3 * ray + c], (float)(1 << f));
+        float a = __fmul_rn(A.viewdirs[3 * ray + c], (float)(1 << f));
         if (is_cos) a = __fadd_rn(a, 1.57079632679489661923f);
         v = sinf(a);
       }
-    } else if (t < V + app_feat) {
-      v = params[app_off + (int64_t)app_ids[ray] * app_feat + (t - V)];
+    } else if (t < V + A.app_feat) {
+      v = A.app_codes ? A.app_codes[(size_t)ray * A.app_feat + (t - V)]
+                      : params[A.app_off + (int64_t)A.app_ids[ray] * A.app_feat + (t - V)];
     } else {
-      v = params[cam_off + (int64_t)cam_ids[ray] * cam_feat + (t - V - app_feat)];
+      const int c = t - V - A.app_feat;
+      v = A.cam_codes ? A.cam_codes[(size_t)ray * A.cam_feat + c] : params[A.cam_off + (int64_t)A.cam_ids[ray] * A.cam_feat + c];
     }
     s_cond[t] = v;
-    cond[(size_t)ray * R + t] = v;
+    A.cond[(size_t)ray * A.R + t] = v;
   }
   __syncthreads();
-  float a = params[bc + t], b = ct_f ? params[bf + t] : 0.f;
-  for (int c = 0; c < R; ++c) {
+  float* ct_f = A.condterm[1];
+  float a = params[A.rgbh_b[0] + t], b = ct_f ? params[A.rgbh_b[1] + t] : 0.f;
+  for (int c = 0; c < A.R; ++c) {
     const float x = s_cond[c];
-    a = fmaf(x, params[kc + (int64_t)(TRUNK_W + c) * RGB_W + t], a);
-    if (ct_f) b = fmaf(x, params[kf + (int64_t)(TRUNK_W + c) * RGB_W + t], b);
+    a = fmaf(x, params[A.rgbh_k[0] + (int64_t)(TRUNK_W + c) * RGB_W + t], a);
+    if (ct_f) b = fmaf(x, params[A.rgbh_k[1] + (int64_t)(TRUNK_W + c) * RGB_W + t], b);
   }
-  ct_c[(size_t)ray * RGB_W + t] = a;
+  A.condterm[0][(size_t)ray * RGB_W + t] = a;
   if (ct_f) ct_f[(size_t)ray * RGB_W + t] = b;
+  if (t < 2 && A.alpha_ct[t]) {   // thread 0: coarse, thread 1: fine
+    float s = 0.f;
+    for (int c = 0; c < A.app_feat; ++c) s = fmaf(s_cond[V + c], params[A.alpha_k[t] + TRUNK_W + c], s);
+    A.alpha_ct[t][ray] = s;
+  }
 }
 
-void launch_ray_prep(const float* params, const float* viewdirs, const int32_t* app_ids, const int32_t* cam_ids,
-                     int B, int Fv, int use_viewdirs, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
-                     int R, int64_t rgbh_k_c, int64_t rgbh_b_c, int64_t rgbh_k_f, int64_t rgbh_b_f, float* cond,
-                     float* condterm_c, float* condterm_f, hipStream_t stream) {
-  hipLaunchKernelGGL(ray_prep_kernel, dim3(B), dim3(128), 0, stream, params, viewdirs, app_ids, cam_ids, B, Fv,
-                     use_viewdirs, app_feat, app_off, cam_feat, cam_off, R, rgbh_k_c, rgbh_b_c, rgbh_k_f, rgbh_b_f,
-                     cond, condterm_c, condterm_f);
+void launch_ray_prep(const RayPrepArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(ray_prep_kernel, dim3(a.B), dim3(128), 0, stream, a);
 }
 
 // ------------------------------------------------------------------ coarse sampling
@@ -202,7 +187,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     const float4* __restrict__ out4, const float* __restrict__ z, const float* __restrict__ dirs, int B, int S,
     int white_bkgd, int sample_at_inf, int sigma_act, const float* __restrict__ rgb_out,
     const float* __restrict__ target, const float* __restrict__ d_rgb, float loss_scale,
-    float4* __restrict__ d_raw4, int rows_pad, float* __restrict__ mse_sum) {
+    float4* __restrict__ d_raw4, int rows_pad, float* __restrict__ mse_sum, float* __restrict__ dsig_ray) {
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0) {   // zero the tile padding rows so they contribute nothing to any gradient
@@ -251,6 +236,7 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
     }
   }
   float Qin = 0.f;   // Q of the last sample of the chunk being processed
+  float dsig_acc = 0.f;
 #pragma unroll
   for (int e = MAX_E - 1; e >= 0; --e) {
     if (e < E) {
@@ -278,16 +264,21 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
         o.z = w * g2 * c.z * (1.f - c.z);
         o.w = sigma_act == 1 ? dsigma * (1.f - expf(-c.w)) : (c.w > 0.f ? dsigma : 0.f);   // softplus' / relu'
         d_raw4[(size_t)ray * S + s] = o;
+        dsig_acc += o.w;
       }
     }
+  }
+  if (dsig_ray) {   // use_alpha_condition: the alpha head's per-ray input sees the sum over the ray's samples
+    dsig_acc = wave_sum(dsig_acc);
+    if (lane == 0) dsig_ray[ray] = dsig_acc;
   }
 }
 
 void launch_composite_bwd(const float4* out4, const float* z, const float* dirs, int B, int S, int white_bkgd,
                           int sample_at_inf, int sigma_act, const float* rgb_out, const float* target, const float* d_rgb,
-                          float loss_scale, float4* d_raw4, int rows_pad, float* mse_sum, hipStream_t stream) {
+                          float loss_scale, float4* d_raw4, int rows_pad, float* mse_sum, float* dsig_ray, hipStream_t stream) {
   hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, out4, z, dirs, B, S, white_bkgd,
-                     sample_at_inf, sigma_act, rgb_out, target, d_rgb, loss_scale, d_raw4, rows_pad, mse_sum);
+                     sample_at_inf, sigma_act, rgb_out, target, d_rgb, loss_scale, d_raw4, rows_pad, mse_sum, dsig_ray);
 }
 
 // ------------------------------------------------------------------ hierarchical sampling
@@ -417,27 +408,108 @@ void launch_cond_embed_grad(const float* params, const float* dray, const int32_
                        app_off, cam_feat, cam_off, rgbh_k, grad);
 }
 
-__global__ void finish_stats_kernel(const float* __restrict__ mse_sums, int B, const float* __restrict__ bg_sum, int bgN,
-                                    float bg_weight, const float* __restrict__ el_sums, int el_rows, float el_weight,
-                                    float* __restrict__ stats) {
+// use_alpha_condition: the alpha head is Dense([bottleneck, appearance code] -> 1) (modules.py:152-157).  Its
+// bottleneck rows are a wgrad group; here the code rows  dW[256 + a] = sum_ray code[ray][a] * dsig[ray]  and the
+// gradient of the codes through the head,  d code[ray][a] = W[256 + a] * dsig[ray]  (scatter-add into the table).
+// One block per code channel a.
+__global__ __launch_bounds__(256) void alpha_cond_grad_kernel(const float* __restrict__ params, const float* __restrict__ cond,
+                                                              const float* __restrict__ dsig, const int32_t* __restrict__ app_ids,
+                                                              int B, int R, int V, int app_feat, int64_t app_off, int64_t alpha_k,
+                                                              float* __restrict__ grad) {
+  __shared__ float red[4];
+  const int a = blockIdx.x, t = threadIdx.x;
+  const float w = params[alpha_k + TRUNK_W + a];
+  float s = 0.f;
+  for (int ray = t; ray < B; ray += 256) {
+    const float d = dsig[ray];
+    s = fmaf(cond[(size_t)ray * R + V + a], d, s);
+    if (app_ids && d != 0.f) atomicAdd(grad + app_off + (int64_t)app_ids[ray] * app_feat + a, w * d);
+  }
+  s = wave_sum(s);
+  if ((t & 63) == 0) red[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) grad[alpha_k + TRUNK_W + a] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+void launch_alpha_cond_grad(const float* params, const float* cond, const float* dsig_ray, const int32_t* app_ids, int B, int R,
+                            int V, int app_feat, int64_t app_off, int64_t alpha_k, float* grad, hipStream_t stream) {
+  if (app_feat > 0)
+    hipLaunchKernelGGL(alpha_cond_grad_kernel, dim3(app_feat), dim3(256), 0, stream, params, cond, dsig_ray, app_ids, B, R, V,
+                       app_feat, app_off, alpha_k, grad);
+}
+
+__global__ void finish_stats_kernel(const StatsArgs A) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
-    const float mc = mse_sums[0] / (3.f * B), mf = mse_sums[1] / (3.f * B);
-    const float bgl = bg_sum ? bg_sum[0] / (float)bgN : 0.f;
-    const float ell = el_sums ? el_sums[0] / (float)B : 0.f;          // sum over samples, mean over rays (training.py:194)
+    float* stats = A.stats;
+    const float B = (float)A.B;
+    const float mc = A.mse_sums[0] / (3.f * B), mf = A.mse_sums[1] / (3.f * B);
+    const float bgl = A.bg_sum ? A.bg_sum[0] / (float)A.bgN : 0.f;
+    const float ell = A.el_sums ? A.el_sums[0] / B : 0.f;          // sum over samples, mean over rays (training.py:194)
+    const float wrc = A.wr_sums ? A.wr_sums[0] / B : 0.f, wrf = A.wr_sums ? A.wr_sums[2] / B : 0.f;
     stats[0] = mc; stats[1] = mf;
     stats[2] = -10.f * logf(mc) / logf(10.f);   // utils.compute_psnr (utils.py:94-103)
     stats[3] = -10.f * logf(mf) / logf(10.f);
-    stats[4] = mc + mf + bg_weight * bgl + el_weight * ell;   // training.py:261 (+ :197, :257-258)
+    stats[4] = mc + mf + A.bg_weight * bgl + A.el_weight * ell + A.wr_weight * (wrc + wrf);   // training.py:261 (+ :197, :212, :257-258)
     stats[5] = bgl;                               // stats['background_loss'] (training.py:259)
     stats[6] = ell;                               // stats['loss/elastic']
-    stats[7] = el_sums ? el_sums[1] / (float)el_rows : 0.f;   // stats['residual/elastic'] (training.py:196)
+    stats[7] = A.el_sums ? A.el_sums[1] / (float)A.el_rows : 0.f;   // stats['residual/elastic'] (training.py:196)
+    stats[8] = wrc; stats[9] = wrf;               // stats['loss/warp_reg'] coarse / fine (training.py:210)
+    stats[10] = A.wr_sums ? A.wr_sums[1] / B : 0.f;   // stats['residual/warp_reg'] (training.py:211)
+    stats[11] = A.wr_sums ? A.wr_sums[3] / B : 0.f;
+    const float jr = (float)(A.el_jac_rows > 0 ? A.el_jac_rows : 1);
+    stats[12] = A.el_sums ? A.el_sums[2] / jr : 0.f;  // metric/jacobian_det, _div, _curl (training.py:214-222): mean over all coarse samples
+    stats[13] = A.el_sums ? A.el_sums[3] / jr : 0.f;
+    stats[14] = A.el_sums ? A.el_sums[4] / jr : 0.f;
+    stats[15] = 0.f;
   }
 }
 
-void launch_finish_stats(const float* mse_sums, int B, const float* bg_sum, int bgN, float bg_weight, const float* el_sums,
-                         int el_rows, float el_weight, float* stats, hipStream_t stream) {
-  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, mse_sums, B, bg_sum, bgN, bg_weight, el_sums, el_rows,
-                     el_weight, stats);
+void launch_finish_stats(const StatsArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(finish_stats_kernel, dim3(1), dim3(64), 0, stream, a);
+}
+
+// ------------------------------------------------------------------ warp regulariser
+// training.py:199-212 for one level: residual = |points - warped_points|^2 at the sample of
+// model_utils.compute_depth_index(stop_gradient(weights)) (first sample whose cumulative weight reaches 0.5, sample 0
+// if none), loss = general_loss_with_squared_residual(residual, alpha, scale), mean over rays.  One wave per ray;
+// d loss / d warped point is ADDED to the selected row of d_points (written before by the NeRF MLP's dgrad).
+__global__ __launch_bounds__(256) void warp_reg_kernel(const float* __restrict__ w, const float* __restrict__ pts,
+                                                       const float* __restrict__ warped, int B, int S, float alpha, float scale,
+                                                       float gscale, float* __restrict__ d_points, float* __restrict__ sums) {
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= B) return;
+  float carry = 0.f;
+  int idx = 0;
+  bool found = false;
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s = s0 + lane;
+    const float cum = wave_incl_sum(s < S ? w[(size_t)ray * S + s] : 0.f, lane) + carry;
+    const unsigned long long m = __ballot(s < S && cum >= 0.5f);
+    if (!found && m) { idx = s0 + __ffsll((long long)m) - 1; found = true; }
+    carry = __shfl(cum, 63);
+  }
+  if (lane == 0) {
+    const size_t row = (size_t)ray * S + idx;
+    float r[3], q = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { r[c] = warped[3 * row + c] - pts[3 * row + c]; q += r[c] * r[c]; }
+    const float beta = fmaxf(1.1920929e-7f, fabsf(alpha - 2.f));
+    const float a_safe = (alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(alpha));
+    const float u = q / (scale * scale * beta) + 1.f;
+    const float rho = scale * (beta / a_safe) * (powf(u, 0.5f * alpha) - 1.f);
+    const float drho = (0.5f / scale) * powf(u, 0.5f * alpha - 1.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d_points[3 * row + c] += gscale * drho * 2.f * r[c];
+    atomicAdd(sums, rho);
+    atomicAdd(sums + 1, sqrtf(q));
+  }
+}
+
+void launch_warp_reg(const float* weights, const float* points, const float* warped, int B, int S, float alpha, float scale,
+                     float gscale, float* d_points, float* sums, hipStream_t stream) {
+  hipLaunchKernelGGL(warp_reg_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, weights, points, warped, B, S, alpha, scale, gscale,
+                     d_points, sums);
 }
 
 // ------------------------------------------------------------------ elastic 'median' reduce

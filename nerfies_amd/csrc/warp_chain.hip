@@ -12,6 +12,7 @@
 // ([PKw][64], <= 16 KiB) -> three workgroups per CU; each wave owns 64 rows x 32 columns (2 MFMA
 // row blocks x 1 column block), weights stream from L2 in B-fragment order.  The heads (128 -> 3+3) and exp_se3 run on
 // the VALU in the epilogue, one row per thread.
+#include "../../include/nerfies_amd.h"
 #include "chain_common.h"
 
 namespace nrf {
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
 #pragma unroll
         for (int c = 0; c < 3; ++c)   // origins + z_vals * directions  (model_utils.py:72-73)
           x[c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
-        id = A.warp_ids[ray];
+        id = A.warp_ids ? A.warp_ids[ray] : ray;   // nullptr: per-ray codes (metadata_encoded / TimeEncoder output)
       }
       float* stp = STASH ? A.st_win + (size_t)tile * PKS * TILE_ROWS : nullptr;
       auto put = [&](int k, float v) {
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
           A.points_raw[3 * row] = x[0]; A.points_raw[3 * row + 1] = x[1]; A.points_raw[3 * row + 2] = x[2];
         }
       } else if (part == 1) {
-        const float* __restrict__ code = prm + A.po.embed + (int64_t)id * A.G;   // glo.py:50-53
+        const float* __restrict__ code = A.embed_table + (int64_t)id * A.G;   // glo.py:50-53
         for (int g = 0; g < A.G; ++g) put(3 + 6 * A.F + g, code[g]);
         for (int k = A.Win; k < PKw; ++k) put(k, 0.f);
         if (STASH) for (int k = PKw; k < PKS; ++k) stp[frag_index(k, p)] = 0.f;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
         int cur = -1;
         for (int q = row0; q < row0 + 8 && q < nvalid; ++q) {
           const int grow = tile * TILE_ROWS + q;
-          const int id = A.point_ids ? A.point_ids[grow] : A.warp_ids[grow / A.S];
+          const int id = A.point_ids ? A.point_ids[grow] : A.warp_ids ? A.warp_ids[grow / A.S] : grow / A.S;
           if (id != cur) {
             if (cur >= 0 && s != 0.f) atomicAdd(A.grad_embed + (size_t)cur * A.G + g, s);
             s = 0.f; cur = id;
@@ -549,16 +550,30 @@ __device__ __forceinline__ void jacobi3(float (&D)[3][3], float (&V)[3][3]) {
   }
 }
 
-// One thread per coarse sample.  With the raw head outputs (w, v), their tangents (wd_c, vd_c) along x_c and the
-// point x:  E = J - I, column c = d/dx_c [exp_se3(w, v) x - x] (Dual evaluation of se3_delta);
+// E = J - I of one sample: column c = d/dx_c [exp_se3(w, v) x - x], from the raw head outputs (w, v), their tangents
+// (wd_c, vd_c) along x_c and the point x (Dual evaluation of se3_delta).
+__device__ __forceinline__ void warp_jacobian_minus_identity(V3 w, V3 v, V3 x, const V3 (&wd)[3], const V3 (&vd)[3], float (&E)[3][3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
+    const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
+    const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
+    const V3T<Dual> dl = se3_delta<Dual>(W, Vv, X);
+    E[0][c] = dl.x.d; E[1][c] = dl.y.d; E[2][c] = dl.z.d;
+  }
+}
+
+// One thread per coarse sample.  E = J - I (above);
 // J^T J - I = E + E^T + E^T E = V diag(mu) V^T;  log s_k = 0.5 log1p(mu_k)  (accurate near the identity);
-// sq = sum log(max(s_k, eps))^2;  rho = general_loss(sq, alpha, scale);  L = (1/B) sum_rows coef_row rho_row.
-// dL/dJ = coef/B * weight * rho'(sq) * J V diag(2 log s_k / s_k^2) V^T;  its pull-back through exp_se3 comes
-// from se3_vjp on Duals: value parts -> adjoints of (wd_c, vd_c), tangent parts (Hessian-vector products)
-// -> adjoints of the primal (w, v).
+// sq = the squared residual of elastic_loss_type (training.py:86-109: 'log_svals' sum log(max(s_k, eps))^2, 'svals'
+// sum (s_k - 1)^2, 'jtj' |J J^T - I|^2 / 4, 'div' tr(E)^2, 'det' (det J - 1)^2, 'log_det' log(max(det J, eps))^2);
+// rho = general_loss(sq, alpha, scale);  L = (1/B) sum_rows coef_row rho_row.
+// dL/dJ = coef/B * weight * rho'(sq) * d sq/dJ  (singular-value types: J V diag((d sq/d s_k) / s_k) V^T);  its pull-back
+// through exp_se3 comes from se3_vjp on Duals: value parts -> adjoints of (wd_c, vd_c), tangent parts (Hessian-vector
+// products) -> adjoints of the primal (w, v).  Also the Jacobian statistics of training.py:214-222.
 __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  float rho_c = 0.f, res = 0.f;
+  float rho_c = 0.f, res = 0.f, jdet = 0.f, jdiv = 0.f, jcurl = 0.f;
   if (row < A.rows_pad) {
     V3 wbar = v3(0.f, 0.f, 0.f), vbar = wbar;
     V3 wdb[3], vdb[3];
@@ -577,27 +592,87 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
         const size_t tr = (size_t)c * A.rows_pad + row;
         const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
         wd[c] = v3(a.x, a.y, a.z); vd[c] = v3(b.x, b.y, b.z);
-        const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
-        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
-        const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
-        const V3T<Dual> dl = se3_delta<Dual>(W, Vv, X);
-        E[0][c] = dl.x.d; E[1][c] = dl.y.d; E[2][c] = dl.z.d;
       }
-      float D[3][3], Vm[3][3];
+      warp_jacobian_minus_identity(w, v, x, wd, vd, E);
+      // det J - 1 = tr E + (principal 2x2 minors of E) + det E: no cancellation near the identity
+      const float trE = E[0][0] + E[1][1] + E[2][2];
+      const float m2 = (E[0][0] * E[1][1] - E[0][1] * E[1][0]) + (E[0][0] * E[2][2] - E[0][2] * E[2][0]) + (E[1][1] * E[2][2] - E[1][2] * E[2][1]);
+      const float detE = E[0][0] * (E[1][1] * E[2][2] - E[1][2] * E[2][1]) - E[0][1] * (E[1][0] * E[2][2] - E[1][2] * E[2][0]) +
+                         E[0][2] * (E[1][0] * E[2][1] - E[1][1] * E[2][0]);
+      const float dm1 = trE + m2 + detE;
+      jdet = 1.f + dm1; jdiv = trE;                                   // utils.jacobian_to_div (utils.py:85-91)
+      const float c0 = E[2][1] - E[1][2], c1 = E[0][2] - E[2][0], c2 = E[1][0] - E[0][1];   // utils.jacobian_to_curl (:71-84)
+      jcurl = sqrtf(c0 * c0 + c1 * c1 + c2 * c2);
+      float sq = 0.f;
+      float Gd[3][3];   // d sq / dJ
+      if (A.loss_type == NRF_ELASTIC_DIV) {
+        sq = trE * trE;
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+        for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) D[i][k] = E[i][k] + E[k][i] + (E[0][i] * E[0][k] + E[1][i] * E[1][k] + E[2][i] * E[2][k]);
-      jacobi3(D, Vm);
-      float m[3], sq = 0.f;
-      const float log_eps = logf(A.eps);
+          for (int k = 0; k < 3; ++k) Gd[i][k] = i == k ? 2.f * trE : 0.f;
+      } else if (A.loss_type == NRF_ELASTIC_DET || A.loss_type == NRF_ELASTIC_LOG_DET) {
+        float J[3][3], Cf[3][3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const float mu = D[k][k], lam = 1.f + mu;
-        const bool live = lam > A.eps * A.eps;     // s_k > eps (training.py:88)
-        const float ls = live ? 0.5f * log1pf(mu) : log_eps;
-        sq += ls * ls;
-        m[k] = live ? 2.f * ls / lam : 0.f;         // (d sq / d s_k) / s_k
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) J[i][k] = E[i][k] + (i == k ? 1.f : 0.f);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {   // cofactor matrix: d det / dJ
+            const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+            Cf[i][k] = J[i1][k1] * J[i2][k2] - J[i1][k2] * J[i2][k1];
+          }
+        float f;
+        if (A.loss_type == NRF_ELASTIC_DET) { sq = dm1 * dm1; f = 2.f * dm1; }
+        else {
+          const bool live = jdet > A.eps;
+          const float ld = live ? log1pf(dm1) : logf(A.eps);
+          sq = ld * ld; f = live ? 2.f * ld / jdet : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Gd[i][k] = f * Cf[i][k];
+      } else {
+        float D[3][3], M[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) D[i][k] = E[i][k] + E[k][i] + (E[0][i] * E[0][k] + E[1][i] * E[1][k] + E[2][i] * E[2][k]);
+        if (A.loss_type == NRF_ELASTIC_JTJ) {   // |J J^T - I|_F^2 / 4 = |J^T J - I|_F^2 / 4 ; d/dJ = J (J^T J - I)
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { sq += 0.25f * D[i][k] * D[i][k]; M[i][k] = D[i][k]; }
+        } else {
+          float Vm[3][3], m[3];
+          jacobi3(D, Vm);
+          const float log_eps = logf(A.eps);
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            const float mu = D[k][k], lam = 1.f + mu;
+            if (A.loss_type == NRF_ELASTIC_SVALS) {
+              const float sk = sqrtf(fmaxf(lam, 0.f)), sm1 = mu / (sk + 1.f);   // s - 1 without cancellation
+              sq += sm1 * sm1;
+              m[k] = sk > 1e-20f ? 2.f * sm1 / sk : 0.f;
+            } else {
+              const bool live = lam > A.eps * A.eps;     // s_k > eps (training.py:88)
+              const float ls = live ? 0.5f * log1pf(mu) : log_eps;
+              sq += ls * ls;
+              m[k] = live ? 2.f * ls / lam : 0.f;         // (d sq / d s_k) / s_k
+            }
+          }
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) M[i][k] = Vm[i][0] * m[0] * Vm[k][0] + Vm[i][1] * m[1] * Vm[k][1] + Vm[i][2] * m[2] * Vm[k][2];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int k = 0; k < 3; ++k) Gd[i][k] = M[i][k] + E[i][0] * M[0][k] + E[i][1] * M[1][k] + E[i][2] * M[2][k];   // J M, J = I + E
       }
       const float beta = fmaxf(1.1920929e-7f, fabsf(A.alpha - 2.f));
       const float a_safe = (A.alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(A.alpha));
@@ -607,23 +682,13 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
       const float coef = A.coef[row];
       rho_c = coef * rho;
       res = (A.res_selected && coef == 0.f) ? 0.f : sqrtf(sq);
-      // G = gs * J M,  M = V diag(m) V^T,  J = I + E
       const float gs = coef * A.gscale * drho;
-      float M[3][3], G[3][3];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) M[i][k] = Vm[i][0] * m[0] * Vm[k][0] + Vm[i][1] * m[1] * Vm[k][1] + Vm[i][2] * m[2] * Vm[k][2];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) G[i][k] = gs * (M[i][k] + E[i][0] * M[0][k] + E[i][1] * M[1][k] + E[i][2] * M[2][k]);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
         const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
         const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
-        const V3T<Dual> g = v3t<Dual>(Dual(G[0][c]), Dual(G[1][c]), Dual(G[2][c]));
+        const V3T<Dual> g = v3t<Dual>(Dual(gs * Gd[0][c]), Dual(gs * Gd[1][c]), Dual(gs * Gd[2][c]));
         V3T<Dual> dw, dv;
         se3_vjp<Dual>(W, Vv, X, g, dw, dv);
         wdb[c] = v3(dw.x.v, dw.y.v, dw.z.v); vdb[c] = v3(dv.x.v, dv.y.v, dv.z.v);
@@ -639,11 +704,46 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
     A.prim_dw4[row] = make_float4(wbar.x, wbar.y, wbar.z, 0.f);
     A.prim_dv4[row] = make_float4(vbar.x, vbar.y, vbar.z, 0.f);
   }
-  // loss / residual sums (one atomic per wave)
-  float a = rho_c, b = res;
+  // loss / residual / Jacobian-statistic sums (one atomic each per wave)
+  float sm[5] = {rho_c, res, jdet, jdiv, jcurl};
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  if ((threadIdx.x & 63) == 0 && (a != 0.f || b != 0.f)) { atomicAdd(A.sums, a); atomicAdd(A.sums + 1, b); }
+  for (int q = 0; q < 5; ++q) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sm[q] += __shfl_xor(sm[q], o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+      if (sm[q] != 0.f) atomicAdd(A.sums + q, sm[q]);
+  }
+}
+
+// return_warp_jacobian (models.py:264-265, warping.py:385-387): J = I + E per sample, row-major [3][3].
+__global__ __launch_bounds__(256) void jacobian_kernel(const JacobianArgs A) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= A.rows) return;
+  const int tile = row / TILE_ROWS, p = row % TILE_ROWS;
+  const float* sw = A.prim_win + (size_t)tile * A.PKS * TILE_ROWS;
+  const V3 x = v3(sw[frag_index(0, p)], sw[frag_index(1, p)], sw[frag_index(2, p)]);
+  const float4 w4 = A.prim_wv[2 * (size_t)row], v4 = A.prim_wv[2 * (size_t)row + 1];
+  V3 wd[3], vd[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const size_t tr = (size_t)c * A.rows_pad + row;
+    const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
+    wd[c] = v3(a.x, a.y, a.z); vd[c] = v3(b.x, b.y, b.z);
+  }
+  float E[3][3];
+  warp_jacobian_minus_identity(v3(w4.x, w4.y, w4.z), v3(v4.x, v4.y, v4.z), x, wd, vd, E);
+  float* o = A.out + (size_t)row * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o[3 * i + k] = E[i][k] + (i == k ? 1.f : 0.f);
+}
+
+void launch_jacobian(const JacobianArgs& a, hipStream_t stream) {
+  hipLaunchKernelGGL(jacobian_kernel, dim3((a.rows + 255) / 256), dim3(256), 0, stream, a);
 }
 
 void launch_elastic(const ElasticArgs& a, hipStream_t stream) {

@@ -9,8 +9,13 @@ LIB_PATH = os.path.join(HERE, '_lib', 'libnerfies_amd.so')
 NRF_FLAG_TRAIN = 1
 NRF_FLAG_NO_WARP = 2
 NRF_FLAG_BF16 = 4
+NRF_FLAG_WARP_JACOBIAN = 8
+NRF_NUM_STATS = 16
 ACT = {'relu': 0, 'softplus': 1}
 WARP_FIELD = {'se3': 0, 'translation': 1}
+META_ENCODER = {'glo': 0, 'time': 1}
+ELASTIC_REDUCE = {'weight': 0, 'median': 1}
+ELASTIC_TYPE = {'log_svals': 0, 'svals': 1, 'jtj': 2, 'div': 3, 'det': 4, 'log_det': 5}
 
 
 class NrfError(RuntimeError):
@@ -32,6 +37,7 @@ class ModelDesc(C.Structure):
       ('use_alpha_condition', C.c_int32), ('use_rgb_condition', C.c_int32), ('use_trunk_condition', C.c_int32),
       ('use_warp', C.c_int32), ('num_warp_freqs', C.c_int32), ('num_warp_embeddings', C.c_int32),
       ('num_warp_features', C.c_int32), ('warp_field_type', C.c_int32),
+      ('noise_std', C.c_float), ('warp_metadata_encoder_type', C.c_int32), ('num_time_encoder_freqs', C.c_int32),
   ]
 
 
@@ -41,7 +47,9 @@ class TensorInfo(C.Structure):
 
 class Rays(C.Structure):
   _fields_ = [('num_rays', C.c_int32), ('origins', C.c_void_p), ('directions', C.c_void_p), ('viewdirs', C.c_void_p),
-              ('warp_ids', C.c_void_p), ('appearance_ids', C.c_void_p), ('camera_ids', C.c_void_p)]
+              ('warp_ids', C.c_void_p), ('appearance_ids', C.c_void_p), ('camera_ids', C.c_void_p),
+              ('warp_codes', C.c_void_p), ('appearance_codes', C.c_void_p), ('camera_codes', C.c_void_p),
+              ('time', C.c_void_p)]
 
 
 class StepScalars(C.Structure):
@@ -49,12 +57,14 @@ class StepScalars(C.Structure):
 
 
 class Rand(C.Structure):
-  _fields_ = [('t_rand', C.c_void_p), ('u', C.c_void_p), ('seed', C.c_uint64), ('offset', C.c_uint64)]
+  _fields_ = [('t_rand', C.c_void_p), ('u', C.c_void_p), ('seed', C.c_uint64), ('offset', C.c_uint64),
+              ('noise_coarse', C.c_void_p), ('noise_fine', C.c_void_p)]
 
 
 class LevelOut(C.Structure):
   _fields_ = [('rgb', C.c_void_p), ('depth', C.c_void_p), ('med_depth', C.c_void_p), ('acc', C.c_void_p),
-              ('weights', C.c_void_p), ('z_vals', C.c_void_p), ('points', C.c_void_p), ('warped_points', C.c_void_p)]
+              ('weights', C.c_void_p), ('z_vals', C.c_void_p), ('points', C.c_void_p), ('warped_points', C.c_void_p),
+              ('warp_jacobian', C.c_void_p)]
 
 
 class Outputs(C.Structure):
@@ -68,7 +78,11 @@ class Background(C.Structure):
 
 class Elastic(C.Structure):
   _fields_ = [('loss_weight', C.c_float), ('reduce_method', C.c_int32), ('eps', C.c_float), ('loss_alpha', C.c_float),
-              ('loss_scale', C.c_float)]
+              ('loss_scale', C.c_float), ('loss_type', C.c_int32)]
+
+
+class WarpReg(C.Structure):
+  _fields_ = [('loss_weight', C.c_float), ('loss_alpha', C.c_float), ('loss_scale', C.c_float)]
 
 
 class CameraDesc(C.Structure):
@@ -132,7 +146,8 @@ def load_library(path=None):
       'nrf_debug_wgrad_segments': [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)],
       'nrf_debug_ws_offset': [vp, C.c_char_p, i32, C.POINTER(i64)],
       'nrf_train_step_loss_grad_ex': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand),
-                                      C.POINTER(Background), C.POINTER(Elastic), vp, vp, vp, C.c_size_t, vp],
+                                      C.POINTER(Background), C.POINTER(Elastic), C.POINTER(WarpReg), u32, vp, vp, vp,
+                                      C.c_size_t, vp],
       'nrf_workspace_bytes_ex': [vp, i32, u32, i32, i32, C.POINTER(C.c_size_t)],
       'nrf_warp_points_workspace_bytes': [vp, i32, C.POINTER(C.c_size_t)],
       'nrf_warp_points': [vp, vp, vp, vp, i32, C.POINTER(StepScalars), vp, vp, C.c_size_t, vp],

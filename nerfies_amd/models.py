@@ -109,8 +109,6 @@ class NerfModel:
 
   # ---- C-ABI plumbing -------------------------------------------------------------------
   def desc(self) -> L.ModelDesc:
-    if self.noise_std not in (None, 0, 0.0):
-      raise L.NrfError('noise_std regularisation is not built (no preset sets it, defaults.gin)')
     if _act_name(self.activation) != 'relu':
       raise L.NrfError('only relu trunk activation is built')
     if self.alpha_channels != 1 or self.rgb_channels != 3:
@@ -150,13 +148,17 @@ class NerfModel:
     if self.use_warp and dict(self.warp_kwargs or {}):
       raise L.NrfError(f'warp_kwargs {dict(self.warp_kwargs)} are not supported: the warp kernels are built for the '
                        'default field (6 x 128 trunk, skip at 4; warping.py:228-239)')
-    if self.use_warp and self.warp_metadata_encoder_type != 'glo':
-      raise L.NrfError("only the 'glo' warp metadata encoder is built")
+    if self.use_warp and self.warp_metadata_encoder_type not in L.META_ENCODER:
+      raise L.NrfError(f"warp_metadata_encoder_type must be one of {sorted(L.META_ENCODER)} ('blend' exists only in the "
+                       'TranslationField, warping.py:142-146, and no preset selects it)')
     d.use_warp = int(self.use_warp)
     d.num_warp_freqs = self.num_warp_freqs
     d.num_warp_embeddings = self.num_warp_embeddings if self.use_warp else 0
     d.num_warp_features = self.num_warp_features
     d.warp_field_type = L.WARP_FIELD[self.warp_field_type] if self.use_warp else 0
+    d.noise_std = float(self.noise_std or 0.0)
+    d.warp_metadata_encoder_type = L.META_ENCODER[self.warp_metadata_encoder_type] if self.use_warp else 0
+    d.num_time_encoder_freqs = 1   # metadata_encoder_num_freqs (warping.py:234); warp_kwargs are rejected above
     return d
 
   @property
@@ -186,12 +188,14 @@ class NerfModel:
       self._layout = P.layout_from_infos(infos, total.value)
     return self._layout
 
-  def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0, elastic: bool = False) -> torch.Tensor:
-    key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic))
+  def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0, elastic: bool = False,
+                jacobian: bool = False) -> torch.Tensor:
+    key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic), bool(jacobian))
     ws = self._ws.get(key)
     if ws is None:
       nbytes = C.c_size_t(0)
-      L.check(self.lib.nrf_workspace_bytes_ex(self.handle, num_rays, L.NRF_FLAG_TRAIN if train else 0,
+      flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jacobian else 0)
+      L.check(self.lib.nrf_workspace_bytes_ex(self.handle, num_rays, flags,
                                               int(num_background_points), int(bool(elastic)), C.byref(nbytes)), self.lib)
       ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
       self._ws[key] = ws
@@ -205,7 +209,7 @@ class NerfModel:
       params = params['model']
     return P.FlatParams(P.flat_from_tree(params, self.layout, device), self.layout)
 
-  def _rays_struct(self, rays_dict, device):
+  def _rays_struct(self, rays_dict, device, metadata_encoded=False):
     origins = _f32(rays_dict['origins'], device)
     directions = _f32(rays_dict['directions'], device)
     viewdirs = _f32(rays_dict['viewdirs'], device) if 'viewdirs' in rays_dict else None
@@ -214,16 +218,40 @@ class NerfModel:
     r = L.Rays()
     r.num_rays = origins.shape[0]
     r.origins, r.directions, r.viewdirs = _ptr(origins), _ptr(directions), _ptr(viewdirs)
-    for field, key in (('warp_ids', 'warp'), ('appearance_ids', 'appearance'), ('camera_ids', 'camera')):
-      t = _ids(md.get(key), device)
+    time_enc = self.use_warp and self.warp_metadata_encoder_type == 'time'
+    for field, cfield, key, width in (('warp_ids', 'warp_codes', 'warp', self.num_warp_features),
+                                      ('appearance_ids', 'appearance_codes', 'appearance', self.num_appearance_features),
+                                      ('camera_ids', 'camera_codes', 'camera', self.num_camera_features)):
+      src = md.get('time' if (key == 'warp' and time_enc) else key)   # models.py:252-254
+      if src is None:
+        continue
+      if metadata_encoded:   # the codes themselves, (B, features) (models.py:198-199, 210-211, 251)
+        t = _f32(src, device).reshape(r.num_rays, -1)
+        if t.shape[1] != width:
+          raise L.NrfError(f"metadata_encoded: metadata[{key!r}] must have {width} features, got {t.shape[1]}")
+        setattr(r, cfield, _ptr(t))
+      elif key == 'warp' and time_enc:   # float timestamps for the TimeEncoder (datasets/core.py:272-274)
+        t = _f32(src, device).reshape(-1)
+        r.time = _ptr(t)
+      else:
+        t = _ids(src, device)
+        setattr(r, field, _ptr(t))
       keep.append(t)
-      setattr(r, field, _ptr(t))
     return r, keep
 
   def _rand_struct(self, rngs, num_rays, device):
     rnd = L.Rand()
     keep = []
     rngs = rngs or {}
+    for field, key, n in (('noise_coarse', 'noise_coarse', self.num_coarse_samples),
+                          ('noise_fine', 'noise_fine', self.num_coarse_samples + self.num_fine_samples)):
+      k = rngs.get(key)   # explicit standard normals for noise_regularize (parity runs)
+      if k is not None:
+        t = _f32(k, device)
+        if tuple(t.shape) != (num_rays, n):
+          raise L.NrfError(f"rngs[{key!r}] normals must have shape {(num_rays, n)}")
+        keep.append(t)
+        setattr(rnd, field, _ptr(t))
     for field, key, n in (('t_rand', 'coarse', self.num_coarse_samples), ('u', 'fine', self.num_fine_samples)):
       k = rngs.get(key)
       if isinstance(k, torch.Tensor) and k.is_floating_point() and k.dim() == 2:
@@ -247,19 +275,24 @@ class NerfModel:
     addresses: what a captured hipGraph replay needs).  `bf16=True` (inference only, no reference counterpart): the NeRF
     MLPs take bfloat16 operands (NRF_FLAG_BF16), everything else stays fp32."""
     del deterministic   # accepted and unused, as in the reference (models.py:298)
-    if metadata_encoded:
-      raise L.NrfError('metadata_encoded=True is not built yet')
-    if return_warp_jacobian or self.use_warp_jacobian:
-      raise L.NrfError('the warp Jacobian is not returned as an output: the elastic regulariser consumes it inside the '
-                       'library (loss_and_grad(..., elastic=...) -> nrf_train_step_loss_grad_ex)')
     warp_on = bool(self.use_warp and use_warp)
+    # models.py:345-346, 367-368: the coarse level carries the Jacobian when the model was built with use_warp_jacobian
+    # or the call asks for it, the fine level only when the call asks for it
+    jac_levels = set()
+    if warp_on and not train:
+      if return_warp_jacobian or self.use_warp_jacobian:
+        jac_levels.add('coarse')
+      if return_warp_jacobian:
+        jac_levels.add('fine')
+    if train and metadata_encoded:
+      raise L.NrfError('metadata_encoded=True is an inference input (the reference never trains with it)')
     if return_points and not warp_on:
       raise L.NrfError('return_points is only built together with the warp field')
     device = torch.as_tensor(rays_dict['origins']).device
     if device.type != 'cuda':
       raise L.NrfError('rays must live on the GPU: the hot path has no CPU fallback')
     fp = self.flat_params(variables, device)
-    rays, keep = self._rays_struct(rays_dict, device)
+    rays, keep = self._rays_struct(rays_dict, device, metadata_encoded)
     B = rays.num_rays
     rnd, keep2 = self._rand_struct(rngs, B, device)
     return_weights = self.use_weights or return_weights
@@ -281,14 +314,16 @@ class NerfModel:
         if return_points:   # models.py:250-251, 266-267
           d['points'] = torch.empty(B, s, 3, device=device)
           d['warped_points'] = torch.empty(B, s, 3, device=device)
+        if name in jac_levels:   # models.py:264-265
+          d['warp_jacobian'] = torch.empty(B, s, 3, 3, device=device)
       for k, t in d.items():
         setattr(lo, k, _ptr(t))
       ret[name] = d
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
-    ws = self.workspace(B, train, device)
+    ws = self.workspace(B, train, device, jacobian=bool(jac_levels))
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0) | \
-        (L.NRF_FLAG_BF16 if bf16 else 0)
+        (L.NRF_FLAG_BF16 if bf16 else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jac_levels else 0)
     L.check(self.lib.nrf_forward(self.handle, _ptr(fp.flat), C.byref(rays), C.byref(scal), C.byref(rnd), C.byref(out),
                                  flags, _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2
@@ -310,19 +345,21 @@ class NerfModel:
     return grad
 
   def loss_and_grad(self, fp: P.FlatParams, batch, warp_extra=None, rngs=None, grad_out=None, stats_out=None,
-                    background=None, elastic=None):
+                    background=None, elastic=None, warp_reg=None, bf16=False):
     """forward + MSE_coarse + MSE_fine [+ background regulariser] + backward in one library call
     (training.py:168-265).  `background` = dict(points (N,3) already noised, warp_ids (N,), weight, alpha=-2,
     scale=1e-3) adds weight * mean(general_loss(|warp(x) - x|^2)) (training.py:117-135, 248-259).
     `elastic` = dict(weight, reduce_method='weight', eps=1e-6, alpha=-2, scale=0.03) adds the elastic regulariser
-    on the coarse samples (training.py:71-114, 177-197).  stats = [mse_c, mse_f, psnr_c, psnr_f, total,
-    background_loss, loss/elastic, residual/elastic]."""
+    on the coarse samples (training.py:71-114, 177-197); `loss_type` in lib.ELASTIC_TYPE.  `warp_reg` = dict(weight,
+    alpha=-2, scale=1e-3): training.py:199-212 on both levels.  `bf16`: bfloat16 MLP operands (NRF_FLAG_BF16).
+    stats (lib.NRF_NUM_STATS floats) = [mse_c, mse_f, psnr_c, psnr_f, total, background_loss, loss/elastic,
+    residual/elastic, warp_reg_c, warp_reg_f, warp_reg residual c, f, jacobian det, div, curl, 0]."""
     device = fp.flat.device
     rays, keep = self._rays_struct(batch, device)
     rnd, keep2 = self._rand_struct(rngs, rays.num_rays, device)
     target = _f32(batch['rgb'], device)[..., :3].contiguous()
     grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
-    stats = stats_out if stats_out is not None else torch.empty(8, device=device)
+    stats = stats_out if stats_out is not None else torch.empty(L.NRF_NUM_STATS, device=device)
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
     bg, nbg, keep3 = None, 0, []
     if background is not None:
@@ -335,16 +372,24 @@ class NerfModel:
     el = None
     if elastic is not None:
       method = elastic.get('reduce_method', 'weight')
-      if method not in ('weight', 'median'):
+      if method not in L.ELASTIC_REDUCE:
         raise L.NrfError(f'unknown elastic_reduce_method {method!r}')
-      el = L.Elastic(float(elastic.get('weight', 0.0)), 0 if method == 'weight' else 1, float(elastic.get('eps', 1e-6)),
-                     float(elastic.get('alpha', -2.0)), float(elastic.get('scale', 0.03)))
+      ltype = elastic.get('loss_type', 'log_svals')
+      if ltype not in L.ELASTIC_TYPE:
+        raise L.NrfError(f"elastic_loss_type {ltype!r} is not built (one of {sorted(L.ELASTIC_TYPE)}; 'nr' produces NaNs in "
+                         'the reference itself, training.py:58)')
+      el = L.Elastic(float(elastic.get('weight', 0.0)), L.ELASTIC_REDUCE[method], float(elastic.get('eps', 1e-6)),
+                     float(elastic.get('alpha', -2.0)), float(elastic.get('scale', 0.03)), L.ELASTIC_TYPE[ltype])
+    wr = None
+    if warp_reg is not None:
+      wr = L.WarpReg(float(warp_reg.get('weight', 0.0)), float(warp_reg.get('alpha', -2.0)), float(warp_reg.get('scale', 0.001)))
     ws = self.workspace(rays.num_rays, True, device, nbg, el is not None)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     L.check(self.lib.nrf_train_step_loss_grad_ex(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
                                                  C.byref(rnd), C.byref(bg) if bg is not None else None,
-                                                 C.byref(el) if el is not None else None, _ptr(grad),
-                                                 _ptr(stats), _ptr(ws), ws.numel() * 4, stream), self.lib)
+                                                 C.byref(el) if el is not None else None,
+                                                 C.byref(wr) if wr is not None else None, L.NRF_FLAG_BF16 if bf16 else 0,
+                                                 _ptr(grad), _ptr(stats), _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2, keep3
     return grad, stats
 
@@ -412,6 +457,7 @@ def construct_nerf(key, config, batch_size: int, appearance_ids: Sequence[int], 
       warp_metadata_encoder_type=g('warp_metadata_encoder_type', 'glo'),
       use_appearance_metadata=g('use_appearance_metadata', False), use_camera_metadata=g('use_camera_metadata', False),
       use_warp=g('use_warp', False), use_warp_jacobian=use_warp_jacobian, use_weights=use_weights,
+      use_trunk_condition=g('use_trunk_condition', False),
       use_alpha_condition=g('use_alpha_condition', False), use_rgb_condition=g('use_rgb_condition', False),
       warp_kwargs=dict(g('warp_kwargs', {}) or {}))
   flat = P.init_flat(model.layout, int(key), device)

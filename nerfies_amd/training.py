@@ -37,9 +37,9 @@ class Optimizer:
     self.target = target
     self.m = torch.zeros_like(target.flat)
     self.v = torch.zeros_like(target.flat)
-    # gradient + the 8 step statistics in ONE buffer: a single all-reduce per step carries both (training.py:266-267)
+    # gradient + the step statistics in ONE buffer: a single all-reduce per step carries both (training.py:266-267)
     n = target.flat.numel()
-    self._gs = torch.zeros(n + 8, dtype=torch.float32, device=target.flat.device)
+    self._gs = torch.zeros(n + L.NRF_NUM_STATS, dtype=torch.float32, device=target.flat.device)
     self.grad = self._gs[:n]
     self.stats = self._gs[n:]
     self.step = 0
@@ -89,20 +89,22 @@ def psum_gradients(grad: torch.Tensor, stats: torch.Tensor, fused: Optional[torc
     else:
       dist.all_reduce(grad, op=dist.ReduceOp.SUM)
       dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-    stats = stats / n
+  # always a fresh tensor: `stats` is a view of the donated gradient buffer, which the next step overwrites
+  stats = stats / n if n > 1 else stats.clone()
   return grad, stats, n
 
 
 def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[str, Any],
                scalar_params: ScalarParams, use_elastic_loss: bool = False, elastic_reduce_method: str = 'median',
                elastic_loss_type: str = 'log_svals', use_background_loss: bool = False,
-               use_warp_reg_loss: bool = False):
+               use_warp_reg_loss: bool = False, *, rngs: Optional[Dict[str, Any]] = None):
   """One optimisation step (training.py:138-271).  `batch` holds this rank's ray shard
-  ('rgb','origins','directions','metadata').  Returns (new_state, stats, rng_key)."""
-  if use_warp_reg_loss:
-    raise L.NrfError('warp_reg loss is not built (no shipped preset enables it, configs.py use_warp_reg_loss=False)')
-  if use_elastic_loss and elastic_loss_type != 'log_svals':
-    raise L.NrfError("only elastic_loss_type='log_svals' (the default, training.py:71) is built")
+  ('rgb','origins','directions','metadata').  Returns (new_state, stats, rng_key).
+  `rngs` (extra, parity runs): explicit uniforms {'coarse': (B,N_c), 'fine': (B,N_f)} instead of the streams derived
+  from `rng_key` (the reference's threefry stream is not reproducible without JAX)."""
+  if use_elastic_loss and elastic_loss_type not in L.ELASTIC_TYPE:
+    raise L.NrfError(f"elastic_loss_type {elastic_loss_type!r} is not built (one of {sorted(L.ELASTIC_TYPE)}; 'nr' produces "
+                     'NaNs in the reference itself, training.py:58)')
   # random.split(rng_key, 4) (training.py:168): derive the per-step stream keys from an int key
   rng_key = int(rng_key)
   mix = lambda k, i: (k * 6364136223846793005 + 1442695040888963407 + i) & 0xFFFFFFFFFFFFFFFF
@@ -117,10 +119,13 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
     noise = scalar_params.background_noise_std * torch.randn(pts.shape, generator=g, device=pts.device)
     background = {'points': pts + noise, 'warp_ids': ids, 'weight': scalar_params.background_loss_weight}
   grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
-                                    rngs={'fine': fine_key, 'coarse': coarse_key}, grad_out=opt.grad, stats_out=opt.stats,
+                                    rngs=rngs if rngs is not None else {'fine': fine_key, 'coarse': coarse_key},
+                                    grad_out=opt.grad, stats_out=opt.stats,
                                     background=background,
-                                    elastic={'weight': scalar_params.elastic_loss_weight, 'reduce_method': elastic_reduce_method}
-                                    if use_elastic_loss else None)
+                                    elastic={'weight': scalar_params.elastic_loss_weight, 'reduce_method': elastic_reduce_method,
+                                             'loss_type': elastic_loss_type} if use_elastic_loss else None,
+                                    warp_reg={'weight': scalar_params.warp_reg_loss_weight, 'alpha': scalar_params.warp_reg_loss_alpha,
+                                              'scale': scalar_params.warp_reg_loss_scale} if use_warp_reg_loss else None)
   grad, stats, n = psum_gradients(grad, stats, fused=opt._gs)
   opt.apply_gradient(grad, learning_rate=scalar_params.learning_rate, grad_scale=1.0 / n)
   out = {
@@ -133,4 +138,12 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
     out['coarse']['loss/elastic'] = stats[6]
     out['coarse']['residual/elastic'] = stats[7]
     out['coarse']['loss/total'] = stats[0] + scalar_params.elastic_loss_weight * stats[6]
+    out['coarse']['metric/jacobian_det'] = stats[12]     # training.py:214-222
+    out['coarse']['metric/jacobian_div'] = stats[13]
+    out['coarse']['metric/jacobian_curl'] = stats[14]
+  if use_warp_reg_loss:  # both levels (training.py:199-212)
+    for lv, i in (('coarse', 0), ('fine', 1)):
+      out[lv]['loss/warp_reg'] = stats[8 + i]
+      out[lv]['residual/warp_reg'] = stats[10 + i]
+      out[lv]['loss/total'] = out[lv]['loss/total'] + scalar_params.warp_reg_loss_weight * stats[8 + i]
   return state, out, next_key

@@ -124,21 +124,49 @@ def dense(p: Dict[str, Tensor], x: Tensor) -> Tensor:
   return x @ p['kernel'] + p['bias']
 
 
+# Test hook on the hidden activations: None = nn.relu.  A callable (name, layer, pre) -> activation lets a test
+# (a) record the pre-activations and (b) PIN the ReLU branch pattern to one measured elsewhere
+# (activation = pre * mask, derivative = mask): a pre-activation within float32 rounding of zero takes the other
+# branch in float32 than in float64, which moves whole gradient columns by percents at small batch sizes; with the
+# pattern pinned to the HIP path's own sign bits the comparison is exact again (tests/test_gpu_pinned.py).
+# `name` = '<level>/MLP_0' (NeRF trunk), '<level>/MLP_1' (rgb branch), '<level>/warp' (SE3 / translation trunk),
+# level in {coarse, fine, background}.
+_RELU_HOOK = None
+
+
+class relu_hook:
+  """with relu_hook(fn): ... -- installs `fn(name, layer, pre)` as the hidden activation of every mlp() call."""
+
+  def __init__(self, fn):
+    self.fn = fn
+
+  def __enter__(self):
+    global _RELU_HOOK
+    self.prev, _RELU_HOOK = _RELU_HOOK, self.fn
+    return self
+
+  def __exit__(self, *exc):
+    global _RELU_HOOK
+    _RELU_HOOK = self.prev
+    return False
+
+
 def mlp(p: Dict[str, Any], x: Tensor, depth: int, skips: Sequence[int],
-        has_logit: bool) -> Tensor:
+        has_logit: bool, name: Optional[str] = None) -> Tensor:
   """modules.py:26-62.  ReLU after every hidden layer; skip = concat([x, inputs])."""
   inputs = x
   for i in range(depth):
     if i in skips:
       x = torch.cat([x, inputs], -1)
-    x = torch.relu(dense(p[f'hidden_{i}'], x))
+    pre = dense(p[f'hidden_{i}'], x)
+    x = torch.relu(pre) if (_RELU_HOOK is None or name is None) else _RELU_HOOK(name, i, pre)
   if has_logit:
     x = dense(p['logit'], x)
   return x
 
 
 def nerf_mlp(p: Dict[str, Any], x: Tensor, alpha_condition: Optional[Tensor],
-             rgb_condition: Optional[Tensor], cfg) -> Tuple[Tensor, Tensor]:
+             rgb_condition: Optional[Tensor], cfg, name: Optional[str] = None) -> Tuple[Tensor, Tensor]:
   """modules.py:65-169.  x (B,S,P) -> rgb (B,S,3), alpha (B,S,1).
 
   Flax auto-names: MLP_0 = trunk, MLP_1 = rgb branch, MLP_2 = alpha branch
@@ -150,7 +178,8 @@ def nerf_mlp(p: Dict[str, Any], x: Tensor, alpha_condition: Optional[Tensor],
   def bcast(c):
     return c[:, None, :].expand(B, S, c.shape[-1]).reshape(B * S, -1)
 
-  h = mlp(p['MLP_0'], x, cfg.nerf_trunk_depth, cfg.nerf_skips, False)
+  sub = (lambda k: None) if name is None else (lambda k: f'{name}/{k}')
+  h = mlp(p['MLP_0'], x, cfg.nerf_trunk_depth, cfg.nerf_skips, False, sub('MLP_0'))
   if alpha_condition is not None or rgb_condition is not None:
     bottleneck = dense(p['bottleneck'], h)
   alpha_in = (torch.cat([bottleneck, bcast(alpha_condition)], -1)
@@ -158,7 +187,7 @@ def nerf_mlp(p: Dict[str, Any], x: Tensor, alpha_condition: Optional[Tensor],
   alpha = mlp(p['MLP_2'], alpha_in, 0, (), True)
   rgb_in = (torch.cat([bottleneck, bcast(rgb_condition)], -1)
             if rgb_condition is not None else h)
-  rgb = mlp(p['MLP_1'], rgb_in, cfg.nerf_rgb_branch_depth, (), True)
+  rgb = mlp(p['MLP_1'], rgb_in, cfg.nerf_rgb_branch_depth, (), True, sub('MLP_1'))
   return rgb.reshape(B, S, -1), alpha.reshape(B, S, -1)
 
 
@@ -166,14 +195,14 @@ def nerf_mlp(p: Dict[str, Any], x: Tensor, alpha_condition: Optional[Tensor],
 # warping.py (SE3Field)
 # ----------------------------------------------------------------------------
 def se3_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, alpha,
-             num_warp_freqs: int) -> Tensor:
+             num_warp_freqs: int, name: Optional[str] = None) -> Tensor:
   """warping.py:322-353 (use_pivot / use_translation off, the shipped default).
 
   points (...,3), metadata_embed (...,G).
   """
   points_embed = annealed_sinusoidal_encode(points, num_warp_freqs, alpha)
   inputs = torch.cat([points_embed, metadata_embed], -1)
-  trunk = mlp(p['trunk'], inputs, 6, (4,), False)
+  trunk = mlp(p['trunk'], inputs, 6, (4,), False, name)
   w = dense(p['branches_w']['logit'], trunk)
   v = dense(p['branches_v']['logit'], trunk)
   theta = torch.linalg.norm(w, dim=-1)
@@ -186,25 +215,36 @@ def se3_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, alpha,
 
 
 def translation_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, alpha,
-                     num_warp_freqs: int) -> Tensor:
+                     num_warp_freqs: int, name: Optional[str] = None) -> Tensor:
   """TranslationField.warp (warping.py:155-164): points + MLP([annealed posenc, code]); the MLP is 6 x 128 with the
   skip at 4 and a 3-channel 'logit' output layer (warping.py:129-137)."""
   points_embed = annealed_sinusoidal_encode(points, num_warp_freqs, alpha)
   inputs = torch.cat([points_embed, metadata_embed], -1)
-  return points + mlp(p['mlp'], inputs, 6, (4,), True)
+  return points + mlp(p['mlp'], inputs, 6, (4,), True, name)
+
+
+def time_encode(p, time, num_freqs, alpha=None):
+  """modules.TimeEncoder (modules.py:297-322): MLP(depth 6, width 64, skips (4,), output_channels=features) on the
+  annealed posenc of the time stamp; alpha=None -> num_freqs (full window).  time (...,1) -> (...,features)."""
+  if alpha is None:
+    alpha = num_freqs
+  return mlp(p['mlp'], annealed_sinusoidal_encode(time, num_freqs, alpha), 6, (4,), True)
 
 
 def se3_field(p, points, metadata, warp_alpha, num_warp_freqs,
-              return_jacobian=False, metadata_encoded=False):
+              return_jacobian=False, metadata_encoded=False, name=None, time_alpha=None, num_time_freqs=1):
   """warping.py:355-389 (SE3Field) and :166-199 (TranslationField; selected by the parameter tree: 'mlp' instead of
-  'trunk' + 'branches_*').  metadata: int ids (...,1)/(...) or encoded (...,G)."""
+  'trunk' + 'branches_*').  metadata: int ids (...,1)/(...), float time stamps (...,1) when the metadata encoder is the
+  TimeEncoder (tree has metadata_encoder/mlp; warping.py:311-313), or encoded (...,G)."""
   se3_warp = globals()['translation_warp' if 'mlp' in p else 'se3_warp']
   if metadata_encoded:
     embed = metadata
+  elif 'mlp' in p['metadata_encoder']:
+    embed = time_encode(p['metadata_encoder'], metadata.to(points.dtype), num_time_freqs, time_alpha)
   else:
     ids = metadata[..., 0] if metadata.shape[-1] == 1 else metadata  # glo.py:50-53
     embed = p['metadata_encoder']['embed']['embedding'][ids.long()]
-  out = {'warped_points': se3_warp(p, points, embed, warp_alpha, num_warp_freqs)}
+  out = {'warped_points': se3_warp(p, points, embed, warp_alpha, num_warp_freqs, name)}
   if return_jacobian:
     # jax.jacfwd(self.warp, argnums=0) per point (warping.py:385-387): column c
     # is the forward-mode derivative along e_c.
@@ -215,7 +255,7 @@ def se3_field(p, points, metadata, warp_alpha, num_warp_freqs,
       tangent = torch.zeros_like(flat_pts)
       tangent[:, c] = 1.0
       _, jvp = torch.autograd.functional.jvp(
-          lambda x: se3_warp(p, x, flat_emb, warp_alpha, num_warp_freqs),
+          lambda x: se3_warp(p, x, flat_emb, warp_alpha, num_warp_freqs, name),
           (flat_pts,), (tangent,), create_graph=torch.is_grad_enabled())
       cols.append(jvp)
     out['jacobian'] = torch.stack(cols, -1).reshape(*points.shape[:-1], 3, 3)
@@ -390,6 +430,9 @@ class ModelSpec:
     self.warp_field_type = 'se3'         # warp_defaults.gin; 'translation' = the ModelConfig dataclass default
     self.use_alpha_condition = False
     self.use_rgb_condition = False
+    self.noise_std = None                # models.py:80; defaults.gin leaves it unset
+    self.warp_metadata_encoder_type = 'glo'   # configs.py:101; 'time' = modules.TimeEncoder on metadata['time']
+    self.num_time_encoder_freqs = 1      # metadata_encoder_num_freqs (warping.py:234)
     for k, v in kw.items():
       if not hasattr(self, k):
         raise AttributeError(k)
@@ -476,16 +519,22 @@ def init_params(spec: ModelSpec, seed=0, trained_like=False, dtype=torch.float64
         fin += Ww
       trunk[f'hidden_{i}'] = dense_p(fin, 128)
     head_scale = 0.3 if trained_like else 1e-4
+    if spec.warp_metadata_encoder_type == 'time':   # modules.TimeEncoder: xavier hidden layers, uniform(0.05) output layer
+      Tin = 1 + 2 * spec.num_time_encoder_freqs
+      tm = {f'hidden_{i}': dense_p((Tin if i == 0 else 64) + (Tin if i == 4 else 0), 64) for i in range(6)}
+      tm['logit'] = dense_p(64, spec.num_warp_features, rng.uniform(0, 0.05, size=(64, spec.num_warp_features)))
+      meta_enc = {'mlp': tm}
+    else:
+      meta_enc = {'embed': {'embedding': torch.tensor(
+          rng.uniform(0, 0.05, size=(spec.num_warp_embeddings, spec.num_warp_features)), dtype=dtype)}}
     if spec.warp_field_type == 'translation':     # warping.py:62-137: one MLP with a 3-channel output layer
       params['warp_field'] = {
-          'metadata_encoder': {'embed': {'embedding': torch.tensor(
-              rng.uniform(0, 0.05, size=(spec.num_warp_embeddings, spec.num_warp_features)), dtype=dtype)}},
+          'metadata_encoder': meta_enc,
           'mlp': dict(trunk, logit=dense_p(128, 3, rng.uniform(0, head_scale / 3, size=(128, 3)))),
       }
     else:
       params['warp_field'] = {
-          'metadata_encoder': {'embed': {'embedding': torch.tensor(
-              rng.uniform(0, 0.05, size=(spec.num_warp_embeddings, spec.num_warp_features)), dtype=dtype)}},
+          'metadata_encoder': meta_enc,
           'trunk': trunk,
           'branches_w': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
           'branches_v': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
@@ -549,9 +598,18 @@ def get_condition_inputs(params, spec: ModelSpec, viewdirs, metadata,
   return alpha_c, rgb_c
 
 
+def noise_regularize(raw_alpha, noise_std, use_stratified_sampling, noise):
+  """model_utils.py:266-282: raw density += noise_std * N(0,1) (`noise` = the standard normals random.normal would
+  draw, same shape as raw_alpha)."""
+  if noise_std is not None and noise_std > 0.0 and use_stratified_sampling:
+    assert noise is not None
+    raw_alpha = raw_alpha + noise_std * noise
+  return raw_alpha
+
+
 def render_samples(params, spec: ModelSpec, level, points, z_vals, directions,
                    viewdirs, metadata, warp_alpha, use_warp, use_warp_jacobian,
-                   metadata_encoded=False, return_points=False):
+                   metadata_encoded=False, return_points=False, noise=None, time_alpha=None):
   """models.py:230-287."""
   alpha_c, rgb_c = get_condition_inputs(params, spec, viewdirs, metadata,
                                         metadata_encoded)
@@ -559,11 +617,12 @@ def render_samples(params, spec: ModelSpec, level, points, z_vals, directions,
   if return_points:
     out['points'] = points
   if use_warp:
-    wmeta = metadata['warp']
+    wmeta = metadata['time'] if spec.warp_metadata_encoder_type == 'time' else metadata['warp']   # models.py:252-254
     ch = spec.num_warp_features if metadata_encoded else 1
     wmeta = wmeta[:, None, :].expand(points.shape[0], points.shape[1], ch)
     wout = se3_field(params['warp_field'], points, wmeta, warp_alpha,
-                     spec.num_warp_freqs, use_warp_jacobian, metadata_encoded)
+                     spec.num_warp_freqs, use_warp_jacobian, metadata_encoded, f'{level}/warp',
+                     time_alpha, spec.num_time_encoder_freqs)
     points = wout['warped_points']
     if 'jacobian' in wout:
       out['warp_jacobian'] = wout['jacobian']
@@ -571,7 +630,9 @@ def render_samples(params, spec: ModelSpec, level, points, z_vals, directions,
       out['warped_points'] = wout['warped_points']
   points_embed = sinusoidal_encode(points, spec.num_nerf_point_freqs)
   raw_rgb, raw_alpha = nerf_mlp(params[f'nerf_mlps_{level}'], points_embed,
-                                alpha_c, rgb_c, spec)
+                                alpha_c, rgb_c, spec, level)
+  raw_alpha = noise_regularize(raw_alpha, spec.noise_std, spec.use_stratified_sampling,
+                               None if noise is None else noise[..., None])
   rgb = torch.sigmoid(raw_rgb)
   sigma = _sigma_act(spec.sigma_activation, raw_alpha[..., 0])
   out.update(volumetric_rendering(
@@ -583,7 +644,7 @@ def render_samples(params, spec: ModelSpec, level, points, z_vals, directions,
 def nerf_model_apply(params, spec: ModelSpec, rays_dict, warp_alpha=0.0,
                      metadata_encoded=False, use_warp=True, return_points=False,
                      return_warp_jacobian=False, use_warp_jacobian=False,
-                     t_rand=None, u=None, fixed_fine_z=None):
+                     t_rand=None, u=None, fixed_fine_z=None, noise_coarse=None, noise_fine=None, time_alpha=0.0):
   """models.py:289-375.  t_rand (B,N_c) / u (B,N_f) stand in for the 'coarse'
   and 'fine' RNG streams; always returns weights for both levels.
   fixed_fine_z (test hook): use these fine z_vals instead of resampling, so a
@@ -598,7 +659,7 @@ def nerf_model_apply(params, spec: ModelSpec, rays_dict, warp_alpha=0.0,
   coarse = render_samples(
       params, spec, 'coarse', points, z_vals, directions, viewdirs, metadata,
       warp_alpha, use_warp, return_warp_jacobian or use_warp_jacobian,
-      metadata_encoded, return_points)
+      metadata_encoded, return_points, noise_coarse, time_alpha)
   coarse['z_vals'] = z_vals
   out = {'coarse': coarse}
   if spec.num_fine_samples > 0:
@@ -612,7 +673,7 @@ def nerf_model_apply(params, spec: ModelSpec, rays_dict, warp_alpha=0.0,
     fine = render_samples(
         params, spec, 'fine', points_f, z_f, directions, viewdirs, metadata,
         warp_alpha, use_warp, return_warp_jacobian, metadata_encoded,
-        return_points)
+        return_points, noise_fine, time_alpha)
     fine['z_vals'] = z_f
     out['fine'] = fine
   return out
@@ -621,11 +682,38 @@ def nerf_model_apply(params, spec: ModelSpec, rays_dict, warp_alpha=0.0,
 # ----------------------------------------------------------------------------
 # training.py
 # ----------------------------------------------------------------------------
-def compute_elastic_loss(jacobian, eps=1e-6):
-  """training.py:71-114, loss_type='log_svals'."""
-  svals = torch.linalg.svdvals(jacobian)
-  log_svals = torch.log(torch.clamp(svals, min=eps))
-  sq_residual = (log_svals ** 2).sum(-1)
+def jacobian_to_curl(jacobian):
+  """utils.py:71-84."""
+  return torch.stack([jacobian[..., 2, 1] - jacobian[..., 1, 2],
+                      jacobian[..., 0, 2] - jacobian[..., 2, 0],
+                      jacobian[..., 1, 0] - jacobian[..., 0, 1]], -1)
+
+
+def jacobian_to_div(jacobian):
+  """utils.py:87-91."""
+  return torch.diagonal(jacobian, dim1=-2, dim2=-1).sum(-1) - 3.0
+
+
+def compute_elastic_loss(jacobian, eps=1e-6, loss_type='log_svals'):
+  """training.py:71-114 (every loss_type but 'nr', which the reference marks as producing NaNs, training.py:58)."""
+  if loss_type == 'log_svals':
+    svals = torch.linalg.svdvals(jacobian)
+    log_svals = torch.log(torch.clamp(svals, min=eps))
+    sq_residual = (log_svals ** 2).sum(-1)
+  elif loss_type == 'svals':
+    svals = torch.linalg.svdvals(jacobian)
+    sq_residual = ((svals - 1.0) ** 2).sum(-1)
+  elif loss_type == 'jtj':
+    jtj = jacobian @ jacobian.transpose(-1, -2)
+    sq_residual = ((jtj - torch.eye(3, dtype=jacobian.dtype)) ** 2).sum((-1, -2)) / 4.0
+  elif loss_type == 'div':
+    sq_residual = jacobian_to_div(jacobian) ** 2
+  elif loss_type == 'det':
+    sq_residual = (torch.linalg.det(jacobian) - 1.0) ** 2
+  elif loss_type == 'log_det':
+    sq_residual = torch.log(torch.clamp(torch.linalg.det(jacobian), min=eps)) ** 2
+  else:
+    raise NotImplementedError(loss_type)
   residual = torch.sqrt(sq_residual)
   loss = general_loss_with_squared_residual(sq_residual, alpha=-2.0, scale=0.03)
   return loss, residual
@@ -636,7 +724,7 @@ def compute_background_loss(params, spec, points, warp_ids_per_point, noise,
   """training.py:117-135 with the random ids / noise supplied by the caller."""
   points = points + noise
   wout = se3_field(params['warp_field'], points, warp_ids_per_point, warp_alpha,
-                   spec.num_warp_freqs, False, False)
+                   spec.num_warp_freqs, False, False, 'background/warp')
   sq_residual = ((wout['warped_points'] - points) ** 2).sum(-1)
   return general_loss_with_squared_residual(sq_residual, alpha=alpha, scale=scale)
 
@@ -644,11 +732,14 @@ def compute_background_loss(params, spec, points, warp_ids_per_point, noise,
 def loss_fn(params, spec: ModelSpec, batch, warp_alpha=0.0, t_rand=None, u=None,
             use_elastic_loss=False, elastic_loss_weight=0.0,
             elastic_reduce_method='weight', use_background_loss=False,
-            background_loss_weight=0.0, background=None, fixed_fine_z=None):
+            background_loss_weight=0.0, background=None, fixed_fine_z=None,
+            elastic_loss_type='log_svals', use_warp_reg_loss=False, warp_reg_loss_weight=0.0,
+            warp_reg_loss_alpha=-2.0, warp_reg_loss_scale=0.001, noise_coarse=None, noise_fine=None, time_alpha=0.0):
   """training.py:171-262 (_compute_loss_and_stats + _loss_fn)."""
   ret = nerf_model_apply(params, spec, batch, warp_alpha, t_rand=t_rand, u=u,
                          use_warp_jacobian=use_elastic_loss,
-                         fixed_fine_z=fixed_fine_z)
+                         fixed_fine_z=fixed_fine_z, return_points=use_warp_reg_loss,
+                         noise_coarse=noise_coarse, noise_fine=noise_fine, time_alpha=time_alpha)
   total = 0.0
   stats = {}
   for level in ('fine', 'coarse'):
@@ -664,13 +755,26 @@ def loss_fn(params, spec: ModelSpec, batch, warp_alpha=0.0, t_rand=None, u=None,
       if elastic_reduce_method == 'median':
         idx = compute_depth_index(weights)
         jac = torch.take_along_dim(jac, idx[..., None, None, None], dim=-3)
-      el, el_res = compute_elastic_loss(jac)
+      el, el_res = compute_elastic_loss(jac, loss_type=elastic_loss_type)
       if elastic_reduce_method == 'weight':
         el = weights * el
       el = el.sum(-1).mean()
       st['loss/elastic'] = el
       st['residual/elastic'] = el_res.mean()
       loss = loss + elastic_loss_weight * el
+    if use_warp_reg_loss:   # training.py:199-212
+      idx = compute_depth_index(mo['weights'].detach())
+      warp_mag = ((mo['points'] - mo['warped_points']) ** 2).sum(-1)
+      wr_res = torch.take_along_dim(warp_mag, idx[..., None], dim=-1)
+      wr = general_loss_with_squared_residual(wr_res, alpha=warp_reg_loss_alpha, scale=warp_reg_loss_scale).mean()
+      st['loss/warp_reg'] = wr
+      st['residual/warp_reg'] = torch.sqrt(wr_res).mean()
+      loss = loss + warp_reg_loss_weight * wr
+    if 'warp_jacobian' in mo:   # training.py:214-222
+      jac_all = mo['warp_jacobian']
+      st['metric/jacobian_det'] = torch.linalg.det(jac_all).mean()
+      st['metric/jacobian_div'] = jacobian_to_div(jac_all).mean()
+      st['metric/jacobian_curl'] = torch.linalg.norm(jacobian_to_curl(jac_all), dim=-1).mean()
     st['loss/total'] = loss
     st['metric/psnr'] = compute_psnr(rgb_loss)
     stats[level] = st
@@ -723,10 +827,12 @@ def synthetic_batch(num_rays, seed=0, dtype=torch.float64, num_ids=4,
   rgb = rng.uniform(0, 1, size=(num_rays, 3))
   ids = rng.integers(0, num_ids, size=(num_rays, 1))
   cam = rng.integers(0, num_camera_ids, size=(num_rays, 1))
+  # metadata['time'] in [-1, 1] as datasets/core.py:272-274 builds it from the frame's time id
+  time = ids.astype(np.float64) / max(num_ids - 1, 1) * 2.0 - 1.0
   return {
       'origins': torch.tensor(o, dtype=dtype),
       'directions': torch.tensor(d, dtype=dtype),
       'rgb': torch.tensor(rgb, dtype=dtype),
       'metadata': {'warp': torch.tensor(ids), 'appearance': torch.tensor(ids),
-                   'camera': torch.tensor(cam)},
+                   'camera': torch.tensor(cam), 'time': torch.tensor(time, dtype=dtype)},
   }

@@ -153,17 +153,18 @@ NERF_CASES = {
 }
 
 
-def build_ref_model(spec):
+def build_ref_model(spec, **extra):
   return ref_models.NerfModel(
       num_coarse_samples=spec.num_coarse_samples, num_fine_samples=spec.num_fine_samples, use_viewdirs=spec.use_viewdirs,
-      near=spec.near, far=spec.far, noise_std=None, nerf_trunk_depth=8, nerf_trunk_width=256, nerf_rgb_branch_depth=1,
+      near=spec.near, far=spec.far, noise_std=spec.noise_std, nerf_trunk_depth=8, nerf_trunk_width=256, nerf_rgb_branch_depth=1,
       nerf_rgb_branch_width=128, nerf_skips=(4,), alpha_channels=1, rgb_channels=3,
       use_stratified_sampling=spec.use_stratified_sampling, num_nerf_point_freqs=spec.num_nerf_point_freqs,
       num_nerf_viewdir_freqs=spec.num_nerf_viewdir_freqs, appearance_ids=tuple(range(spec.num_appearance_embeddings)),
       camera_ids=tuple(range(spec.num_camera_embeddings)), warp_ids=tuple(range(spec.num_warp_embeddings)),
       num_appearance_features=spec.num_appearance_features, num_camera_features=spec.num_camera_features,
       num_warp_features=spec.num_warp_features, num_warp_freqs=spec.num_warp_freqs, sigma_activation=nn.softplus,
-      use_camera_metadata=spec.use_camera_metadata, use_warp=spec.use_warp, warp_field_type='se3')
+      use_camera_metadata=spec.use_camera_metadata, use_warp=spec.use_warp, warp_field_type='se3',
+      use_appearance_metadata=spec.use_appearance_metadata, use_alpha_condition=spec.use_alpha_condition, **extra)
 
 
 def nerf_model():
@@ -309,6 +310,131 @@ def cameras():
   save('camera', **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# round 2: the rest of NerfModel.apply's contract and of train_step's loss assembly
+# ---------------------------------------------------------------------------------------------
+NERF_CASES_R2 = {
+    # use_alpha_condition: the appearance code conditions the alpha head AND (models.py:206) the rgb branch
+    'alpha_cond': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True,
+                        use_appearance_metadata=True, use_alpha_condition=True, use_camera_metadata=True), 0.0),
+    # (noise_std > 0 cannot be driven through the reference's NerfModel: models.py:274 hands noise_regularize the
+    #  {'rgb', 'alpha'} DICT the MLP returns, and model_utils.py:280 slices it like the array it was in jaxnerf ->
+    #  TypeError under JAX as well.  noise_regularize itself is pinned on an array in elastic_types_and_noise().)
+    # every code path at once, evaluated with metadata_encoded=True on the gathered codes
+    'encoded': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                     num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True, use_appearance_metadata=True,
+                     use_alpha_condition=True), 3.25),
+    # warp_metadata_encoder_type = 'time': modules.TimeEncoder on metadata['time'], half-open annealing window
+    'time': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                  num_warp_freqs=5, num_warp_features=8, warp_metadata_encoder_type='time'), 3.25),
+}
+TIME_ALPHA = 0.6
+
+
+def nerf_model_r2():
+  for name, (kw, alpha) in NERF_CASES_R2.items():
+    spec = O.ModelSpec(**kw)
+    seed = sum(ord(c) for c in name)
+    params = O.init_params(spec, seed=seed, trained_like=True)
+    pn = tree_np(params)
+    batch = O.synthetic_batch(3, seed=seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    Nc, Nf = spec.num_coarse_samples, spec.num_fine_samples
+    t_rand = rng.uniform(0, 1, (3, Nc)); u = rng.uniform(0, 1, (3, Nf))
+    nz_c = rng.normal(size=(3, Nc)); nz_f = rng.normal(size=(3, Nc + Nf))
+    model = build_ref_model(spec, warp_metadata_encoder_type=spec.warp_metadata_encoder_type)
+    md = {k: v.numpy() for k, v in batch['metadata'].items()}
+    encoded = name == 'encoded'
+    if encoded:   # the codes the encoders would produce (glo.py:50-53), handed over pre-encoded
+      md = {'warp': pn['warp_field']['metadata_encoder']['embed']['embedding'][md['warp'][:, 0]],
+            'appearance': pn['appearance_encoder']['embed']['embedding'][md['appearance'][:, 0]],
+            'camera': pn['camera_encoder']['embed']['embedding'][md['camera'][:, 0]]}
+    rays = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(), 'metadata': md}
+    ret = model.apply({'params': pn}, rays, {'alpha': alpha, 'time_alpha': TIME_ALPHA}, metadata_encoded=encoded,
+                      return_points=spec.use_warp, return_weights=True, return_warp_jacobian=spec.use_warp,
+                      rngs={'coarse': jrandom.Key(uniform=t_rand, normal=nz_c[..., None]),
+                            'fine': jrandom.Key(uniform=u, normal=nz_f[..., None])})
+    out = dict(t_rand=t_rand, u=u, noise_coarse=nz_c, noise_fine=nz_f, alpha=alpha, time_alpha=TIME_ALPHA, seed=seed)
+    if encoded:
+      out.update({'codes/' + k: v for k, v in md.items()})
+    for lv, d in ret.items():
+      for k, v in d.items():
+        out[f'{lv}/{k}'] = v
+    save('nerf_' + name, **out)
+
+
+TRAIN_CASES = {
+    # name: (elastic_loss_type, elastic_reduce_method, use_warp_reg_loss)
+    'log_svals_weight': ('log_svals', 'weight', True),
+    'svals_median': ('svals', 'median', False),
+    'jtj_weight': ('jtj', 'weight', False),
+    'div_weight': ('div', 'weight', True),
+    'det_median': ('det', 'median', False),
+    'log_det_weight': ('log_det', 'weight', False),
+}
+
+
+def train_step_stats():
+  """training.train_step itself (training.py:138-271), forward half: the reference's own loss assembly -- rgb, every
+  elastic_loss_type under both reduce methods, warp_reg, background, the Jacobian metrics, totals, psnr -- on the oracle's
+  parameters.  jax.value_and_grad is stood in for by a plain evaluation (the gradient half is torch.autograd on the
+  oracle), random.split hands train_step the four prepared keys, the optimizer is a pass-through."""
+  import types
+  import jax
+  spec = O.ModelSpec(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                     num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True)
+  params = O.init_params(spec, seed=41, trained_like=True)
+  batch = O.synthetic_batch(3, seed=42)
+  rng = np.random.default_rng(43)
+  t_rand = rng.uniform(0, 1, (3, 8)); u = rng.uniform(0, 1, (3, 6))
+  nbg = 7
+  bg_pts = rng.uniform(-0.4, 0.4, (nbg, 3)); bg_ids = rng.integers(0, 4, (nbg, 1)); bg_noise = rng.normal(size=(nbg, 3))
+  model = build_ref_model(spec, use_warp_jacobian=True)
+  rb = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(), 'rgb': batch['rgb'].numpy(),
+        'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}, 'background_points': bg_pts}
+  sp = ref_training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, warp_reg_loss_weight=0.5, warp_reg_loss_alpha=-2.0,
+                                 warp_reg_loss_scale=0.001, background_loss_weight=1.5, background_noise_std=0.001)
+
+  class Opt:
+    target = {'model': tree_np(params)}
+
+    def apply_gradient(self, grad, learning_rate):
+      return self
+  state = types.SimpleNamespace(optimizer=Opt(), warp_extra={'alpha': 3.25, 'time_alpha': 0.0}, replace=lambda **kw: None)
+  bundle = jrandom.Key()
+  bundle.parts = [jrandom.Key(), jrandom.Key(uniform=u), jrandom.Key(uniform=t_rand), jrandom.Key(normal=bg_noise, choice=bg_ids)]
+  split0, vag0 = jrandom.split, jax.value_and_grad
+  jrandom.split = lambda key, num=2: key.parts if hasattr(key, 'parts') and num == 4 else split0(key, num)
+  jax.value_and_grad = lambda fn, has_aux=False: (lambda p: (fn(p), None))
+  out = dict(t_rand=t_rand, u=u, alpha=3.25, bg_points=bg_pts, bg_ids=bg_ids, bg_noise=bg_noise, elastic_loss_weight=0.01,
+             warp_reg_loss_weight=0.5, background_loss_weight=1.5)
+  try:
+    for name, (ltype, method, wreg) in TRAIN_CASES.items():
+      _, stats, _ = ref_training.train_step(model, bundle, state, rb, sp, use_elastic_loss=True, elastic_reduce_method=method,
+                                            elastic_loss_type=ltype, use_background_loss=True, use_warp_reg_loss=wreg)
+      for lv in ('coarse', 'fine'):
+        for k, v in stats[lv].items():
+          out[f'{name}/{lv}/{k}'] = np.asarray(v)
+      out[f'{name}/background_loss'] = np.asarray(stats['background_loss'])
+  finally:
+    jrandom.split, jax.value_and_grad = split0, vag0
+  save('train_step_stats', **out)
+
+
+def elastic_types_and_noise():
+  rng = np.random.default_rng(51)
+  J = np.eye(3) + 0.25 * rng.normal(size=(6, 3, 3))
+  out = dict(J=J, div=np.array([ref_utils.jacobian_to_div(j) for j in J]), curl=np.stack([ref_utils.jacobian_to_curl(j) for j in J]))
+  for t in ('log_svals', 'svals', 'jtj', 'div', 'det', 'log_det'):
+    el = [ref_training.compute_elastic_loss(j, loss_type=t) for j in J]
+    out[f'{t}/loss'] = np.array([e[0] for e in el]); out[f'{t}/residual'] = np.array([e[1] for e in el])
+  raw = rng.normal(size=(2, 5, 4)); nz = rng.normal(size=(2, 5, 1))
+  out.update(raw=raw, normals=nz, noised_strat=ref_mu.noise_regularize(jrandom.Key(normal=nz), raw, 0.4, True),
+             noised_det=ref_mu.noise_regularize(jrandom.Key(normal=nz), raw, 0.4, False),
+             noised_none=ref_mu.noise_regularize(jrandom.Key(normal=nz), raw, None, True))
+  save('elastic_types_noise', **out)
+
+
 if __name__ == '__main__':
   rigid_body()
   model_utils()
@@ -321,3 +447,6 @@ if __name__ == '__main__':
   dataset_items()
   losses_and_schedules()
   cameras()
+  nerf_model_r2()
+  train_step_stats()
+  elastic_types_and_noise()

@@ -1,6 +1,8 @@
 """Shared test plumbing: oracle ModelSpec -> nerfies_amd model on the GPU with identical parameters."""
+import os
 import types
 
+import numpy as np
 import torch
 
 from oracle import nerfies_oracle as O
@@ -21,7 +23,8 @@ def config_from_spec(spec):
       use_appearance_metadata=spec.use_appearance_metadata, use_camera_metadata=spec.use_camera_metadata,
       appearance_metadata_dims=spec.num_appearance_features, camera_metadata_dims=spec.num_camera_features,
       use_warp=spec.use_warp, num_warp_freqs=spec.num_warp_freqs, num_warp_features=spec.num_warp_features,
-      warp_field_type=spec.warp_field_type, use_alpha_condition=spec.use_alpha_condition, use_rgb_condition=spec.use_rgb_condition)
+      warp_field_type=spec.warp_field_type, use_alpha_condition=spec.use_alpha_condition, use_rgb_condition=spec.use_rgb_condition,
+      noise_std=spec.noise_std)
 
 
 def gpu_model(spec, oparams, batch_size=0):
@@ -43,3 +46,214 @@ def gpu_batch(batch):
 def flat_grad_from_tree(grads, layout):
   from nerfies_amd import params as P
   return P.flat_from_tree(O.tree_map(lambda t: t.float(), grads), layout, 'cpu')
+
+
+# ---------------------------------------------------------------------------------------------
+# ReLU sign bits of the last stashed forward (training workspace), decoded to boolean masks the
+# oracle can be pinned to (oracle.relu_hook).  Layout: include/nerfies_amd.h nrf_debug_ws_offset.
+# ---------------------------------------------------------------------------------------------
+def _ws_words(model, ws, name, level, nwords):
+  import ctypes as C
+  from nerfies_amd import lib as L
+  off = C.c_int64(0)
+  L.check(model.lib.nrf_debug_ws_offset(model.handle, name.encode(), level, C.byref(off)), model.lib)
+  return ws[off.value:off.value + nwords].view(torch.int32).cpu().numpy().view('uint32')
+
+
+def _decode_bits(words, nlayers, ntiles, ncb, rows):
+  """words: uint32 [nlayers][ntiles][4 waves][64 lanes][ncb] -> bool [nlayers][rows][4 * 32 * ncb]."""
+  import numpy as np
+  w = words.reshape(nlayers, ntiles, 4, 64, ncb)
+  q, e = np.arange(8), np.arange(4)
+  bits = ((w[..., None, None] >> (4 * q[:, None] + e[None, :]).astype('uint32')) & 1).astype(bool)   # [L][t][wave][lane][cb][q][e]
+  lane = np.arange(64)
+  j, h = lane & 31, lane >> 5
+  g = (q[None, :] & 1) + 2 * h[:, None] + 4 * (q[None, :] >> 1)          # [lane][q]
+  p = 4 * g[:, :, None] + e[None, None, :]                               # [lane][q][e] tile row
+  wave, cb = np.arange(4), np.arange(ncb)
+  n = wave[:, None, None] * 32 * ncb + 32 * cb[None, None, :] + j[None, :, None]   # [wave][lane][cb] feature
+  out = np.zeros((nlayers, ntiles * 64, 4 * 32 * ncb), bool)
+  t = np.arange(ntiles)
+  rows_idx = (t[:, None, None, None, None, None] * 64 + p[None, None, :, None, :, :])          # [t][1][lane][1][q][e]
+  rows_idx = np.broadcast_to(rows_idx, (ntiles, 4, 64, ncb, 8, 4))
+  cols_idx = np.broadcast_to(n[None, :, :, :, None, None], (ntiles, 4, 64, ncb, 8, 4))
+  for l in range(nlayers):
+    out[l][rows_idx, cols_idx] = bits[l]
+  return torch.from_numpy(out[:, :rows])
+
+
+def gpu_relu_masks(model, spec, num_rays, nbg=0, elastic=False):
+  """{oracle hook name: [bool (rows, width) per layer]} read back from the training workspace of the last
+  loss_and_grad / apply(train=True) call with these sizes."""
+  ws = model.workspace(num_rays, True, DEV, nbg, elastic)
+  torch.cuda.synchronize()
+  masks = {}
+  levels = [('coarse', 0, num_rays * spec.num_coarse_samples)]
+  if spec.num_fine_samples > 0:
+    levels.append(('fine', 1, num_rays * (spec.num_coarse_samples + spec.num_fine_samples)))
+  for name, lv, rows in levels:
+    nt = (rows + 63) // 64
+    m = _decode_bits(_ws_words(model, ws, 'bits_trunk', lv, nt * 4 * 128 * 8), 8, nt, 2, rows)
+    masks[f'{name}/MLP_0'] = [m[l][:, :spec.nerf_trunk_width] for l in range(8)]
+    m = _decode_bits(_ws_words(model, ws, 'bits_rgbh', lv, nt * 4 * 64), 1, nt, 1, rows)
+    masks[f'{name}/MLP_1'] = [m[0][:, :spec.nerf_rgb_branch_width]]
+    if spec.use_warp:
+      m = _decode_bits(_ws_words(model, ws, 'w_bits', lv, nt * 4 * 64 * 6), 6, nt, 1, rows)
+      masks[f'{name}/warp'] = [m[l] for l in range(6)]
+  if spec.use_warp and nbg > 0:
+    nt = (nbg + 63) // 64
+    m = _decode_bits(_ws_words(model, ws, 'w_bits', 2, nt * 4 * 64 * 6), 6, nt, 1, nbg)
+    masks['background/warp'] = [m[l] for l in range(6)]
+  return masks
+
+
+class PinnedRelu:
+  """oracle.relu_hook callable: activation = pre * mask with the HIP path's masks.  Records where the oracle's own sign
+  disagrees: `flips` / `total` units and, per disagreeing unit, |pre| relative to its layer's rms (`mags`)."""
+
+  def __init__(self, masks):
+    self.masks = masks
+    self.flips, self.total, self.mags = 0, 0, []
+
+  def __call__(self, name, layer, pre):
+    m = self.masks[name][layer].reshape(pre.shape)
+    with torch.no_grad():
+      bad = (pre.detach() > 0) != m
+      nb = int(bad.sum())
+      self.flips += nb
+      self.total += m.numel()
+      if nb:
+        rms = float(pre.detach().pow(2).mean().sqrt())
+        self.mags.append(pre.detach()[bad].abs().double() / max(rms, 1e-30))
+    return pre * m.to(pre.dtype)
+
+  @property
+  def worst(self):
+    return float(torch.cat(self.mags).max()) if self.mags else 0.0
+
+  def quantile(self, q):
+    return float(torch.cat(self.mags).quantile(q)) if self.mags else 0.0
+
+
+# ---------------------------------------------------------------------------------------------
+# Pinned-branch gradient parity (see tests/test_gpu_pinned.py for the rationale)
+# ---------------------------------------------------------------------------------------------
+FLIP_FRACTION = 2e-3     # units whose fp64 sign differs from the HIP path's
+FLIP_PRE = 5e-3          # ... and the 95th percentile of their |pre| relative to the layer rms (rounding-level ties only)
+
+
+def grad_tol(spec):
+  """Per-leaf gradient tolerance, relative to the leaf's max-abs entry: 2e-3, and 4e-3 with the warp on at F_p = 9, 10.
+  With the warp on, float32 rounding of the warped point (3e-8 absolute) is a phase error of 2^(F_p-1) * 3e-8 in the top
+  posenc band; the per-sample dL/dx' (dominated by the top bands, magnitude ~2^F_p) cancels across samples into a much
+  smaller parameter gradient, so the RELATIVE error of the warp leaves grows like 2^F_p in ANY float32 evaluation: the
+  oracle's own float32 restatement, with identical branches and samples, is 4e-4 from float64 at F_p = 8 and 1-2e-3 at
+  F_p = 10 (tests/test_pinned_host.py::test_float32_floor_of_the_warp_gradients)."""
+  return 4e-3 if (spec.use_warp and spec.num_nerf_point_freqs > 8) else 2e-3
+
+
+def host_threads(n):
+  class _T:
+    def __enter__(self):
+      self.prev = torch.get_num_threads()
+      torch.set_num_threads(max(1, min(n, os.cpu_count() or 1)))
+
+    def __exit__(self, *a):
+      torch.set_num_threads(self.prev)
+  return _T()
+
+
+def leaf(tree, path):
+  node = tree
+  for k in path.split('/'):
+    node = node[k]
+  return node
+
+
+def run_pinned(spec, B, alpha, seed=3, strat=True, elastic=None, background=None, params=None, batch=None, t_rand=None, u=None,
+               warp_reg=None):
+  """GPU loss_and_grad, masks read back, fp64 oracle pinned to them.  Returns a dict of everything compared."""
+  from nerfies_amd import params as P
+  p64 = params if params is not None else O.init_params(spec, seed=seed, trained_like=True, dtype=torch.float64)
+  b64 = batch if batch is not None else O.synthetic_batch(B, seed=seed + 1, dtype=torch.float64)
+  model, fp = gpu_model(spec, p64, B)
+  gb = gpu_batch(b64)
+  rngs = None
+  if spec.use_stratified_sampling and t_rand is None:
+    g = torch.Generator().manual_seed(seed)
+    t_rand = torch.rand(B, spec.num_coarse_samples, generator=g).double()
+    u = torch.rand(B, spec.num_fine_samples, generator=g).double()
+  if t_rand is not None:
+    rngs = {'coarse': t_rand.float().to(DEV), 'fine': u.float().to(DEV)}
+  gkw, okw, nbg = {}, {}, 0
+  if background is not None:   # dict(points, warp_ids, noise, weight)
+    nbg = background['points'].shape[0]
+    gkw['background'] = {'points': (background['points'] + background['noise']).float().to(DEV),
+                         'warp_ids': background['warp_ids'].to(DEV), 'weight': background['weight']}
+    okw.update(use_background_loss=True, background_loss_weight=background['weight'],
+               background={k: background[k] for k in ('points', 'warp_ids', 'noise')})
+  if elastic is not None:      # dict(weight, reduce_method[, loss_type])
+    gkw['elastic'] = dict(elastic)
+    okw.update(use_elastic_loss=True, elastic_loss_weight=elastic['weight'], elastic_reduce_method=elastic.get('reduce_method', 'weight'),
+               elastic_loss_type=elastic.get('loss_type', 'log_svals'))
+  if warp_reg is not None:     # dict(weight[, alpha, scale])
+    gkw['warp_reg'] = dict(warp_reg)
+    okw.update(use_warp_reg_loss=True, warp_reg_loss_weight=warp_reg['weight'], warp_reg_loss_alpha=warp_reg.get('alpha', -2.0),
+               warp_reg_loss_scale=warp_reg.get('scale', 0.001))
+  if spec.noise_std and spec.use_stratified_sampling:   # explicit normals for model_utils.noise_regularize
+    g2 = torch.Generator().manual_seed(seed + 77)
+    nz_c = torch.randn(B, spec.num_coarse_samples, generator=g2).double()
+    nz_f = torch.randn(B, spec.num_coarse_samples + spec.num_fine_samples, generator=g2).double()
+    rngs = dict(rngs or {}, noise_coarse=nz_c.float().to(DEV), noise_fine=nz_f.float().to(DEV))
+    okw.update(noise_coarse=nz_c, noise_fine=nz_f)
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha}, rngs=rngs, **gkw)
+  torch.cuda.synchronize()
+  masks = gpu_relu_masks(model, spec, B, nbg, elastic is not None)
+  hook = PinnedRelu(masks)
+  # the fine samples are a stop_gradient input of the fine pass (model_utils.py:187): the oracle takes the HIP path's own
+  # (they agree with its natural ones to ~1e-5, asserted below; through the 2^(F_p-1) posenc that difference alone
+  # would move the gradients by more than the kernels' own error)
+  z_fine = None
+  if spec.num_fine_samples > 0:
+    ws = model.workspace(B, True, DEV, nbg, elastic is not None)
+    S1 = spec.num_coarse_samples + spec.num_fine_samples
+    z_fine = _ws_words(model, ws, 'z', 1, B * S1).view('float32').reshape(B, S1)
+    z_fine = torch.from_numpy(z_fine.copy()).double()
+  with O.relu_hook(hook):
+    loss, ostats, ograds, ret = O.loss_and_grad(p64, spec, b64, warp_alpha=alpha, t_rand=t_rand, u=u, fixed_fine_z=z_fine, **okw)
+  if z_fine is not None:   # ... and its own resampling lands on the same depths
+    with torch.no_grad():
+      z_nat = O.sample_pdf(.5 * (ret['coarse']['z_vals'][..., 1:] + ret['coarse']['z_vals'][..., :-1]), ret['coarse']['weights'][..., 1:-1],
+                           b64['origins'], b64['directions'], ret['coarse']['z_vals'], spec.num_fine_samples,
+                           spec.use_stratified_sampling, u)[0]
+    assert (z_nat - z_fine).abs().max().item() < 2e-4 * (spec.far - spec.near), (z_nat - z_fine).abs().max().item()
+    assert (z_nat - z_fine).abs().mean().item() < 2e-6 * (spec.far - spec.near)
+  got = P.tree_from_flat(grad.cpu(), model.layout)
+  errs = {}
+  for path, og in O.tree_leaves_with_path(ograds):
+    scale = max(og.abs().max().item(), 1e-30)
+    errs[path] = ((leaf(got, path).double() - og).abs().max().item() / scale, scale)
+  return dict(model=model, fp=fp, gb=gb, rngs=rngs, stats=stats.cpu(), loss=loss.item(), ostats=ostats, ret=ret, errs=errs, hook=hook,
+              alpha=alpha, tol=grad_tol(spec))
+
+
+def assert_pinned(r, label, loss_tol=1e-5):
+  assert abs(r['stats'][4].item() - r['loss']) < loss_tol, (label, r['stats'][4].item(), r['loss'])
+  worst = max(r['errs'].items(), key=lambda kv: kv[1][0])
+  print(f'[{label}] loss gpu {r["stats"][4].item():.7f} oracle {r["loss"]:.7f}; worst leaf {worst[0]} rel err {worst[1][0]:.2e}; '
+        f'ReLU ties {r["hook"].flips}/{r["hook"].total} (|pre|/rms: 95 % below {r["hook"].quantile(0.95):.1e}, max {r["hook"].worst:.1e})')
+  for path, (err, scale) in r['errs'].items():
+    assert err < r['tol'], (label, path, err, scale)
+  h = r['hook']
+  assert h.flips <= FLIP_FRACTION * h.total, (label, h.flips, h.total)
+  assert h.quantile(0.95) < FLIP_PRE, (label, h.quantile(0.95), h.worst)
+
+
+def assert_forward(r, spec, atol=1e-4):
+  """The rendered outputs of a (non-training) forward on the same rays against the pinned oracle's."""
+  out = r['model'].apply({'params': r['fp']}, r['gb'], {'alpha': r['alpha']}, rngs=r['rngs'], return_weights=True)
+  for lv in out:
+    for k in ('rgb', 'depth', 'acc', 'weights'):
+      np.testing.assert_allclose(out[lv][k].cpu().numpy(), r['ret'][lv][k].detach().numpy(), atol=atol, err_msg=f'{lv}/{k}')
+
+

@@ -51,8 +51,17 @@ def test_struct_sizes_match_header():
   fields = re.findall(r'\b(?:int32_t|float)\s+([a-z_0-9]+);', body)
   assert [f[0] for f in L.ModelDesc._fields_] == fields
   assert C.sizeof(L.ModelDesc) == 4 * len(fields)
-  assert C.sizeof(L.Rays) == 8 + 6 * 8
+  assert C.sizeof(L.Rays) == 8 + 10 * 8
   assert C.sizeof(L.TensorInfo) == 96 + 8 + 4 + 4
+  # every other POD struct: same field names in the same order as the header, pointer / 4-byte / 8-byte fields only
+  for cname, ct in (('nrf_rays', L.Rays), ('nrf_step_scalars', L.StepScalars), ('nrf_rand', L.Rand), ('nrf_level_out', L.LevelOut),
+                    ('nrf_background', L.Background), ('nrf_elastic', L.Elastic), ('nrf_warp_reg', L.WarpReg)):
+    body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (cname, cname), src, flags=re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    names = re.findall(r'([a-z_0-9]+)\s*;', body)
+    assert [f[0] for f in ct._fields_] == names, (cname, names)
+  assert '#define NRF_NUM_STATS %d' % L.NRF_NUM_STATS in src
+  assert '#define NRF_FLAG_WARP_JACOBIAN %du' % L.NRF_FLAG_WARP_JACOBIAN in src
 
 
 def _desc(**kw):
@@ -96,6 +105,21 @@ def test_param_layout_uses_flax_paths(lib):
   assert names['nerf_mlps_fine/MLP_1/hidden_0/kernel'][:2] == (256 + 27 + 2, 128)  # bottleneck + viewdirs + camera
   assert names['nerf_mlps_fine/MLP_2/logit/kernel'][:2] == (256, 1)
   assert names['camera_encoder/embed/embedding'][:2] == (2, 2)
+  # use_alpha_condition (modules.py:152-157, models.py:204-208): the appearance code widens the alpha head AND the rgb branch
+  h2 = C.c_void_p()
+  d2 = _desc(use_appearance_metadata=1, num_appearance_embeddings=4, num_appearance_features=8, use_alpha_condition=1)
+  assert lib.nrf_create(C.byref(d2), C.byref(h2)) == 0
+  n2 = C.c_int32(0)
+  assert lib.nrf_param_layout(h2, None, C.byref(n2)) == 0
+  infos2 = (L.TensorInfo * n2.value)()
+  assert lib.nrf_param_layout(h2, infos2, C.byref(n2)) == 0
+  names2 = {t.name.decode(): (t.rows, t.cols) for t in infos2}
+  assert names2['nerf_mlps_coarse/MLP_2/logit/kernel'] == (256 + 8, 1)
+  assert names2['nerf_mlps_coarse/MLP_1/hidden_0/kernel'] == (256 + 27 + 8, 128)
+  assert names2['appearance_encoder/embed/embedding'] == (4, 8)
+  assert lib.nrf_destroy(h2) == 0
+  d3 = _desc(use_trunk_condition=1)
+  assert lib.nrf_create(C.byref(d3), C.byref(h2)) == -3 and b'trunk' in lib.nrf_last_error()
   total = C.c_int64(0)
   assert lib.nrf_param_count(h, C.byref(total)) == 0
   # 589 956 parameters per NeRF MLP at P=51, R=29

@@ -87,20 +87,18 @@ def test_hip_matches_golden(name):
 
   def digest_close(got, want, n, tol):
     scale = max(want[4], 1e-9)
-    if tol > 1e-2:   # loose regime: magnitude digests only (a flipped branch shifts whole columns coherently)
-      return abs(got[1] - want[1]) <= tol * max(want[1], 1e-9) + tol * scale and abs(got[4] - want[4]) <= tol * scale + 1e-9
     return (abs(got[0] - want[0]) <= tol * scale * np.sqrt(n) + 1e-9 and
             abs(got[1] - want[1]) <= tol * max(want[1], 1e-9) + tol * scale and
             abs(got[2] - want[2]) <= tol * scale + 1e-9 and abs(got[3] - want[3]) <= tol * scale + 1e-9 and
             abs(got[4] - want[4]) <= tol * scale + 1e-9)
 
-  # Gradient digests.  Warp off: 1e-3 against the fp64 oracle (or the fp32 oracle).  Warp on: the
-  # F_p=8 posenc amplifies the fp32 rounding of the warped point by 2^7, so a handful of trunk
-  # pre-activations take the other ReLU branch than in fp64 -- and than in ANY other fp32
-  # evaluation order (the two oracles differ from each other by the same 1-5 %).  Those fixtures are
-  # therefore only held to 20 % magnitude digests here (5 rays); the tight (2e-3) gradient parity of the warp path is asserted in
-  # tests/test_gpu_parity.py::test_warp_loss_and_grad_parity at F_p <= 3 where no branch flips.
-  tol = 0.2 if (spec.use_warp and spec.num_nerf_point_freqs > 3) else (3e-3 if spec.use_warp else 1e-3)
+  # Gradient digests against the fp64 fixture.  Warp ON with the presets' posenc width (F_p > 3): fp32 rounding of the warped
+  # point flips a few ReLU ties, which moves whole gradient columns by percents at 5 rays -- those cases are compared
+  # leaf by leaf (2e-3) against the oracle pinned to the HIP path's own branch pattern in
+  # tests/test_gpu_pinned.py::test_golden_warp_cases_pinned instead of through a loose digest here.
+  if spec.use_warp and spec.num_nerf_point_freqs > 3:
+    return
+  tol = 3e-3 if spec.use_warp else 1e-3
   for path, g in O.tree_leaves_with_path(tree):
     got = G.leaf_digest(g.double().cpu())
     assert digest_close(got, gold['grad/' + path], g.numel(), tol) or \

@@ -1,0 +1,270 @@
+"""The rest of NerfModel.apply's contract and of train_step's loss terms on the GPU:
+use_alpha_condition, metadata_encoded, return_warp_jacobian / use_warp_jacobian, noise_std, use_warp_reg_loss, every
+elastic_loss_type, the Jacobian metrics.  Forward results against the fp64 oracle AND against vectors produced by the
+reference's own NerfModel.apply (tests/golden/ref_nerf_alpha_cond.npz, ref_nerf_encoded.npz); gradients leaf by leaf
+against the oracle pinned to the HIP path's branch pattern (tests/test_gpu_pinned.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from oracle import nerfies_oracle as O  # noqa: E402
+import helpers as H  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _ref(name):
+  return dict(np.load(os.path.join(HERE, 'golden', f'ref_{name}.npz')))
+
+
+def _np(t):
+  return t.detach().cpu().numpy()
+
+
+# ---------------------------------------------------------------------------------------------
+# use_alpha_condition (models.py:204-208, modules.py:152-157)
+# ---------------------------------------------------------------------------------------------
+ALPHA_KW = dict(use_appearance_metadata=True, use_alpha_condition=True, num_coarse_samples=32, num_fine_samples=32)
+
+
+@pytest.mark.parametrize('kw,B', [(dict(use_camera_metadata=True), 11), (dict(use_stratified_sampling=True, num_appearance_features=5), 70),
+                                  (dict(nerf_trunk_width=128, nerf_rgb_branch_width=64), 9),
+                                  (dict(use_warp=True, num_nerf_point_freqs=6, use_camera_metadata=True), 9)])
+def test_alpha_condition_forward_and_gradients(kw, B):
+  spec = O.ModelSpec(**dict(ALPHA_KW, **kw))
+  r = H.run_pinned(spec, B, 4.0, seed=31)
+  H.assert_pinned(r, f'alpha condition {kw}')
+  H.assert_forward(r, spec)
+  e = r['errs']
+  # the appearance table and the code rows of both heads carry gradient
+  assert e['appearance_encoder/embed/embedding'][1] > 0
+  assert e['nerf_mlps_fine/MLP_2/logit/kernel'][1] > 0 and e['nerf_mlps_coarse/MLP_1/hidden_0/kernel'][1] > 0
+  from nerfies_amd import params as P
+  tree = P.tree_from_flat(r['fp'].flat.cpu(), r['model'].layout)
+  assert tuple(tree['nerf_mlps_fine']['MLP_2']['logit']['kernel'].shape) == (spec.nerf_trunk_width + spec.num_appearance_features, 1)
+
+
+def test_alpha_condition_matches_the_reference_run():
+  """GPU forward against the output of the reference's own NerfModel.apply (through the NumPy shim)."""
+  r = _ref('nerf_alpha_cond')
+  spec = O.ModelSpec(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True,
+                     use_appearance_metadata=True, use_alpha_condition=True, use_camera_metadata=True)
+  seed = int(r['seed'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(3, seed=seed + 1)
+  model, fp = H.gpu_model(spec, params, 3)
+  out = model.apply({'params': fp}, H.gpu_batch(batch), {'alpha': 0.0},
+                    rngs={'coarse': torch.tensor(r['t_rand']).float().to(DEV), 'fine': torch.tensor(r['u']).float().to(DEV)},
+                    return_weights=True)
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'weights'):
+      np.testing.assert_allclose(_np(out[lv][k]), r[f'{lv}/{k}'], atol=1e-4, err_msg=f'{lv}/{k}')
+
+
+def test_appearance_code_is_dead_without_alpha_condition():
+  """models.py:204-208: with use_alpha_condition=False the appearance code reaches nothing (the rgb branch only gets it
+  under the same flag) -- kept as in the reference."""
+  spec = O.ModelSpec(use_appearance_metadata=True, use_alpha_condition=False, num_coarse_samples=16, num_fine_samples=16)
+  p = O.init_params(spec, seed=2, trained_like=True)
+  b = O.synthetic_batch(5, seed=3)
+  model, fp = H.gpu_model(spec, p, 5)
+  gb = H.gpu_batch(b)
+  a = model.apply({'params': fp}, gb, {})['fine']['rgb'].clone()
+  gb['metadata']['appearance'] = (gb['metadata']['appearance'] + 1) % 4
+  np.testing.assert_array_equal(_np(model.apply({'params': fp}, gb, {})['fine']['rgb']), _np(a))
+
+
+# ---------------------------------------------------------------------------------------------
+# metadata_encoded=True (models.py:198-199, 210-211, 251; warping.py:378-381)
+# ---------------------------------------------------------------------------------------------
+def test_metadata_encoded_matches_ids_oracle_and_reference():
+  r = _ref('nerf_encoded')
+  spec = O.ModelSpec(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                     num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True, use_appearance_metadata=True,
+                     use_alpha_condition=True)
+  seed = int(r['seed'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(3, seed=seed + 1)
+  model, fp = H.gpu_model(spec, params, 3)
+  gb = H.gpu_batch(batch)
+  by_ids = model.apply({'params': fp}, gb, {'alpha': 3.25}, return_points=True, return_weights=True)
+  enc = dict(gb)
+  enc['metadata'] = {k: torch.tensor(r['codes/' + k]).float().to(DEV) for k in ('warp', 'appearance', 'camera')}
+  by_codes = model.apply({'params': fp}, enc, {'alpha': 3.25}, metadata_encoded=True, return_points=True, return_weights=True,
+                         return_warp_jacobian=True)
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc', 'weights', 'warped_points'):
+      np.testing.assert_allclose(_np(by_codes[lv][k]), _np(by_ids[lv][k]), atol=1e-6, err_msg=f'{lv}/{k}')     # same kernels, same codes
+      np.testing.assert_allclose(_np(by_codes[lv][k]), r[f'{lv}/{k}'], atol=1e-4, err_msg=f'ref {lv}/{k}')     # the reference's own run
+    np.testing.assert_allclose(_np(by_codes[lv]['warp_jacobian']), r[f'{lv}/warp_jacobian'], atol=2e-4)
+  # interpolated codes (the video notebook's use of this switch): between two frames' renders, not equal to either
+  mid = dict(enc)
+  mid['metadata'] = {k: 0.5 * (v + v.roll(1, 0)) for k, v in enc['metadata'].items()}
+  o = model.apply({'params': fp}, mid, {'alpha': 3.25}, metadata_encoded=True)
+  ref_mid = O.nerf_model_apply(params, spec, {**batch, 'metadata': {k: v.double().cpu() for k, v in mid['metadata'].items()}}, 3.25,
+                               metadata_encoded=True)
+  np.testing.assert_allclose(_np(o['fine']['rgb']), _np(ref_mid['fine']['rgb']), atol=1e-4)
+  from nerfies_amd.lib import NrfError
+  with pytest.raises(NrfError):
+    model.apply({'params': fp}, enc, {'alpha': 3.25}, metadata_encoded=True, train=True)
+  with pytest.raises(NrfError):   # wrong code width
+    bad = dict(enc); bad['metadata'] = dict(enc['metadata'], warp=enc['metadata']['warp'][:, :5])
+    model.apply({'params': fp}, bad, {'alpha': 3.25}, metadata_encoded=True)
+
+
+class _NearestKink:
+  """oracle.relu_hook recorder: per sample, the smallest |pre-activation| / layer rms over every hidden unit."""
+
+  def __init__(self):
+    self.min = None
+
+  def __call__(self, name, layer, pre):
+    with torch.no_grad():
+      d = pre.detach()
+      r = (d.abs() / d.pow(2).mean().sqrt().clamp_min(1e-30)).reshape(-1, d.shape[-1]).min(-1).values
+      self.min = r if self.min is None else torch.minimum(self.min, r)
+    return torch.relu(pre)
+
+
+# ---------------------------------------------------------------------------------------------
+# return_warp_jacobian / use_warp_jacobian (models.py:264-265, 345-346, 367-368; warping.py:385-387)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw,alpha,B', [(dict(), 3.5, 7), (dict(num_warp_freqs=6, num_warp_features=3), 6.0, 40),
+                                        (dict(warp_field_type='translation'), 2.0, 7),
+                                        (dict(num_coarse_samples=128, num_fine_samples=128), 8.0, 96)])
+def test_warp_jacobian_output(kw, alpha, B):
+  spec = O.ModelSpec(**dict(dict(num_coarse_samples=32, num_fine_samples=32, use_warp=True), **kw))
+  p = O.init_params(spec, seed=4, trained_like=True)
+  b = O.synthetic_batch(B, seed=5)
+  model, fp = H.gpu_model(spec, p, B)
+  out = model.apply({'params': fp}, H.gpu_batch(b), {'alpha': alpha}, return_warp_jacobian=True, return_points=True)
+  ref = O.nerf_model_apply(p, spec, b, alpha, return_warp_jacobian=True, return_points=True)
+  for lv in ('coarse', 'fine'):
+    J = out[lv]['warp_jacobian']
+    assert tuple(J.shape) == (B, ref[lv]['z_vals'].shape[1], 3, 3)
+    # the fine samples of the two sides differ by ~1e-6 in depth: compare J where the points agree, through the oracle
+    # evaluated AT the GPU's points
+    pts = out[lv]['points'].double().cpu()
+    ids = b['metadata']['warp'][:, None, :].expand(B, pts.shape[1], 1)
+    kink = _NearestKink()
+    with O.relu_hook(kink):
+      jo = O.se3_field(p['warp_field'], pts, ids, alpha, spec.num_warp_freqs, return_jacobian=True, name='jac/warp')['jacobian']
+    # J is piecewise constant in the ReLU branch pattern: a sample with a trunk unit within float32 rounding of its kink
+    # (amplified by 2^(F_w-1) in the posenc angle) may sit on the other branch than float64 and differs by O(1) there.
+    # Asserted: every deviating sample has such a tie (|pre| < 1e-3 of its layer's rms), and they are few.
+    bad = ((J.double().cpu() - jo).abs() > 5e-5 + 2e-5 * jo.abs()).reshape(-1, 9).any(-1)
+    assert bad.float().mean().item() < 0.06, (lv, bad.float().mean().item())
+    assert (kink.min[bad] < 1e-3).all(), (lv, kink.min[bad].max().item())
+    assert (~bad).float().mean().item() > 0.9
+    assert (J - torch.eye(3, device=DEV)).abs().max().item() > 1e-3      # a real deformation, not the identity
+  # use_warp_jacobian on the model (construct_nerf(..., use_warp_jacobian=True)): coarse level only (models.py:345)
+  model.use_warp_jacobian = True
+  o2 = model.apply({'params': fp}, H.gpu_batch(b), {'alpha': alpha})
+  assert 'warp_jacobian' in o2['coarse'] and 'warp_jacobian' not in o2['fine']
+  np.testing.assert_allclose(_np(o2['coarse']['warp_jacobian']), _np(out['coarse']['warp_jacobian']), atol=1e-6)
+  model.use_warp_jacobian = False
+  o3 = model.apply({'params': fp}, H.gpu_batch(b), {'alpha': alpha})
+  assert 'warp_jacobian' not in o3['coarse']
+  np.testing.assert_allclose(_np(o3['fine']['rgb']), _np(out['fine']['rgb']), atol=1e-6)   # the extra pass changes nothing else
+
+
+# ---------------------------------------------------------------------------------------------
+# noise_std (model_utils.noise_regularize, model_utils.py:266-282)
+# ---------------------------------------------------------------------------------------------
+def test_noise_regularize_parity_and_philox():
+  spec = O.ModelSpec(num_coarse_samples=32, num_fine_samples=32, use_stratified_sampling=True, noise_std=0.5)
+  r = H.run_pinned(spec, 21, 0.0, seed=8)
+  H.assert_pinned(r, 'noise_std=0.5 explicit normals')
+  H.assert_forward(r, spec)
+  model, fp, gb = r['model'], r['fp'], r['gb']
+  # on-device Philox normals: reproducible per key, different across keys, and of the right scale (the rendered colour
+  # moves by as much as with the explicit normals)
+  base = {'coarse': r['rngs']['coarse'], 'fine': r['rngs']['fine']}
+  a1 = model.apply({'params': fp}, gb, {}, rngs=base)['fine']['rgb'].clone()
+  a2 = model.apply({'params': fp}, gb, {}, rngs=base)['fine']['rgb'].clone()
+  np.testing.assert_array_equal(_np(a1), _np(a2))
+  spec0 = O.ModelSpec(num_coarse_samples=32, num_fine_samples=32, use_stratified_sampling=True)
+  m0, fp0 = H.gpu_model(spec0, O.init_params(spec, seed=8, trained_like=True), 21)
+  clean = m0.apply({'params': fp0}, gb, {}, rngs=base)['fine']['rgb']
+  d_philox = (a1 - clean).abs().mean().item()
+  explicit = model.apply({'params': fp}, gb, {}, rngs=r['rngs'])['fine']['rgb']
+  d_explicit = (explicit - clean).abs().mean().item()
+  assert d_philox > 0 and 0.3 < d_philox / d_explicit < 3.0, (d_philox, d_explicit)
+  # deterministic sampling switches the noise off (model_utils.py:278: only if use_stratified_sampling)
+  spec_d = O.ModelSpec(num_coarse_samples=32, num_fine_samples=32, use_stratified_sampling=False, noise_std=0.5)
+  md, fpd = H.gpu_model(spec_d, O.init_params(spec, seed=8, trained_like=True), 21)
+  spec_c = O.ModelSpec(num_coarse_samples=32, num_fine_samples=32, use_stratified_sampling=False)
+  mc, fpc = H.gpu_model(spec_c, O.init_params(spec, seed=8, trained_like=True), 21)
+  np.testing.assert_array_equal(_np(md.apply({'params': fpd}, gb, {})['fine']['rgb']), _np(mc.apply({'params': fpc}, gb, {})['fine']['rgb']))
+
+
+# ---------------------------------------------------------------------------------------------
+# train_step's other loss terms (training.py:71-114, 199-222)
+# ---------------------------------------------------------------------------------------------
+WARP_KW = dict(num_coarse_samples=32, num_fine_samples=32, num_nerf_point_freqs=6, use_warp=True, use_stratified_sampling=True)
+
+
+@pytest.mark.parametrize('ltype,method', [('svals', 'weight'), ('jtj', 'median'), ('div', 'weight'), ('det', 'weight'),
+                                          ('log_det', 'median'), ('log_svals', 'median')])
+def test_elastic_loss_types(ltype, method):
+  spec = O.ModelSpec(**WARP_KW)
+  r = H.run_pinned(spec, 12, 5.0, seed=13, elastic={'weight': 0.05, 'reduce_method': method, 'loss_type': ltype})
+  H.assert_pinned(r, f'elastic {ltype}/{method}', loss_tol=2e-5)
+  o, st = r['ostats']['coarse'], r['stats']
+  assert o['loss/elastic'].item() > 0
+  for i, k in ((6, 'loss/elastic'), (7, 'residual/elastic'), (12, 'metric/jacobian_det'), (13, 'metric/jacobian_div'), (14, 'metric/jacobian_curl')):
+    assert abs(st[i].item() - o[k].item()) < 1e-6 + 3e-4 * abs(o[k].item()), (k, st[i].item(), o[k].item())
+
+
+def test_unknown_elastic_type_is_rejected():
+  from nerfies_amd.lib import NrfError
+  spec = O.ModelSpec(**WARP_KW)
+  model, fp = H.gpu_model(spec, O.init_params(spec, seed=1, trained_like=True), 4)
+  gb = H.gpu_batch(O.synthetic_batch(4, seed=2))
+  with pytest.raises(NrfError, match='nr'):
+    model.loss_and_grad(fp, gb, warp_extra={'alpha': 1.0}, rngs={'coarse': 1, 'fine': 2}, elastic={'weight': 0.1, 'loss_type': 'nr'})
+
+
+@pytest.mark.parametrize('kw,wr', [(dict(), dict(weight=0.5)), (dict(use_camera_metadata=True, num_warp_freqs=6), dict(weight=2.0, alpha=-2.0, scale=0.01)),
+                                   (dict(warp_field_type='translation'), dict(weight=1.0))])
+def test_warp_reg_loss(kw, wr):
+  spec = O.ModelSpec(**dict(WARP_KW, **kw))
+  r = H.run_pinned(spec, 14, 6.0, seed=17, warp_reg=wr)
+  H.assert_pinned(r, f'warp_reg {kw}', loss_tol=3e-5)
+  st = r['stats']
+  for lv, i in (('coarse', 0), ('fine', 1)):
+    o = r['ostats'][lv]
+    assert o['loss/warp_reg'].item() > 0
+    assert abs(st[8 + i].item() - o['loss/warp_reg'].item()) < 1e-7 + 3e-4 * o['loss/warp_reg'].item(), lv
+    assert abs(st[10 + i].item() - o['residual/warp_reg'].item()) < 1e-7 + 3e-4 * o['residual/warp_reg'].item(), lv
+
+
+def test_train_step_reports_every_reference_stat():
+  """training.train_step with everything on: the stats dict carries the reference's keys (training.py:172-225, 259)."""
+  from nerfies_amd import training
+  spec = O.ModelSpec(**WARP_KW)
+  model, fp = H.gpu_model(spec, O.init_params(spec, seed=3, trained_like=True), 16)
+  gb = dict(H.gpu_batch(O.synthetic_batch(16, seed=4)))
+  gb['background_points'] = (torch.rand(200, 3, device=DEV) - 0.5) * 0.8
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=4.0)
+  sp = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, warp_reg_loss_weight=0.1, background_loss_weight=1.0)
+  state, stats, key = training.train_step(model, 5, state, gb, sp, use_elastic_loss=True, elastic_reduce_method='weight',
+                                          elastic_loss_type='svals', use_background_loss=True, use_warp_reg_loss=True)
+  assert set(stats['coarse']) == {'loss/rgb', 'loss/total', 'metric/psnr', 'loss/elastic', 'residual/elastic', 'loss/warp_reg',
+                                  'residual/warp_reg', 'metric/jacobian_det', 'metric/jacobian_div', 'metric/jacobian_curl'}
+  assert set(stats['fine']) == {'loss/rgb', 'loss/total', 'metric/psnr', 'loss/warp_reg', 'residual/warp_reg'}
+  assert 'background_loss' in stats and all(torch.isfinite(v).all() for lv in ('coarse', 'fine') for v in stats[lv].values())
+  total = stats['coarse']['loss/total'] + stats['fine']['loss/total'] + sp.background_loss_weight * stats['background_loss']
+  assert abs(total.item() - state.optimizer.stats[4].item()) < 1e-5
+  # stats are fresh tensors, not views of the donated gradient buffer (the next step must not change them)
+  keep = stats['fine']['loss/rgb'].item()
+  held = stats['fine']['loss/rgb']
+  training.train_step(model, key, state, gb, sp, use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
+  assert held.item() == keep

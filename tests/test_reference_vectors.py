@@ -262,3 +262,108 @@ def test_schedules_match_reference():
     S.from_config(3.0)
   with pytest.raises(KeyError):
     S.from_tuple(('nope', 1))
+
+
+# ---- round 2: the rest of NerfModel.apply's contract and train_step's own loss assembly ----
+NERF_CASES_R2 = {
+    'alpha_cond': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True,
+                        use_appearance_metadata=True, use_alpha_condition=True, use_camera_metadata=True), 0.0),
+    'encoded': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                     num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True, use_appearance_metadata=True,
+                     use_alpha_condition=True), 3.25),
+    'time': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                  num_warp_freqs=5, num_warp_features=8, warp_metadata_encoder_type='time'), 3.25),
+}
+
+
+@pytest.mark.parametrize('name', sorted(NERF_CASES_R2))
+def test_nerf_model_apply_alpha_condition_and_encoded_metadata(name):
+  """NerfModel.apply with use_alpha_condition (modules.py:152-157 and the models.py:206 quirk) and with
+  metadata_encoded=True (models.py:198-199, 210-211, 251; warping.py:378-381), as run by the reference itself."""
+  kw, alpha = NERF_CASES_R2[name]
+  r = ref('nerf_' + name)
+  spec = O.ModelSpec(**kw)
+  seed = int(r['seed'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(3, seed=seed + 1)
+  encoded = name == 'encoded'
+  if encoded:
+    ids = {k: v[:, 0] for k, v in batch['metadata'].items()}
+    batch['metadata'] = {k: T(r['codes/' + k]) for k in ('warp', 'appearance', 'camera')}
+    close(params['appearance_encoder']['embed']['embedding'][ids['appearance']], r['codes/appearance'], 1e-15)
+  ret = O.nerf_model_apply(params, spec, batch, alpha, metadata_encoded=encoded, return_points=spec.use_warp,
+                           return_warp_jacobian=spec.use_warp, t_rand=T(r['t_rand']), u=T(r['u']), time_alpha=float(r['time_alpha']))
+  if name == 'time':   # modules.TimeEncoder (modules.py:297-322) through SE3Field.encode_metadata (warping.py:311-313)
+    assert set(params['warp_field']['metadata_encoder']) == {'mlp'}
+    other = O.nerf_model_apply(params, spec, batch, alpha, t_rand=T(r['t_rand']), u=T(r['u']), time_alpha=2.0)
+    assert (other['fine']['rgb'] - ret['fine']['rgb']).abs().max() > 1e-6    # the annealing window of the time posenc matters
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights'):
+      close(ret[lv][k], r[f'{lv}/{k}'], 1e-8, msg=f'{name} {lv}/{k}')
+    if spec.use_warp:
+      close(ret[lv]['warped_points'], r[f'{lv}/warped_points'], 1e-9)
+      close(ret[lv]['warp_jacobian'], r[f'{lv}/warp_jacobian'], 2e-6)
+  if encoded:   # ... and the encoded evaluation equals the id-driven one
+    batch2 = O.synthetic_batch(3, seed=seed + 1)
+    ret2 = O.nerf_model_apply(params, spec, batch2, alpha, t_rand=T(r['t_rand']), u=T(r['u']))
+    close(ret2['fine']['rgb'], r['fine/rgb'], 1e-8)
+  # the appearance code must matter: without the alpha condition it is dead (models.py:204-208)
+  if name == 'time':
+    return
+  p2 = O.tree_map(lambda t: t.clone(), params)
+  p2['appearance_encoder']['embed']['embedding'] += 0.3
+  if not encoded:
+    ret3 = O.nerf_model_apply(p2, spec, batch, alpha, t_rand=T(r['t_rand']), u=T(r['u']))
+    assert (ret3['fine']['rgb'] - ret['fine']['rgb']).abs().max() > 1e-4
+
+
+TRAIN_CASES = {'log_svals_weight': ('log_svals', 'weight', True), 'svals_median': ('svals', 'median', False),
+               'jtj_weight': ('jtj', 'weight', False), 'div_weight': ('div', 'weight', True),
+               'det_median': ('det', 'median', False), 'log_det_weight': ('log_det', 'weight', False)}
+
+
+@pytest.mark.parametrize('name', sorted(TRAIN_CASES))
+def test_train_step_loss_assembly_matches_reference(name):
+  """The forward half of the reference's own training.train_step (training.py:168-262) -- run under the shim with
+  jax.value_and_grad replaced by a plain evaluation -- against oracle.loss_fn: rgb losses, psnr, every elastic_loss_type
+  under both reduce methods, warp_reg, background, Jacobian metrics, per-level totals."""
+  ltype, method, wreg = TRAIN_CASES[name]
+  r = ref('train_step_stats')
+  spec = O.ModelSpec(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                     num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True)
+  params = O.init_params(spec, seed=41, trained_like=True)
+  batch = O.synthetic_batch(3, seed=42)
+  bg = {'points': T(r['bg_points']), 'warp_ids': torch.tensor(r['bg_ids']), 'noise': T(r['bg_noise']) * 0.001}
+  total, stats, _ = O.loss_fn(params, spec, batch, float(r['alpha']), t_rand=T(r['t_rand']), u=T(r['u']), use_elastic_loss=True,
+                              elastic_loss_weight=float(r['elastic_loss_weight']), elastic_reduce_method=method,
+                              elastic_loss_type=ltype, use_background_loss=True,
+                              background_loss_weight=float(r['background_loss_weight']), background=bg, use_warp_reg_loss=wreg,
+                              warp_reg_loss_weight=float(r['warp_reg_loss_weight']))
+  seen = 0
+  for lv in ('coarse', 'fine'):
+    keys = [k[len(f'{name}/{lv}/'):] for k in r if k.startswith(f'{name}/{lv}/')]
+    assert set(keys) == set(stats[lv]), (sorted(keys), sorted(stats[lv]))
+    for k in keys:
+      # the reference Jacobians are central differences of its warp (~1e-7); everything derived from them inherits that
+      tol = 1e-9 if k in ('loss/rgb', 'metric/psnr') or (lv == 'fine' and 'warp_reg' not in k and k != 'loss/total') else 5e-6
+      close(stats[lv][k], r[f'{name}/{lv}/{k}'], tol, msg=f'{name} {lv} {k}')
+      seen += 1
+  close(stats['background_loss'], r[f'{name}/background_loss'], 1e-10)
+  assert seen >= 11 and ('loss/warp_reg' in stats['fine']) == wreg
+  want_total = sum(float(r[f'{name}/{lv}/loss/total']) for lv in ('coarse', 'fine')) + float(r['background_loss_weight']) * float(r[f'{name}/background_loss'])
+  assert abs(total.item() - want_total) < 1e-6
+
+
+def test_elastic_loss_types_and_noise_regularize():
+  r = ref('elastic_types_noise')
+  J = T(r['J'])
+  close(O.jacobian_to_div(J), r['div'], 1e-12); close(O.jacobian_to_curl(J), r['curl'], 1e-12)
+  for t in ('log_svals', 'svals', 'jtj', 'div', 'det', 'log_det'):
+    el, res = O.compute_elastic_loss(J, loss_type=t)
+    close(el, r[f'{t}/loss'], 1e-10, msg=t); close(res, r[f'{t}/residual'], 1e-10, msg=t)
+  with pytest.raises(NotImplementedError):
+    O.compute_elastic_loss(J, loss_type='nr')
+  raw, nz = T(r['raw']), T(r['normals'])
+  close(torch.cat([raw[..., :3], O.noise_regularize(raw[..., 3:4], 0.4, True, nz)], -1), r['noised_strat'], 1e-15)
+  close(torch.cat([raw[..., :3], O.noise_regularize(raw[..., 3:4], 0.4, False, nz)], -1), r['noised_det'], 0)
+  close(torch.cat([raw[..., :3], O.noise_regularize(raw[..., 3:4], None, True, nz)], -1), r['noised_none'], 0)

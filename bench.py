@@ -31,15 +31,102 @@ PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, d
 TRAFFIC_KERNEL = {'wgrad': 'nrf::wgrad_kernel'}
 
 
+def kernel_source_sha():
+  """sha256[:16] over the HIP sources: profiles/hbm_traffic.json carries the value it was measured at."""
+  import hashlib
+  h = hashlib.sha256()
+  csrc = os.path.join(ROOT, 'nerfies_amd', 'csrc')
+  for f in sorted(os.listdir(csrc)):
+    h.update(open(os.path.join(csrc, f), 'rb').read())
+  return h.hexdigest()[:16]
+
+
 def hbm_traffic(profile_name):
-  """HBM bytes per launch of the dominant kernel from the committed PMC pass (profiles/hbm_traffic.json:
-  FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), or None when that kernel has no unambiguous entry."""
+  """(HBM bytes per launch of the dominant kernel, provenance) from the committed PMC pass (profiles/hbm_traffic.json,
+  written by scripts/make_hbm_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  The file records the
+  hash of the kernel sources it was measured at; when the sources have changed since, the figure is stale and
+  (None, reason) is returned instead."""
   path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
   sym = TRAFFIC_KERNEL.get(profile_name)
   if sym is None or not os.path.exists(path):
-    return None
-  k = json.load(open(path)).get('kernels', {}).get(sym)
-  return None if k is None else k['fetch_bytes'] + k['write_bytes']
+    return None, 'no PMC pass committed for this kernel'
+  rec = json.load(open(path))
+  k = rec.get('kernels', {}).get(sym)
+  if k is None:
+    return None, 'kernel not in profiles/hbm_traffic.json'
+  if rec.get('csrc_sha16') != kernel_source_sha():
+    return None, f"stale: measured at csrc {rec.get('csrc_sha16')}, sources are now {kernel_source_sha()}"
+  return k['fetch_bytes'] + k['write_bytes'], rec.get('source', 'profiles/hbm_traffic.json')
+
+
+class ClockSampler:
+  """Shader clock / board power of the bench GPU, sampled from sysfs (amdgpu hwmon: freq1_input Hz, power1_average or
+  power1_input uW) on a background thread, so a sub-second timed window can be shown to sit in a steady state."""
+
+  def __init__(self, index=0, period=0.05):
+    import glob
+    self.files = {}
+    cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/hwmon/hwmon*'))
+    self.card = None
+    try:   # the card whose PCI address is the bench device's (a box exposes many cards, one of them visible to HIP)
+      pr = torch.cuda.get_device_properties(index)
+      want = f'{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}'
+      match = [c for c in cards if want in os.path.realpath(os.path.join(c, '..', '..'))]
+      cards = match or cards
+      self.card = want if match else None
+    except (AttributeError, RuntimeError):
+      pass
+    if cards:
+      hw = cards[0] if self.card else cards[min(index, len(cards) - 1)]
+      for key, names in (('sclk_mhz', ['freq1_input']), ('power_w', ['power1_average', 'power1_input'])):
+        for n in names:
+          if os.path.exists(os.path.join(hw, n)):
+            self.files[key] = os.path.join(hw, n)
+            break
+    self.period, self.samples, self._stop, self._thread = period, {k: [] for k in self.files}, False, None
+
+  def _read(self):
+    for k, f in self.files.items():
+      try:
+        v = float(open(f).read().strip())
+        self.samples[k].append(v / 1e6)
+      except (OSError, ValueError):
+        pass
+
+  def start(self):
+    import threading
+    self.samples = {k: [] for k in self.files}
+    self._stop = False
+
+    def loop():
+      while not self._stop:
+        self._read()
+        time.sleep(self.period)
+    self._thread = threading.Thread(target=loop, daemon=True)
+    self._thread.start()
+
+  def stop(self):
+    self._stop = True
+    if self._thread is not None:
+      self._thread.join()
+    out = {}
+    for k, v in self.samples.items():
+      if v:
+        out[k] = {'min': min(v), 'mean': sum(v) / len(v), 'max': max(v), 'n': len(v)}
+    if out:
+      out['pci'] = self.card or 'unmatched (first hwmon card)'
+    return out or None
+
+
+def burn_in(step, seconds):
+  """Untimed steps of the same workload for >= `seconds` (clocks / power settle), synchronising every 16 steps."""
+  t0, n = time.perf_counter(), 0
+  while time.perf_counter() - t0 < seconds:
+    for _ in range(16):
+      step()
+    torch.cuda.synchronize()
+    n += 16
+  return n
 
 
 class Cfg:
@@ -61,57 +148,61 @@ def synthetic_batch(n, seed, device):
   return {'origins': o.to(device), 'directions': d.to(device), 'rgb': rgb.to(device), 'metadata': {}}
 
 
-def cpu_baseline(seconds_budget=18.0):
+def cpu_baseline(seconds_budget=20.0):
   """The oracle's torch-CPU fp32 restatement of the same train step ("reference restated on CPU":
-  JAX is not installable here), on a bounded sample: 128 rays of the same 64+128 workload.
-  torch's intra-op pool does not scale to every core of a 128+-core host for 256-wide layers, so a
-  few thread counts are probed first and the fastest is used and reported as `cores`."""
+  JAX is not installable here) on the SAME batch shape as the GPU line: 1024 rays x (64+128), fwd+bwd+Adam, a
+  bounded number of steps.  torch's intra-op pool does not scale to every core of a 128+-core host for 256-wide
+  layers, so a few thread counts are probed first (on 128 rays, to keep the probe short) and the fastest is used and
+  reported as `cores`."""
   from oracle import nerfies_oracle as O
-  n = 128
   spec = O.ModelSpec(num_coarse_samples=N_COARSE, num_fine_samples=N_FINE, num_nerf_point_freqs=POINT_FREQS,
                      use_stratified_sampling=True)
   params = O.init_params(spec, seed=0, dtype=torch.float32)
-  batch = O.synthetic_batch(n, seed=0, dtype=torch.float32)
-  g = torch.Generator().manual_seed(0)
-  t_rand = torch.rand(n, N_COARSE, generator=g)
-  u = torch.rand(n, N_FINE, generator=g)
   leaves = [t for _, t in O.tree_leaves_with_path(params)]
   m = [torch.zeros_like(t) for t in leaves]
   v = [torch.zeros_like(t) for t in leaves]
   counter = [0]
 
-  def step():
-    _, _, grads, _ = O.loss_and_grad(params, spec, batch, t_rand=t_rand, u=u)
-    for j, (_, gt) in enumerate(O.tree_leaves_with_path(grads)):
-      p, m[j], v[j] = O.adam_update(leaves[j], m[j], v[j], gt, counter[0], 1e-3)
-      leaves[j].copy_(p)
-    counter[0] += 1
+  def make(n):
+    batch = O.synthetic_batch(n, seed=0, dtype=torch.float32)
+    g = torch.Generator().manual_seed(0)
+    t_rand = torch.rand(n, N_COARSE, generator=g)
+    u = torch.rand(n, N_FINE, generator=g)
 
-  def timed():
-    t0 = time.perf_counter()
-    step()
-    return time.perf_counter() - t0
+    def timed():
+      t0 = time.perf_counter()
+      _, _, grads, _ = O.loss_and_grad(params, spec, batch, t_rand=t_rand, u=u)
+      for j, (_, gt) in enumerate(O.tree_leaves_with_path(grads)):
+        p, m[j], v[j] = O.adam_update(leaves[j], m[j], v[j], gt, counter[0], 1e-3)
+        leaves[j].copy_(p)
+      counter[0] += 1
+      return time.perf_counter() - t0
+    return timed
 
   ncpu = os.cpu_count() or 1
+  probe = make(128)
   best_t, best_threads = None, 1
   for th in sorted({c for c in (4, 8, 16, 32, 64, ncpu) if c <= ncpu}):
     torch.set_num_threads(th)
-    timed()                       # warm-up at this thread count
-    t = min(timed(), timed())
+    probe()                       # warm-up at this thread count
+    t = min(probe(), probe())
     if best_t is None or t < best_t:
       best_t, best_threads = t, th
     if t > 4 * best_t:            # clearly past the scaling knee
       break
   torch.set_num_threads(best_threads)
+  n = RAYS_PER_GPU
+  timed = make(n)
+  timed()                         # warm-up at the full size
   times = []
   t_start = time.perf_counter()
-  while len(times) < 3 or (time.perf_counter() - t_start < seconds_budget and len(times) < 40):
+  while len(times) < 3 or (time.perf_counter() - t_start < seconds_budget and len(times) < 20):
     times.append(timed())
   times.sort()
   med = times[len(times) // 2]
   return {'value': n / med, 'unit': 'rays/s', 'cores': best_threads, 'kind': 'port',
-          'sample': f'{n} rays x ({N_COARSE}+{N_FINE}) samples, fwd+bwd+Adam, fp32 torch-CPU oracle, '
-                    f'median of {len(times)} steps, {best_threads} threads (best of a probe up to {ncpu})'}
+          'sample': f'{n} rays x ({N_COARSE}+{N_FINE}) samples (the full GPU batch shape), fwd+bwd+Adam, fp32 torch-CPU '
+                    f'oracle, median of {len(times)} steps, {best_threads} threads (best of a probe up to {ncpu} on 128 rays)'}
 
 
 def side_mode(args, world, rank, dev):
@@ -157,6 +248,8 @@ def side_mode(args, world, rank, dev):
     per_step, name = n, 'train rays/sec (256 samples/ray, SE3 warp + elastic + background regularisers)'
     workload = ('gpu_vrig_paper.gin shape: 768 rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, elastic loss '
                 "(reduce 'weight', w=0.001) on the coarse samples, background points 16384/world (w=1), stratified")
+  if args.burn_in_s > 0:
+    burn_in(step, args.burn_in_s)
   for _ in range(args.warmup):
     step()
   barrier()
@@ -205,6 +298,8 @@ def main():
   ap.add_argument('--steps', type=int, default=30)
   ap.add_argument('--warmup', type=int, default=5)
   ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--burn-in-s', type=float, default=3.0,
+                  help='seconds of untimed steps of the same workload before the warm-up + timed steps (steady-state clocks)')
   ap.add_argument('--mode', default='train', choices=['train', 'eval', 'vrig'],
                   help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
                        '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
@@ -245,19 +340,46 @@ def main():
       dist.barrier()
     torch.cuda.synchronize()
 
+  box = {'state': state, 'key': key, 'stats': None}
+
+  def step():
+    box['state'], box['stats'], box['key'] = training.train_step(model, box['key'], box['state'], batch, sp)
+
+  # untimed burn-in at the same workload (>= --burn-in-s seconds) so the short timed window below sits at steady-state
+  # clocks and power; the sampler keeps running through the timed region
+  sampler = ClockSampler(local_rank if world > 1 else 0)
+  burn_steps = burn_in(step, args.burn_in_s) if args.burn_in_s > 0 else 0
   for _ in range(args.warmup):
-    state, stats, key = training.train_step(model, key, state, batch, sp)
+    step()
   barrier()
+  sampler.start()
   t0 = time.perf_counter()
   for _ in range(args.steps):
-    state, stats, key = training.train_step(model, key, state, batch, sp)
+    step()
   barrier()
   elapsed = time.perf_counter() - t0
+  clocks = sampler.stop()
   if world > 1:
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+  state, stats, key = box['state'], box['stats'], box['key']
   loss = stats['fine']['loss/rgb'].item()
+
+  # ---- the gradient all-reduce on its own (outside the timed region): the fused [grad | stats] buffer, 20 calls ----
+  allreduce_us = None
+  if world > 1:
+    buf = torch.zeros_like(state.optimizer._gs)
+    for _ in range(5):
+      dist.all_reduce(buf)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    e0.record()
+    for _ in range(20):
+      dist.all_reduce(buf)
+    e1.record()
+    torch.cuda.synchronize()
+    allreduce_us = e0.elapsed_time(e1) * 1e3 / 20
 
   # ---- per-kernel timing of the SAME step with HIP events on the launch stream ----
   model.profile_enable(True)
@@ -279,6 +401,7 @@ def main():
     dom = max(mf, key=lambda e: e['ms'])
     dom_ms = dom['ms'] / dom['launches']
     achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
+    traffic, traffic_src = hbm_traffic(dom['name'])
     out = {
         'metric': 'train rays/sec (192 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
@@ -287,11 +410,16 @@ def main():
                                'stratified, fwd+MSE+bwd+grad all-reduce+Adam', 'rays_per_gpu': RAYS_PER_GPU,
                    'global_batch': world * RAYS_PER_GPU, 'parallelism': f'ray-shard dp{world}'},
         'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': hbm_traffic(dom['name']),
-                     'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']},
+                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
+                     'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']},
         'step_tflops': step_flops / (ms_per_step * 1e-3) / 1e12,
         'step_frac_of_fp32_mfma_peak': step_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
         'kernels': kernels, 'final_loss_fine': loss,
+        'steady_state': {'burn_in_steps': burn_steps, 'burn_in_s': args.burn_in_s, 'timed_window_s': elapsed,
+                         'during_timed_window': clocks},
+        'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'dist_backend': backend if world > 1 else None,
+        'grad_allreduce_us': allreduce_us, 'grad_allreduce_bytes': 4 * state.optimizer._gs.numel(),
+        'csrc_sha16': kernel_source_sha(),
     }
     if world == 1 and not args.no_cpu_baseline:
       out['cpu_baseline'] = cpu_baseline()

@@ -38,8 +38,14 @@ def process_batch(*, batch, rng, state, tag, item_id, step, writer, render_fn, s
   if 'rgb' in batch:
     m = evaluation.image_metrics(render['rgb'], batch['rgb'])
     out = {k: float(v) for k, v in m.items()}
-    print(f'\t[{tag}] {item_id}: ' + ', '.join(f'{k}={v:.04f}' for k, v in out.items()), flush=True)
+    if _rank() == 0:
+      print(f'\t[{tag}] {item_id}: ' + ', '.join(f'{k}={v:.04f}' for k, v in out.items()), flush=True)
   return out
+
+
+def _rank():
+  import torch.distributed as dist
+  return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
 
 def process_iterator(tag, item_ids, iterator, rng, state, step, render_fn, writer, save_dir, datasource):
@@ -52,7 +58,9 @@ def process_iterator(tag, item_ids, iterator, rng, state, step, render_fn, write
       md = {}
       for name, ids in (('appearance', datasource.appearance_ids), ('warp', datasource.warp_ids), ('camera', datasource.camera_ids)):
         if ids:
-          md[name] = torch.full(batch['origins'][..., :1].shape, int(g.randint(len(ids))), dtype=torch.int32,
+          # a raw id VALUE, as random.choice(datasource.*_ids) gives (the embedding row: tables have max(ids)+1 rows,
+          # models.py:121-131) -- the same convention training.train_step's background ids follow
+          md[name] = torch.full(batch['origins'][..., :1].shape, int(ids[g.randint(len(ids))]), dtype=torch.int32,
                                 device=batch['origins'].device)
       batch['metadata'] = md
     stats = process_batch(batch=batch, rng=rng, state=state, tag=tag, item_id=item_id, step=step, writer=writer,
@@ -93,7 +101,7 @@ def main(argv=None):
   init_state = training.TrainState(optimizer=training.Optimizer(params))
   renderer = evaluation.GraphedChunkRenderer(model, bf16=flags.bf16)   # hipGraph replay per chunk
   render_fn = functools.partial(evaluation.render_image, model_fn=renderer, device_count=world, chunk=eval_config.chunk)
-  writer = utils.ScalarLog(summary_dir)
+  writer = utils.ScalarLog(summary_dir, enabled=rank == 0)   # summaries, meters and prints on process 0 only
   last_step, results = 0, {}
   while True:
     if checkpoints.latest_checkpoint(checkpoint_dir) is None:

@@ -19,39 +19,46 @@ class GraphedChunkRenderer:
 
   model_fn-compatible: `renderer(key_0, key_1, params, rays_dict, warp_extra)`; rays are copied into
   static buffers, the graph is replayed and copies of the static outputs are returned.
-  The graph is (re)captured whenever the chunk size, the parameter buffer or warp_alpha changes."""
+  One graph per (chunk size, parameter buffer, warp_alpha, metadata keys) is kept, so a frame whose last chunk is
+  shorter replays two graphs instead of re-capturing twice per frame; render_image additionally edge-pads the tail to
+  the full chunk when the renderer asks for it (`wants_fixed_chunks`), so that one graph serves the whole frame."""
+  wants_fixed_chunks = True
+  MAX_GRAPHS = 8
 
   def __init__(self, model, use_warp=True, bf16=False):
     self.model = model
     self.use_warp = use_warp
     self.bf16 = bf16   # NRF_FLAG_BF16 inference mode (bfloat16 MLP operands)
-    self._key = None
-    self._graph = None
-    self._in = None
-    self._out = None
+    self._slots = {}   # key -> (graph, static inputs, static outputs); insertion-ordered, oldest evicted
+    self.captures = 0
 
   def _capture(self, fp, rays, warp_extra):
     model = self.model
-    self._in = _tree_map(lambda x: x.clone(), rays)
-    call = lambda out=None: model.apply({'params': fp}, self._in, warp_extra, use_warp=self.use_warp, out=out, bf16=self.bf16)
+    ins = _tree_map(lambda x: x.clone(), rays)
+    call = lambda out=None: model.apply({'params': fp}, ins, warp_extra, use_warp=self.use_warp, out=out, bf16=self.bf16)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
-      self._out = call()          # warm-up: uploads the descriptor tables (not capturable), sizes the workspace
-      call(self._out)
+      outs = call()               # warm-up: uploads the descriptor tables (not capturable), sizes the workspace
+      call(outs)
     torch.cuda.current_stream().wait_stream(s)
-    self._graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(self._graph):
-      call(self._out)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+      call(outs)
+    self.captures += 1
+    return graph, ins, outs
 
   def __call__(self, key_0, key_1, params, rays, warp_extra):
     del key_0, key_1               # eval is deterministic (eval.py:239 forces use_stratified_sampling off)
     n = rays['origins'].shape[0]
     alpha = float((warp_extra or {}).get('alpha', 0.0))
     key = (n, params.flat.data_ptr(), alpha, tuple(sorted((rays.get('metadata') or {}).keys())))
-    if key != self._key:
-      self._capture(params, rays, warp_extra)
-      self._key = key
+    slot = self._slots.get(key)
+    if slot is None:
+      # every chunk size has its own workspace (descriptor tables included), so graphs of different sizes coexist
+      while len(self._slots) >= self.MAX_GRAPHS:
+        del self._slots[next(iter(self._slots))]
+      slot = self._slots[key] = self._capture(params, rays, warp_extra)
     else:
       def cp(dst, src):
         if isinstance(dst, dict):
@@ -59,9 +66,9 @@ class GraphedChunkRenderer:
             cp(dst[k], src[k])
         else:
           dst.copy_(src)
-      cp(self._in, rays)
-    self._graph.replay()
-    return _tree_map(lambda x: x.clone(), self._out)   # the static buffers are overwritten by the next replay
+      cp(slot[1], rays)
+    slot[0].replay()
+    return _tree_map(lambda x: x.clone(), slot[2])   # the static buffers are overwritten by the next replay
 
 
 def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_count: int = 1, rng=0,
@@ -80,25 +87,31 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
   rank = dist.get_rank() if world > 1 else 0
   del device_count
   ret_maps = []
-  for batch_idx in range(int(math.ceil(num_rays / chunk))):
+  num_chunks = int(math.ceil(num_rays / chunk))
+  # a graph-replaying renderer wants ONE chunk size per frame: the tail is edge-padded to the full chunk (rendered and
+  # dropped) instead of being a second shape; otherwise it is padded to a multiple of the world size only
+  fixed = bool(getattr(model_fn, 'wants_fixed_chunks', False)) and num_chunks > 1
+  for batch_idx in range(num_chunks):
     i0 = batch_idx * chunk
     chunk_rays = _tree_map(lambda x: x[i0:i0 + chunk], flat)
     n = chunk_rays['origins'].shape[0]
-    pad = (world - n % world) % world
+    full = -(-chunk // world) * world if fixed else n
+    pad = max(full - n, 0) + (world - max(full, n) % world) % world
     if pad:
       chunk_rays = _tree_map(lambda x: torch.cat([x, x[-1:].expand(pad, *x.shape[1:])], 0), chunk_rays)
     per = (n + pad) // world
-    mine = _tree_map(lambda x: x[rank * per:(rank + 1) * per], chunk_rays)
+    mine = _tree_map(lambda x: x[rank * per:(rank + 1) * per], chunk_rays) if world > 1 else chunk_rays
     out = model_fn(rng, rng + 1, state.optimizer.target, mine, state.warp_extra)
     ret_key = default_ret_key or ('fine' if 'fine' in out else 'coarse')
     ret = out[ret_key]
-    if world > 1:
-      gathered = {}
-      for k, v in ret.items():
-        parts = [torch.empty_like(v) for _ in range(world)]
-        dist.all_gather(parts, v.contiguous())
-        gathered[k] = torch.cat(parts, 0)
-      ret = gathered
+    if world > 1:   # ONE all_gather per chunk: every output key packed side by side into a (per, sum of widths) buffer
+      keys = list(ret.keys())
+      cols = [ret[k].reshape(per, -1).to(torch.float32) for k in keys]
+      packed = torch.cat(cols, 1).contiguous()
+      gathered = torch.empty(world * per, packed.shape[1], dtype=packed.dtype, device=packed.device)
+      dist.all_gather_into_tensor(gathered, packed)
+      split = torch.split(gathered, [c.shape[1] for c in cols], 1)
+      ret = {k: split[i].reshape(world * per, *ret[k].shape[1:]).to(ret[k].dtype) for i, k in enumerate(keys)}
     if pad:
       ret = {k: v[:-pad] for k, v in ret.items()}
     ret_maps.append(ret)

@@ -87,17 +87,26 @@ class TimeTracker:
 class ScalarLog:
   """Stand-in for the tensorboard SummaryWriter calls of train.py / eval.py: one JSON object per line."""
 
-  def __init__(self, directory):
-    os.makedirs(directory, exist_ok=True)
-    self._fp = open(os.path.join(directory, 'scalars.jsonl'), 'a')
+  def __init__(self, directory, enabled=True):
+    """enabled=False: a writer that drops everything (ranks other than 0: the reference writes summaries on process 0
+    only, eval.py `jax.process_index() == 0`)."""
+    self._fp = None
+    if enabled:
+      os.makedirs(directory, exist_ok=True)
+      self._fp = open(os.path.join(directory, 'scalars.jsonl'), 'a')
 
   def scalar(self, tag, value, step):
+    if self._fp is None:
+      return
     self._fp.write(json.dumps({'tag': tag, 'value': float(value), 'step': int(step)}) + '\n')
     self._fp.flush()
 
   def text(self, tag, textdata, step):
+    if self._fp is None:
+      return
     self._fp.write(json.dumps({'tag': tag, 'text': textdata, 'step': int(step)}) + '\n')
     self._fp.flush()
 
   def close(self):
-    self._fp.close()
+    if self._fp is not None:
+      self._fp.close()

@@ -46,6 +46,17 @@ def _fake_model_fn(key0, key1, params, rays, warp_extra):
   return {'fine': {'rgb': rgb, 'depth': (o * d).sum(-1), 'acc': o.norm(dim=-1)}}
 
 
+class _FixedChunkFn:
+  wants_fixed_chunks = True   # what evaluation.GraphedChunkRenderer declares
+
+  def __init__(self):
+    self.sizes = set()
+
+  def __call__(self, key0, key1, params, rays, warp_extra):
+    self.sizes.add(rays['origins'].shape[0])
+    return _fake_model_fn(key0, key1, params, rays, warp_extra)
+
+
 class _State:
   class optimizer:
     target = None
@@ -74,6 +85,11 @@ def _worker(rank, port, tmp):
   # ---- eval: rank-sliced chunks + all_gather reassemble the full image (evaluation.py:62-99) ----
   rays = {'origins': torch.linspace(-1, 1, 5 * 7 * 3).reshape(5, 7, 3), 'directions': torch.ones(5, 7, 3) * 0.1}
   img = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=9)   # 35 px: ragged, needs padding
+  fixed = _FixedChunkFn()   # a graph-replaying renderer: every call must see the same per-rank slice length
+  img_fixed = evaluation.render_image(_State, rays, fixed, device_count=WORLD, chunk=9)
+  assert fixed.sizes == {5}, fixed.sizes    # ceil(9 / 2) rays per rank in every chunk, the tail padded up to it
+  for k in img:
+    assert torch.equal(img[k], img_fixed[k])
   # ---- data: every rank takes its own 1/world slice of each global batch (core.py:110-121) ----
   from nerfies_amd import datasets
   n = 50

@@ -156,13 +156,19 @@ def test_warp_jacobian_output(kw, alpha, B):
     kink = _NearestKink()
     with O.relu_hook(kink):
       jo = O.se3_field(p['warp_field'], pts, ids, alpha, spec.num_warp_freqs, return_jacobian=True, name='jac/warp')['jacobian']
-    # J is piecewise constant in the ReLU branch pattern: a sample with a trunk unit within float32 rounding of its kink
-    # (amplified by 2^(F_w-1) in the posenc angle) may sit on the other branch than float64 and differs by O(1) there.
-    # Asserted: every deviating sample has such a tie (|pre| < 1e-3 of its layer's rms), and they are few.
-    bad = ((J.double().cpu() - jo).abs() > 5e-5 + 2e-5 * jo.abs()).reshape(-1, 9).any(-1)
+    # Float32 rounding of J scales with the sample's own |J| (the tangents carry the 2^(F_w-1) posenc factor): tolerance
+    # 5e-5 + 2e-4 * max|J_sample|.  Beyond that, J is piecewise constant in the ReLU branch pattern: a sample with a trunk
+    # unit within float32 rounding of its kink may sit on the other branch than float64 and differs by O(1) there.
+    # Asserted: every sample deviating by more than the rounding tolerance has such a tie (|pre| < 2e-3 of its layer's
+    # rms), and they are few.
+    err = (J.double().cpu() - jo).abs().reshape(-1, 9).max(-1).values
+    scale = jo.abs().reshape(-1, 9).max(-1).values
+    bad = err > 5e-5 + 2e-4 * scale
+    print(f'[jacobian {lv}] alpha {alpha}: err/scale median {(err / scale).median().item():.1e}, 99 % {(err / scale).quantile(0.99).item():.1e}; '
+          f'{int(bad.sum())}/{bad.numel()} samples on another ReLU branch, their nearest kink <= {kink.min[bad].max().item() if bad.any() else 0:.1e}')
     assert bad.float().mean().item() < 0.06, (lv, bad.float().mean().item())
-    assert (kink.min[bad] < 1e-3).all(), (lv, kink.min[bad].max().item())
-    assert (~bad).float().mean().item() > 0.9
+    assert (kink.min[bad] < 2e-3).all(), (lv, kink.min[bad].max().item())
+    assert (err / scale).median().item() < 2e-5
     assert (J - torch.eye(3, device=DEV)).abs().max().item() > 1e-3      # a real deformation, not the identity
   # use_warp_jacobian on the model (construct_nerf(..., use_warp_jacobian=True)): coarse level only (models.py:345)
   model.use_warp_jacobian = True

@@ -1,0 +1,95 @@
+"""The PRODUCT train_step on two ranks (training.py:266-267, train.py:254-262): two processes share cuda:0 (RCCL refuses
+two ranks on one device, so the collective backend is gloo on the same CUDA tensors -- the code path is the one
+`torchrun bench.py --gpus N` takes, only the transport differs), each runs nerfies_amd.training.train_step on its half
+of the rays for three Adam steps, and the parameters must match a single-process run on the whole batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+pytestmark = pytest.mark.gpu
+WORLD, B, STEPS, LR = 2, 96, 3, 1e-3
+KW = dict(num_coarse_samples=32, num_fine_samples=32, num_nerf_point_freqs=8, use_stratified_sampling=True, use_warp=True,
+          use_camera_metadata=True)
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
+
+
+def _inputs():
+  from oracle import nerfies_oracle as O
+  spec = O.ModelSpec(**KW)
+  p = O.init_params(spec, seed=31, trained_like=True)
+  b = O.synthetic_batch(B, seed=32)
+  g = torch.Generator().manual_seed(33)
+  uni = [(torch.rand(B, spec.num_coarse_samples, generator=g), torch.rand(B, spec.num_fine_samples, generator=g)) for _ in range(STEPS)]
+  return spec, p, b, uni
+
+
+def _run(rank, world):
+  """STEPS train steps on rows [rank*B/world, (rank+1)*B/world) of the batch; returns (flat params, per-step stats)."""
+  import helpers as H
+  from nerfies_amd import training
+  spec, p, b, uni = _inputs()
+  per = B // world
+  sl = slice(rank * per, (rank + 1) * per)
+  model, fp = H.gpu_model(spec, p, per)
+  gb = H.gpu_batch(b)
+  gb = {k: (v[sl] if torch.is_tensor(v) else {kk: vv[sl] for kk, vv in v.items()}) for k, v in gb.items()}
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=4.0)
+  sp = training.ScalarParams(learning_rate=LR, elastic_loss_weight=0.01)
+  hist = []
+  for k, (t_rand, u) in enumerate(uni):
+    state, stats, _ = training.train_step(model, k, state, gb, sp, use_elastic_loss=True, elastic_reduce_method='weight',
+                                          rngs={'coarse': t_rand[sl].to(H.DEV), 'fine': u[sl].to(H.DEV)})
+    hist.append([stats['coarse']['loss/rgb'].item(), stats['fine']['loss/rgb'].item(), stats['coarse']['loss/elastic'].item()])
+  torch.cuda.synchronize()
+  return fp.flat.cpu(), np.array(hist)
+
+
+def _worker(rank, port, tmp):
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+  flat, hist = _run(rank, WORLD)
+  both = [torch.empty_like(flat) for _ in range(WORLD)]
+  dist.all_gather(both, flat)
+  assert torch.equal(both[0], both[1])   # replicas stay bit-identical: same all-reduced gradient, same Adam
+  if rank == 0:
+    torch.save({'flat': flat, 'hist': hist}, tmp)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_train_step_equals_full_batch(tmp_path):
+  from nerfies_amd import params as P
+  import helpers as H
+  tmp = str(tmp_path / 'out.pt')
+  mp.spawn(_worker, args=(_free_port(), tmp), nprocs=WORLD, join=True)
+  got = torch.load(tmp, weights_only=False)
+  want, hist = _run(0, 1)
+  spec, p, _, _ = _inputs()
+  model, fp0 = H.gpu_model(spec, p, B)
+  init = fp0.flat.cpu()
+  travel = (want - init).norm().item()
+  diff = (got['flat'] - want).norm().item()
+  print(f'[2 ranks vs 1] |dp| {diff:.3e} over a travel of {travel:.3e}; max entry {(got["flat"] - want).abs().max().item():.2e}')
+  assert travel > 0.1 * LR * STEPS * np.sqrt(want.numel())     # Adam moved (most entries by ~lr per step)
+  assert diff < 1e-2 * travel
+  # single entries: an entry whose gradient is at rounding level gets sign-like Adam updates (m / sqrt(v)), so two float32
+  # summation orders (64-row tiles over different row sets) may move it in different directions -- bounded by the travel
+  assert (got['flat'] - want).abs().max().item() < LR * STEPS
+  # pmean of the statistics (training.py:267): the mean of the two shard MSEs is the full-batch MSE; the elastic loss
+  # likewise (mean over rays)
+  np.testing.assert_allclose(got['hist'], hist, rtol=2e-4, atol=1e-7)

@@ -24,10 +24,17 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
 }
+// Cache policy of the stash / dY stores (aux immediate of the buffer store: 1 = sc0, 2 = nt, 16 = sc1).  The stash is
+// written once and next read by another kernel after > 1 GB of other traffic, so it is stored non-temporal: the lines
+// do not displace the packed weights every workgroup re-reads from L2 (scripts/exp_stash_policy.sh, config A: 135.6 ->
+// 137.9 k rays/s; with nt on the wgrad operand copies as well 138.6; write-through sc0 sc1: no change).
+#ifndef NRF_STASH_AUX
+#define NRF_STASH_AUX 2
+#endif
 __device__ __forceinline__ void buf_store4(const float4& v, __amdgpu_buffer_rsrc_t r, int voff, int off) {
   u32x4 d;
   d.x = __float_as_uint(v.x); d.y = __float_as_uint(v.y); d.z = __float_as_uint(v.z); d.w = __float_as_uint(v.w);
-  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff + off, 0, 0);
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, voff + off, 0, NRF_STASH_AUX);
 }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

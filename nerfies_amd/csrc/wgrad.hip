@@ -25,6 +25,11 @@ constexpr int WG_LDS_FLOATS = WG_VEC + 2 * WG_VSTRIDE;
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// cache policy of the streamed operand copies (aux immediate: 1 = sc0, 2 = nt, 16 = sc1): every byte is read exactly once
+#ifndef NRF_WGRAD_AUX
+#define NRF_WGRAD_AUX 2
+#endif
+
 // Issues this wave's share of the global->LDS copies of chunk `c` (32 rows) of one operand tile:
 // pieces (blk, qq), blk < nblocks, qq < 4; piece id = blk*4 + qq is dealt round-robin to the 8 waves.
 __device__ __forceinline__ void stage_operand(const float* __restrict__ tile_base, int nblocks, int c, float* lds_oper,
@@ -34,7 +39,7 @@ __device__ __forceinline__ void stage_operand(const float* __restrict__ tile_bas
     const int blk = pid >> 2, qq = pid & 3;
     const float* src = tile_base + ((size_t)(blk * 8 + 4 * c + qq) * 64 + lane) * 4;
     float* dst = lds_oper + pid * 256;   // wave-uniform base; the hardware adds lane * 16 bytes
-    __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, NRF_WGRAD_AUX);
   }
 }
 

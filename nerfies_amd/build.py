@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libnerfies_amd.so')
-SOURCES = ['mlp_chain.hip', 'mlp_bf16.hip', 'warp_chain.hip', 'wgrad.hip', 'ray_kernels.hip', 'camera.hip', 'time_encoder.hip', 'nrf_api.hip']
+SOURCES = ['mlp_chain.hip', 'mlp_bf16.hip', 'warp_chain.hip', 'wgrad.hip', 'wgrad_bf16.hip', 'ray_kernels.hip', 'camera.hip', 'time_encoder.hip', 'nrf_api.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 
 

@@ -1,8 +1,17 @@
-// bf16-operand forward chain of the NeRF MLP (inference / rendering; BASELINE config D "bf16 MLP with fp32 composite").
+// bf16-operand chains of the NeRF MLP: forward (inference / rendering, and with the training stash) and the data-gradient
+// pass (BASELINE config D "bf16 MLP with fp32 composite").
 //
-// Opt-in mode (NRF_FLAG_BF16): activations and weights are rounded to bfloat16 (RNE) as MFMA operands, accumulation,
+// Opt-in mode (NRF_FLAG_BF16): activations, gradients and weights are rounded to bfloat16 (RNE) as MFMA operands; accumulation,
 // biases (hi + lo bf16 pair), the per-ray condition term, the activations' ReLU and everything outside the MLP
-// (sampling, compositing) stay fp32.  Not bit-comparable with the fp32 path: tests bound it at ~1e-2 on rendered colour.
+// (sampling, compositing, loss, master weights, Adam) stay fp32.  Not bit-comparable with the fp32 path: tests bound it at
+// ~1e-2 on rendered colour.
+//
+// Training (STASH): every layer's packed output registers -- which ARE the next layer's B operand -- are stored as they lie
+// (nrf_internal.h BfStash: 1 KiB coalesced per wave store, non-temporal), plus one sign bit per pre-activation
+// (v_alignbit: one VALU op per element).  The dgrad kernel below runs the same transposed chain backwards,
+//   dX^T[in feature][sample] = W . dY^T,   A = W as it is stored (K = the layer's output features),
+// masks with the sign bits, and stores each dpre in the same layout; wgrad_bf16.hip turns the two stashes into weight
+// gradients (LDS transpose reads).
 //
 // Dataflow: transposed GEMMs  H^T[feature][sample] = W^T . X^T  with v_mfma_f32_32x32x16_bf16; a wave owns NG groups of 32
 // samples (default 1; with 2 every weight fragment feeds two MFMAs) and ALL output features.  In the D layout lane (n, h) holds
@@ -83,9 +92,11 @@ __device__ __forceinline__ void bf_wait_vm() {   // s_waitcnt vmcnt(K), K a comp
 // BIAS.  Weights are prefetched TWO chunks ahead into a ring of three LDS buffers (an L2 -> LDS copy takes longer than one
 // chunk of MFMAs): NEXT1 / NEXT2 = byte counts of the two chunks that follow this GEMM's last one in the stream; WRAP:
 // they are the first two chunks of the chain (offsets 0 and NEXT1).
+// bias_b0: B operand register 0 of the bias k-step (k-slots 0, 1 of the h = 0 lanes): 1, 1 for a bias; the dgrad passes
+// (d sigma, d sigma) so that the row adds  d sigma * w_alpha  (the alpha head's input gradient).
 template <int NG, int NW, int NIN, int NOUT, bool BIAS, int NEXT1, int NEXT2, bool WRAP = false, bool INIT = true>
 __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[NG][NOUT], const unsigned (&in)[NG][NIN][8], BfStream& st, char* lds, int lane,
-                                        int wave) {
+                                        int wave, unsigned bias_b0 = 0x3F803F80u) {
   constexpr int NCHUNK = NIN / 2;   // 4 k-steps = 2 input blocks per chunk
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (INIT) {
@@ -127,7 +138,7 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[NG][NOUT], const unsigned 
         bf16x8 bop[NG];
 #pragma unroll
         for (int g = 0; g < NG; ++g)
-          bop[g] = bias_row ? as_bf16x8(0x3F803F80u, 0u, 0u, 0u)   // B = 1 in k-slots 0, 1 (bias hi + lo)
+          bop[g] = bias_row ? as_bf16x8(bias_b0, 0u, 0u, 0u)        // B = 1 in k-slots 0, 1 (bias hi + lo)
                             : as_bf16x8(in[g][b][4 * s2], in[g][b][4 * s2 + 1], in[g][b][4 * s2 + 2], in[g][b][4 * s2 + 3]);
 #pragma unroll
         for (int o = 0; o < NOUT; ++o)
@@ -174,6 +185,40 @@ __device__ __forceinline__ void bf_pack(unsigned (&out)[NG][NB][8], const f32x16
       }
 }
 
+// ---- training stash helpers ----
+// NB blocks of one group: [b][jp][lane] x 16 B, non-temporal (written once, read by another kernel much later)
+template <int NB>
+__device__ __forceinline__ void bf_store_blocks(uint32_t* group_base, const unsigned (&v)[NB][8], int lane) {
+  u32x4v* p = reinterpret_cast<u32x4v*>(group_base) + lane;
+#pragma unroll
+  for (int b = 0; b < NB; ++b)
+#pragma unroll
+    for (int jp = 0; jp < 2; ++jp) {
+      const u32x4v q = {v[b][4 * jp], v[b][4 * jp + 1], v[b][4 * jp + 2], v[b][4 * jp + 3]};
+      __builtin_nontemporal_store(q, p + (b * 2 + jp) * 64);
+    }
+}
+// ReLU derivative bits of NB blocks of accumulators: element (o, r) -> bit 31 - (16 (o & 1) + r) of dword o >> 1, 1 where
+// pre > 0 (the sign bit of 0 - pre: +0 and -0 both give 0, as jax's relu gradient does); a v_sub + a v_alignbit per element
+template <int NB>
+__device__ __forceinline__ void bf_signbits(unsigned (&mb)[(NB + 1) / 2], const f32x16 (&acc)[NB]) {
+#pragma unroll
+  for (int o = 0; o < NB; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb[o >> 1] = __builtin_amdgcn_alignbit(mb[o >> 1], __float_as_uint(__fsub_rn(0.f, acc[o][r])), 31);
+}
+// acc = 0 where the stashed pre-activation was not positive
+template <int NB>
+__device__ __forceinline__ void bf_mask(f32x16 (&acc)[NB], const unsigned (&mb)[(NB + 1) / 2]) {
+#pragma unroll
+  for (int o = 0; o < NB; ++o)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int keep = __builtin_amdgcn_sbfe((int)mb[o >> 1], 31 - (16 * (o & 1) + r), 1);   // -1 where pre > 0
+      acc[o][r] = __uint_as_float(__float_as_uint(acc[o][r]) & (unsigned)keep);
+    }
+}
+
 __device__ __forceinline__ float bf_sigma(float x, int kind) {
   return kind == 1 ? fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))) : fmaxf(x, 0.f);
 }
@@ -189,8 +234,9 @@ constexpr int LG0 = 20 * KB, LG1 = 16 * KB;         // rgb logits, padded to 4 b
 
 // NG sample groups of 32 per wave, NW waves per workgroup (NG * NW = 8): <2, 4> = one wave per SIMD with every weight fragment
 // feeding two MFMAs; <1, 8> = two waves per SIMD (latencies overlap) at twice the LDS reads per MFMA.
-template <int NG, int NW>
+template <int NG, int NW, bool STASH = false>
 __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void nerf_mlp_fwd_bf16_kernel(const ChainFwdArgs A) {
+  static_assert(!STASH || NG == 1, "the training stash is laid out for one 32-sample group per wave");
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -255,14 +301,28 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
           }
     };
 
+    // training stash: this wave's group
+    const size_t gidx = (size_t)it * 8 + wave;
+    auto stash_layer = [&](int l, const f32x16 (&acc)[NG][8], const unsigned (&packed)[NG][8][8]) {
+      if constexpr (STASH) {
+        unsigned mb[4] = {0u, 0u, 0u, 0u};
+        bf_signbits<8>(mb, acc[0]);
+        const u32x4v q = {mb[0], mb[1], mb[2], mb[3]};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x4v*>(A.bst.bits) + ((size_t)l * A.bst.ngroups + gidx) * 64 + lane);
+        bf_store_blocks<8>(A.bst.h + ((size_t)l * A.bst.ngroups + gidx) * 8 * BF_BLOCK_DW, packed[0], lane);
+      }
+    };
+
     // ---- trunk ----
     unsigned act[NG][8][8];
     {
       unsigned pe[NG][2][8];
       posenc(pe);
+      if constexpr (STASH) bf_store_blocks<2>(A.bst.pe + gidx * 2 * BF_BLOCK_DW, pe[0], lane);
       f32x16 acc[NG][8];
       bf_gemm<NG, NW, 2, 8, true, T0, T1>(acc, pe, st, bf_lds, lane, wave);
       bf_pack<NG, 8, true>(act, acc);
+      stash_layer(0, acc, act);
     }
 #pragma unroll 1
     for (int l = 1; l < TRUNK_DEPTH; ++l) {
@@ -278,6 +338,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         bf_gemm<NG, NW, 8, 8, true, T0, T1>(acc, act, st, bf_lds, lane, wave);
       }
       bf_pack<NG, 8, true>(act, acc);
+      stash_layer(l, acc, act);
     }
 
     // ---- bottleneck (linear) + alpha head as the ninth output block ----
@@ -294,6 +355,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 #pragma unroll
           for (int q = 0; q < 8; ++q) bn[g][o][q] = pack_bf16(acc9[g][o][2 * q], acc9[g][o][2 * q + 1]);
       }
+      if constexpr (STASH) bf_store_blocks<8>(A.bst.bn + gidx * 8 * BF_BLOCK_DW, bn[0], lane);
     }
 
     // ---- rgb branch ----
@@ -314,6 +376,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
           }
       }
       bf_pack<NG, 4, true>(rgbh, acc4);
+      if constexpr (STASH) {
+        unsigned mb[2] = {0u, 0u};
+        bf_signbits<4>(mb, acc4[0]);
+        const u32x4v q = {mb[0], mb[1], 0u, 0u};
+        __builtin_nontemporal_store(q, reinterpret_cast<u32x4v*>(A.bst.bits) + ((size_t)8 * A.bst.ngroups + gidx) * 64 + lane);
+        bf_store_blocks<4>(A.bst.rgbh + gidx * 4 * BF_BLOCK_DW, rgbh[0], lane);
+      }
     }
     f32x16 acc1[NG][4];   // blocks 1..3 are padding (zero weights)
     bf_gemm<NG, NW, 4, 4, true, T0, T0, true>(acc1, rgbh, st, bf_lds, lane, wave);   // then the chain restarts: layer 0, layer 1
@@ -331,6 +400,126 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         A.out4[row[g]] = o;
       }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// data-gradient chain (training): d raw (rgb, sigma) -> dpre of every layer, stored for wgrad_bf16.hip
+// ---------------------------------------------------------------------------------------------
+namespace {
+// chunk byte counts of the dgrad weight stream (GEMMs in execution order, one chunk = 4 k-steps x NOUT KiB):
+//   G1  logit^T   K = 32 (3 valid) padded to one 4-k-step chunk -> 128:   DG1
+//   G2  rgbh^T    K = 128 -> 256:                                          2 x DG
+//   G3  bn^T      K = 256 -> 256, first chunk carries the alpha row:      DG3, 3 x DG
+//   L7..L1        K = 256 -> 256:                                          4 x DG each
+constexpr int DG1 = 16 * KB, DG = 32 * KB, DG3 = 40 * KB;
+}  // namespace
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_bwd_bf16_kernel(const ChainBwdBf16Args A) {
+  extern __shared__ __attribute__((aligned(16))) char bf_lds[];
+  constexpr int NW = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 31, h = lane >> 5;
+  const int niter = (A.rows + 255) / 256;
+  const BfStash& S = A.st;
+
+  BfStream st;
+  st.src = reinterpret_cast<const char*>(A.wpk) + lane * 16;
+  st.soff = 0;
+  st.cur = 0;
+  bf_dma<DG1, NW>(st.src, 0, bf_lds, 0, wave);      // G1
+  bf_dma<DG, NW>(st.src, DG1, bf_lds, 1, wave);     // G2, chunk 0
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll 1
+  for (int it = blockIdx.x; it < niter; it += gridDim.x) {
+    const size_t gidx = (size_t)it * 8 + wave;
+    const int row = it * 256 + wave * 32 + n;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < A.rows) d = A.d_raw4[row];
+    auto bits_of = [&](int l) {   // nrf_internal.h BfStash::bits
+      return __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(S.bits) + ((size_t)l * S.ngroups + gidx) * 64 + lane);
+    };
+
+    // ---- d raw -> the "small" dY block (features 0..3 = d rgb logits, d raw sigma) ----
+    unsigned dsm[1][2][8];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) dsm[0][b][q] = 0u;
+    if (h == 0) { dsm[0][0][0] = pack_bf16(d.x, d.y); dsm[0][0][1] = pack_bf16(d.z, d.w); }
+    bf_store_blocks<2>(S.dsmall + gidx * 2 * BF_BLOCK_DW, dsm[0], lane);
+    const unsigned dsig2 = pack_bf16(d.w, d.w);
+
+    // ---- G1: d rgb hidden = W_logit . d logits (K index 3 = d sigma meets a zero weight row), ReLU mask ----
+    unsigned drg[1][4][8];
+    {
+      f32x16 acc4[1][4];
+      bf_gemm<1, NW, 2, 4, false, DG, DG>(acc4, dsm, st, bf_lds, lane, wave);
+      const u32x4v mq = bits_of(8);
+      const unsigned mb[2] = {mq.x, mq.y};
+      bf_mask<4>(acc4[0], mb);
+      bf_pack<1, 4, false>(drg, acc4);
+      bf_store_blocks<4>(S.drgbh + gidx * 4 * BF_BLOCK_DW, drg[0], lane);
+    }
+    // ---- G2: d bottleneck = W_rgbh[0:256] . d rgb hidden (linear) ----
+    unsigned dy[1][8][8];
+    {
+      f32x16 acc[1][8];
+      bf_gemm<1, NW, 4, 8, false, DG3, DG>(acc, drg, st, bf_lds, lane, wave);
+      bf_pack<1, 8, false>(dy, acc);
+      bf_store_blocks<8>(S.dbn + gidx * 8 * BF_BLOCK_DW, dy[0], lane);
+    }
+    // ---- G3: d h8 = W_bn . d bottleneck + w_alpha d sigma (the extra k-step), mask of layer 7 -> dpre_7 ----
+    {
+      f32x16 acc[1][8];
+      bf_gemm<1, NW, 8, 8, true, DG, DG>(acc, dy, st, bf_lds, lane, wave, dsig2);
+      const u32x4v mq = bits_of(7);
+      const unsigned mb[4] = {mq.x, mq.y, mq.z, mq.w};
+      bf_mask<8>(acc[0], mb);
+      bf_pack<1, 8, false>(dy, acc);
+      bf_store_blocks<8>(S.dy + ((size_t)7 * S.ngroups + gidx) * 8 * BF_BLOCK_DW, dy[0], lane);
+    }
+    // ---- l = 7..1: d h_l = W_l[0:256] . dpre_l, mask of layer l-1 -> dpre_{l-1} ----
+#pragma unroll 1
+    for (int l = TRUNK_DEPTH - 1; l >= 1; --l) {
+      f32x16 acc[1][8];
+      if (l > 1) bf_gemm<1, NW, 8, 8, false, DG, DG>(acc, dy, st, bf_lds, lane, wave);
+      else       bf_gemm<1, NW, 8, 8, false, DG1, DG, true>(acc, dy, st, bf_lds, lane, wave);   // then the stream restarts: G1, G2
+      const u32x4v mq = bits_of(l - 1);
+      const unsigned mb[4] = {mq.x, mq.y, mq.z, mq.w};
+      bf_mask<8>(acc[0], mb);
+      bf_pack<1, 8, false>(dy, acc);
+      bf_store_blocks<8>(S.dy + ((size_t)(l - 1) * S.ngroups + gidx) * 8 * BF_BLOCK_DW, dy[0], lane);
+    }
+  }
+}
+
+void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stream) {
+  const size_t lds = 3 * BF_BUF_BYTES;
+  (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel, dim3(grid), dim3(512), lds, stream, a);
+}
+
+// dray[ray][f] = sum over the ray's samples of dpre_rgbh[sample][f]  (gradient of the per-ray rgb-condition term), read back
+// from the bf16 stash: [group][b (4)][jp][lane = n + 32 h][(jj, i)], feature f = 32 b + 8 (2 jp + jj) + 4 h + i.
+__global__ __launch_bounds__(128) void dray_bf16_kernel(const uint32_t* __restrict__ drgbh, int S, float* __restrict__ dray) {
+  const int ray = blockIdx.x, f = threadIdx.x;
+  const int b = f >> 5, j = (f >> 3) & 3, h = (f >> 2) & 1, i = f & 3;
+  const unsigned short* base = reinterpret_cast<const unsigned short*>(drgbh);
+  const size_t in_group = ((size_t)(b * 2 + (j >> 1)) * 64 + 32 * h) * 8 + (j & 1) * 4 + i;   // + n * 8
+  float s = 0.f;
+  for (int k = 0; k < S; ++k) {
+    const size_t row = (size_t)ray * S + k;
+    const unsigned short v = base[(row >> 5) * (4 * BF_BLOCK_DW * 2) + in_group + (row & 31) * 8];
+    s += __uint_as_float((unsigned)v << 16);
+  }
+  dray[(size_t)ray * RGB_W + f] = s;
+}
+
+void launch_dray_bf16(const uint32_t* drgbh, int B, int S, float* dray, hipStream_t stream) {
+  hipLaunchKernelGGL(dray_bf16_kernel, dim3(B), dim3(128), 0, stream, drgbh, S, dray);
 }
 
 namespace {
@@ -357,7 +546,9 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 32 * b + 8 * (2 * s + (e >> 2)) + 4 * h + (e & 3);
-        if (k < d.krows && col < d.ncols) v[e] = params[d.src_off + (int64_t)(d.row0 + k) * d.src_ld + col];
+        if (k < d.krows && col < d.ncols)
+          v[e] = d.transposed ? params[d.src_off + (int64_t)(d.row0 + col) * d.src_ld + k]
+                              : params[d.src_off + (int64_t)(d.row0 + k) * d.src_ld + col];
       }
     }
     uint4 out;
@@ -373,6 +564,11 @@ void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, f
 
 void launch_chain_fwd_bf16(const ChainFwdArgs& a, int grid, hipStream_t stream) {
   const size_t lds = 3 * BF_BUF_BYTES;
+  if (a.bst.h) {   // training: stash every layer's packed output + sign bits
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<1, 8, true>), dim3(grid), dim3(512), lds, stream, a);
+    return;
+  }
   // measured (8192 rays x 256 samples): <1, 8> 3.44 ms, <2, 4> 4.30 ms for the fine level -> two waves per SIMD by default
   static const bool w8 = getenv("NRF_BF16_W4") == nullptr;
   if (w8) {

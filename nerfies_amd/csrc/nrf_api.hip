@@ -34,7 +34,10 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 struct LevelWs {   // float offsets from the workspace base, per level (0 = coarse, 1 = fine)
   size_t wpk, z, out4, rgb, depth, med, acc, weights, condterm;
   size_t alpha_ct = 0, dsig_ray = 0;   // use_alpha_condition: per-ray code term of the alpha head / per-ray sum of d raw sigma
-  size_t bf_wpk = 0;   // bf16 weight stream of the NRF_FLAG_BF16 forward (inference plans)
+  size_t bf_wpk = 0;   // bf16 weight stream of the NRF_FLAG_BF16 forward
+  // bf16 training (NRF_FLAG_TRAIN | NRF_FLAG_BF16): dgrad weight stream, the two bf16 stashes (nrf_internal.h BfStash), bias slabs
+  size_t bf_wpkT = 0, b_pe = 0, b_h = 0, b_bn = 0, b_rgbh = 0, b_bits = 0, b_dy = 0, b_dbn = 0, b_drgbh = 0, b_dsmall = 0;
+  int b_ngroups = 0;
   size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
   // SE3 warp field (per level: the field is evaluated on the coarse and on the fine samples)
@@ -55,6 +58,12 @@ struct WsPlan {
   std::vector<WgradSegment> segs;
   std::vector<int> seg_begin;
   int wgrad_nwg = 0;
+  // the same tables for the bf16 wgrad kernel (NeRF MLP groups of a bf16 training plan; "tile" = 32-sample group)
+  std::vector<WgradGroup> bgroups;
+  std::vector<WgradSegment> bsegs;
+  std::vector<int> bseg_begin;
+  size_t bgroups_off_b = 0, bsegs_off_b = 0, bsegbegin_off_b = 0;
+  int bwgrad_nwg = 0;
   size_t cond, mse, zero_rgb, slabs;
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
   size_t bg_loss;       // [64] background-loss accumulator
@@ -298,14 +307,20 @@ int* tile_counter_or_null(float* base, int idx) {
 constexpr int BG = 2;   // level index of the background-point batch
 constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coarse tiles)
 
-constexpr uint32_t PLAN_FLAGS = NRF_FLAG_TRAIN | NRF_FLAG_WARP_JACOBIAN;   // the flags a workspace layout depends on
+// the flags a workspace layout depends on: TRAIN, WARP_JACOBIAN, and BF16 together with TRAIN (bf16 stash instead of fp32)
+uint32_t plan_flags(uint32_t flags) {
+  uint32_t f = flags & (NRF_FLAG_TRAIN | NRF_FLAG_WARP_JACOBIAN);
+  if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_BF16)) f |= NRF_FLAG_BF16;
+  return f;
+}
 
 void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 0) {
   WsPlan& p = h->plan;
-  flags &= PLAN_FLAGS;
+  flags = plan_flags(flags);
   if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic) return;
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
+  const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
   const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) && h->warp;   // tangent pass in an inference plan
   const bool wstash = train || jac;                                // the warp kernels keep their input / sign-bit stash
   p = WsPlan();
@@ -360,12 +375,45 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     gv.dst = w.v_k; gv.vecoff = &L.w_dv4;
     push(gv);
   };
+  // bf16 training: the NeRF MLP groups go to the bf16 wgrad kernel (X / dY = bf16 stash buffers of Kb / Nb blocks per
+  // 32-sample group); bias = the group also owns the bias gradient (column sums of its dY)
+  struct BSpec { int lv; size_t* xoff; size_t xadd; int Kb; size_t* yoff; size_t yadd; int Nb;
+                 int64_t dst; int dst_ld, rows, cols, col0;          // weight leaf <- slab[0:rows][col0:col0+cols]
+                 int64_t bias_dst; int bias_cols;                     // bias leaf <- column sums [0:bias_cols], or -1
+                 int64_t bias2_dst; int bias2_col0; };                // a second 1-wide bias leaf (alpha: column 3), or -1
+  std::vector<BSpec> bspecs;
+  if (bft) {
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      LevelWs& L = p.L[lv];
+      const MlpParamOffsets& po = h->po[lv];
+      L.b_ngroups = (p.rows[lv] + 255) / 256 * 8;
+      const size_t layer = (size_t)L.b_ngroups * 8 * BF_BLOCK_DW;
+      auto bpush = [&](size_t* xoff, size_t xadd, int Kb, size_t* yoff, size_t yadd, int Nb, int64_t dst, int dst_ld, int rows, int cols,
+                       int col0, int64_t bias_dst, int bias_cols, int64_t bias2_dst = -1, int bias2_col0 = 0) {
+        bspecs.push_back({lv, xoff, xadd, Kb, yoff, yadd, Nb, dst, dst_ld, rows, cols, col0, bias_dst, bias_cols, bias2_dst, bias2_col0});
+      };
+      for (int l = 0; l < TRUNK_DEPTH; ++l) {
+        if (l == 0) {
+          bpush(&L.b_pe, 0, 2, &L.b_dy, 0, 8, po.trunk_k[0], 256, h->P, 256, 0, po.trunk_b[0], 256);
+        } else {
+          bpush(&L.b_h, (size_t)(l - 1) * layer, 8, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256, 256, 0, po.trunk_b[l], 256);
+          if (l == d.nerf_skip_layer)
+            bpush(&L.b_pe, 0, 2, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l] + 256 * 256, 256, h->P, 256, 0, -1, 0);
+        }
+      }
+      bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dbn, 0, 8, po.bn_k, 256, 256, 256, 0, po.bn_b, 256);
+      bpush(&L.b_bn, 0, 8, &L.b_drgbh, 0, 4, po.rgbh_k, 128, 256, 128, 0, po.rgbh_b, 128);
+      // narrow heads against the "small" dY block: columns 0..2 = d rgb logits (X = rgb hidden), column 3 = d raw sigma (X = h8)
+      bpush(&L.b_rgbh, 0, 4, &L.b_dsmall, 0, 2, po.logit_k, 3, 128, 3, 0, po.logit_b, 3, po.alpha_b, 3);
+      bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);
+    }
+  }
   if (train) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
       LevelWs& L = p.L[lv];
       const MlpParamOffsets& po = h->po[lv];
       const size_t layer = (size_t)p.ntiles[lv] * FRAG_TILE_256;
-      for (int l = 0; l < TRUNK_DEPTH; ++l) {
+      for (int l = 0; l < TRUNK_DEPTH && !bft; ++l) {
         if (l == 0) {
           specs.push_back({lv, SRC_PLAIN, &L.st_pe, PKS * TILE_ROWS, h->P, Kb_pe, SRC_FRAG256, &L.dy_trunk, FRAG_TILE_256, 8, 0,
                            po.trunk_k[0], 256, h->P, 256, Kb_pe * 8, 0, 0});
@@ -377,6 +425,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
                              po.trunk_k[l] + 256 * 256, 256, h->P, 256, Kb_pe * 8, 0, (size_t)l * layer});
         }
       }
+      if (!bft) {
       specs.push_back({lv, SRC_FRAG256, &L.st_h, FRAG_TILE_256, 256, 8, SRC_FRAG256, &L.dy_bn, FRAG_TILE_256, 8, 0,
                        po.bn_k, 256, 256, 256, 64, (size_t)7 * layer, 0});
       specs.push_back({lv, SRC_FRAG256, &L.st_bn, FRAG_TILE_256, 256, 8, SRC_FRAG128, &L.dy_rgbh, FRAG_TILE_128, 4, 0,
@@ -389,6 +438,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
                          po.alpha_k, 1, 256, 1, 12, (size_t)7 * layer, 0});
       specs.push_back({lv, SRC_FRAG128, &L.st_rgbh, FRAG_TILE_128, 128, 4, 0, nullptr, 0, 0, 3,
                        po.logit_k, 3, 128, 3, 6, 0, 0});
+      }
       if (h->warp) add_warp_groups(lv, lv > 0 ? 1 : 0);   // the field is shared by both passes: level 1 accumulates
     }
     if (h->warp && bgN > 0) add_warp_groups(BG, 2);
@@ -448,6 +498,40 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     while ((int)p.seg_begin.size() < nwg + 1) p.seg_begin.push_back((int)p.segs.size());
     p.wgrad_nwg = nwg;
   }
+  // ---- the same stream-K cut for the bf16 groups: HBM-bound, cost = blocks streamed per 32-sample group ----
+  std::vector<int> bnsplit(bspecs.size(), 0);
+  if (!bspecs.empty()) {
+    const double bc_seg = env_cost("NRF_BCOST_SEG", 24.0);   // opening a segment (pipeline fill + 256 KiB slab flush), in block units
+    auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb); };
+    double total = 0;
+    for (auto& sp : bspecs) total += bcost(sp) * p.L[sp.lv].b_ngroups;
+    const int nwg = G;
+    total += bc_seg * (nwg + (double)bspecs.size());
+    const double quota = total / nwg;
+    p.bseg_begin.assign(1, 0);
+    int w = 0;
+    double room = quota;
+    for (size_t gi = 0; gi < bspecs.size(); ++gi) {
+      const double c = bcost(bspecs[gi]);
+      int t0 = 0;
+      const int nt = p.L[bspecs[gi].lv].b_ngroups;
+      while (t0 < nt) {
+        int take_n = (int)floor((room - bc_seg) / c + 1e-9);
+        if (take_n <= 0 && w < nwg - 1) {
+          p.bseg_begin.push_back((int)p.bsegs.size());
+          ++w; room += quota;
+          continue;
+        }
+        if (take_n <= 0 || w == nwg - 1 || take_n > nt - t0) take_n = nt - t0;
+        p.bsegs.push_back({(int)gi, t0, t0 + take_n, bnsplit[gi]});
+        bnsplit[gi] += 1;
+        t0 += take_n;
+        room -= bc_seg + take_n * c;
+      }
+    }
+    while ((int)p.bseg_begin.size() < nwg + 1) p.bseg_begin.push_back((int)p.bsegs.size());
+    p.bwgrad_nwg = nwg;
+  }
   p.ntasks = (int)p.segs.size();
   const int npack = 64;
   const int nreduce_max = 192;
@@ -458,23 +542,29 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   p.segs_off_b = p.reduce_off_b + align_up(nreduce_max * sizeof(ReduceDesc), 256);
   p.segbegin_off_b = p.segs_off_b + align_up(p.segs.size() * sizeof(WgradSegment) + 256, 256);
   p.emb_off_b = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
-  const size_t table_bytes = p.emb_off_b + align_up((h->emb.size() + 1) * sizeof(EmbedDesc), 256);
+  p.bgroups_off_b = p.emb_off_b + align_up((h->emb.size() + 1) * sizeof(EmbedDesc), 256);
+  p.bsegs_off_b = p.bgroups_off_b + align_up(bspecs.size() * sizeof(WgradGroup) + 256, 256);
+  p.bsegbegin_off_b = p.bsegs_off_b + align_up(p.bsegs.size() * sizeof(WgradSegment) + 256, 256);
+  const size_t table_bytes = p.bsegbegin_off_b + align_up((p.bseg_begin.size() + 1) * sizeof(int), 256);
   p.tables = take(table_bytes / 4);
   if (h->embed) {
     p.iparams = take((size_t)h->nparams);
     if (train) p.igrad = take((size_t)h->nparams);
   }
   p.bfpack.clear();
-  if (!train) {   // weight stream of the bf16 forward (mlp_bf16.hip), GEMMs in execution order, rows of nout KiB
+  if (!train || bft) {   // weight stream of the bf16 forward (mlp_bf16.hip), GEMMs in execution order, rows of nout KiB
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
       const size_t stream_floats = (size_t)(40 + 7 * 136 + 32 + 153 + 64 + 36 + 64) * 256;   // KiB -> floats, + slack
       p.L[lv].bf_wpk = take(stream_floats);
       size_t at = 0;   // floats from the level's stream base
+      size_t base = p.L[lv].bf_wpk;
+      int tr = 0;
       auto emit = [&](int kind, int64_t src, int ld, int row0, int krows, int ncols, int nrows, int nout, int npanel, int o0) {
         RcPackDesc e;
-        e.src_off = src; e.dst_off = (long long)(p.L[lv].bf_wpk + at); e.kind = kind; e.src_ld = ld; e.row0 = row0; e.krows = krows;
-        e.ncols = ncols; e.ngroups = nrows; e.nout = nout; e.nout_panel = npanel; e.o0 = o0;
+        memset(&e, 0, sizeof(e));
+        e.src_off = src; e.dst_off = (long long)(base + at); e.kind = kind; e.src_ld = ld; e.row0 = row0; e.krows = krows;
+        e.ncols = ncols; e.ngroups = nrows; e.nout = nout; e.nout_panel = npanel; e.o0 = o0; e.transposed = tr;
         p.bfpack.push_back(e);
       };
       auto gemm = [&](int64_t wk, int ld, int row0, int krows, int ncols, int nin, int nout, int64_t bias) {
@@ -495,6 +585,16 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       at += (size_t)16 * 9 * 256;
       gemm(po.rgbh_k, RGB_W, 0, TRUNK_W, RGB_W, 8, 4, -1);
       gemm(po.logit_k, 3, 0, RGB_W, 3, 4, 4, po.logit_b);   // padded to 4 output blocks (whole 4-KiB chunk groups)
+      if (bft) {
+        // dgrad stream (nerf_mlp_bwd_bf16_kernel): A = W as stored, [m = the layer's input feature][k = its output feature];
+        // gemm(leaf, ld, row0, valid K, valid M, K blocks, M blocks, bias leaf)
+        p.L[lv].bf_wpkT = take((size_t)(16 + 64 + 8 + 128 + 7 * 128 + 64) * 256);
+        base = p.L[lv].bf_wpkT; at = 0; tr = 1;
+        gemm(po.logit_k, 3, 0, 3, RGB_W, 2, 4, -1);                        // G1: K padded to one 4-k-step chunk (3 valid)
+        gemm(po.rgbh_k, RGB_W, 0, RGB_W, TRUNK_W, 4, 8, -1);               // G2: rows 0..255 of [256+R, 128]
+        gemm(po.bn_k, TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, po.alpha_k);     // G3: + the alpha row (w_alpha as the "bias")
+        for (int l = TRUNK_DEPTH - 1; l >= 1; --l) gemm(po.trunk_k[l], TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, -1);
+      }
     }
     p.bf_desc = take(p.bfpack.size() * sizeof(RcPackDesc) / 4 + 16);
   }
@@ -532,7 +632,22 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     L.weights = take((size_t)p.rows[lv]);
     L.condterm = take((size_t)B * RGB_W);
     if (h->A > 0) { L.alpha_ct = take(B); L.dsig_ray = take(B); }
-    if (train) {
+    if (bft) {   // bf16 stashes (nrf_internal.h BfStash), dwords
+      const size_t ng = L.b_ngroups;
+      L.b_pe = take(ng * 2 * BF_BLOCK_DW);
+      L.b_h = take(ng * 8 * BF_BLOCK_DW * TRUNK_DEPTH);
+      L.b_bn = take(ng * 8 * BF_BLOCK_DW);
+      L.b_rgbh = take(ng * 4 * BF_BLOCK_DW);
+      L.b_bits = take(ng * 64 * 4 * (TRUNK_DEPTH + 1));
+      L.b_dy = take(ng * 8 * BF_BLOCK_DW * TRUNK_DEPTH);
+      L.b_dbn = take(ng * 8 * BF_BLOCK_DW);
+      L.b_drgbh = take(ng * 4 * BF_BLOCK_DW);
+      L.b_dsmall = take(ng * 2 * BF_BLOCK_DW);
+      L.d_raw4 = take(nt * TILE_ROWS * 4);
+      L.dray = take((size_t)B * RGB_W);
+      L.small_part = take((size_t)2 * G * SMALL_PART);
+      L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
+    } else if (train) {
       L.st_pe = take(nt * PKS * TILE_ROWS);
       L.st_h = take(nt * FRAG_TILE_256 * TRUNK_DEPTH);
       L.st_bn = take(nt * FRAG_TILE_256);
@@ -665,12 +780,39 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       wsmall(w.w_b, 3, 768);
       wsmall(w.v_b, 3, 771);
     };
+    // bf16 groups: slab [Kb*32][Nb*32] per segment (+ a bias slab [Nb*32]); the leaf takes a column window of it
+    for (size_t i = 0; i < bspecs.size(); ++i) {
+      const BSpec& sp = bspecs[i];
+      WgradGroup g;
+      memset(&g, 0, sizeof(g));
+      g.x_off = (int64_t)(*sp.xoff + sp.xadd); g.x_tile_stride = sp.Kb * BF_BLOCK_DW; g.Kb = sp.Kb; g.x_kvalid = sp.rows;
+      g.dy_off = (int64_t)(*sp.yoff + sp.yadd); g.dy_tile_stride = sp.Nb * BF_BLOCK_DW; g.Nb = sp.Nb;
+      g.ntiles = p.L[sp.lv].b_ngroups; g.nsplit = bnsplit[i]; g.vec_off = -1;
+      g.slab_off = (int64_t)take((size_t)g.nsplit * sp.Kb * 32 * sp.Nb * 32);
+      g.vslab_off = sp.bias_dst >= 0 ? (int64_t)take((size_t)g.nsplit * sp.Nb * 32) : -1;
+      p.bgroups.push_back(g);
+      ReduceDesc r;
+      memset(&r, 0, sizeof(r));
+      r.dst_off = sp.dst; r.dst_ld = sp.dst_ld; r.rows = sp.rows; r.cols = sp.cols;
+      r.src_off = g.slab_off + sp.col0; r.src_ld = sp.Nb * 32; r.part_stride = (int64_t)sp.Kb * 32 * sp.Nb * 32; r.nparts = g.nsplit;
+      p.reduce.push_back(r);
+      auto bias = [&](int64_t dst, int cols, int col0) {
+        ReduceDesc b;
+        memset(&b, 0, sizeof(b));
+        b.dst_off = dst; b.dst_ld = cols; b.rows = 1; b.cols = cols;
+        b.src_off = g.vslab_off + col0; b.src_ld = sp.Nb * 32; b.part_stride = sp.Nb * 32; b.nparts = g.nsplit;
+        p.reduce.push_back(b);
+      };
+      if (sp.bias_dst >= 0) bias(sp.bias_dst, sp.bias_cols, 0);
+      if (sp.bias2_dst >= 0) bias(sp.bias2_dst, 1, sp.bias2_col0);
+    }
     // bias gradients and per-ray condition rows
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
       const LevelWs& L = p.L[lv];
       const int grid = p.ntiles[lv] < 2 * G ? p.ntiles[lv] : 2 * G;   // chain kernels: two workgroups per CU
       auto small = [&](int64_t dst, int cols, int sp_off) {
+        if (bft) return;   // the bf16 wgrad kernel sums the bias columns itself
         ReduceDesc r;
         memset(&r, 0, sizeof(r));
         r.dst_off = dst; r.dst_ld = cols; r.rows = 1; r.cols = cols;
@@ -726,6 +868,14 @@ int upload_tables(nrf_handle h, float* ws, hipStream_t stream) {
     e = hipMemcpyAsync(ws + p.bf_desc, p.bfpack.data(), p.bfpack.size() * sizeof(RcPackDesc), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload bf16 pack table");
   }
+  if (!p.bgroups.empty()) {
+    e = hipMemcpyAsync(base + p.bgroups_off_b, p.bgroups.data(), p.bgroups.size() * sizeof(WgradGroup), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload bf16 wgrad table");
+    e = hipMemcpyAsync(base + p.bsegs_off_b, p.bsegs.data(), p.bsegs.size() * sizeof(WgradSegment), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload bf16 wgrad segments");
+    e = hipMemcpyAsync(base + p.bsegbegin_off_b, p.bseg_begin.data(), p.bseg_begin.size() * sizeof(int), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return fail_hip(e, "upload bf16 wgrad segment index");
+  }
   if (h->embed) {
     e = hipMemcpyAsync(base + p.emb_off_b, h->emb.data(), h->emb.size() * sizeof(EmbedDesc), hipMemcpyHostToDevice, stream);
     if (e != hipSuccess) return fail_hip(e, "upload embed table");
@@ -774,6 +924,16 @@ int validate_rays(nrf_handle h, const nrf_rays* rays) {
   return NRF_OK;
 }
 
+BfStash bf_stash(const WsPlan& p, int lv, float* ws) {
+  const LevelWs& L = p.L[lv];
+  BfStash b;
+  auto u = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+  b.pe = u(L.b_pe); b.h = u(L.b_h); b.bn = u(L.b_bn); b.rgbh = u(L.b_rgbh); b.bits = u(L.b_bits);
+  b.dy = u(L.b_dy); b.dbn = u(L.b_dbn); b.drgbh = u(L.b_drgbh); b.dsmall = u(L.b_dsmall);
+  b.ngroups = L.b_ngroups;
+  return b;
+}
+
 ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train, const nrf_rand* rnd) {
   const WsPlan& p = h->plan;
   const LevelWs& L = p.L[lv];
@@ -792,7 +952,9 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
     a.noise = rnd ? (lv == 0 ? rnd->noise_coarse : rnd->noise_fine) : nullptr;
     a.noise_seed = rnd ? rnd->seed : 0; a.noise_offset = rnd ? rnd->offset : 0; a.noise_stream = 2u + (unsigned)lv;
   }
-  if (train) {
+  if (train && (p.flags & NRF_FLAG_BF16)) {
+    a.bst = bf_stash(p, lv, ws);
+  } else if (train) {
     a.st_pe = ws + L.st_pe; a.st_h = ws + L.st_h; a.st_bn = ws + L.st_bn; a.st_rgbh = ws + L.st_rgbh;
     a.bits_trunk = reinterpret_cast<uint32_t*>(ws + L.bits_trunk);
     a.bits_rgbh = reinterpret_cast<uint32_t*>(ws + L.bits_rgbh);
@@ -881,7 +1043,8 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   const bool warp_on = h->warp && !(flags & NRF_FLAG_NO_WARP);   // models.py:296 use_warp argument
   if (warp_on && !scalars) return fail(NRF_E_NULL, "nrf_step_scalars (warp_alpha) required with the warp field");
   if (h->warp && !warp_on && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
-  if ((flags & NRF_FLAG_BF16) && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is an inference mode: no bf16 backward is built");
+  if ((flags & NRF_FLAG_BF16) && train && h->warp)
+    return fail(NRF_E_UNSUPPORTED, "bf16 training is built for the canonical NeRF (use_warp off): the bf16 dgrad does not yet return d points");
   if ((flags & NRF_FLAG_BF16) && h->A > 0) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is not built for use_alpha_condition");
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
   const bool encoded = rays->warp_codes || rays->appearance_codes || rays->camera_codes;
@@ -1037,6 +1200,18 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
                          target ? nullptr : d_rgb[lv], loss_scale, reinterpret_cast<float4*>(ws + L.d_raw4),
                          p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, h->A > 0 ? ws + L.dsig_ray : nullptr, stream);
     h->prof.end(stream);
+    const bool bft = p.flags & NRF_FLAG_BF16;
+    if (bft) {   // bf16 dgrad chain: dpre of every layer into the bf16 dY stash, then the per-ray condition sums
+      ChainBwdBf16Args ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.wpk = ws + L.bf_wpkT; ba.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
+      ba.S = p.S[lv]; ba.B = B; ba.rows = p.rows[lv]; ba.st = bf_stash(p, lv, ws);
+      const int nit = (p.rows[lv] + 255) / 256;
+      h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, false) * p.rows[lv], stream);
+      launch_chain_bwd_bf16(ba, nit < h->num_cus ? nit : h->num_cus, stream);
+      h->prof.end(stream);
+      launch_dray_bf16(ba.st.drgbh, B, p.S[lv], ws + L.dray, stream);
+    }
     ChainBwdArgs a;
     memset(&a, 0, sizeof(a));
     a.params = params; a.po = h->po[lv]; a.wpk = ws + L.wpk; a.pk = h->pk;
@@ -1051,9 +1226,11 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     a.alpha_on_bn = h->A > 0 ? 1 : 0;
     a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_BWD + lv);
     const int grid = p.ntiles[lv] < 2 * h->num_cus ? p.ntiles[lv] : 2 * h->num_cus;   // two workgroups per CU
-    h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
-    launch_chain_bwd(a, grid, stream);
-    h->prof.end(stream);
+    if (!bft) {
+      h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
+      launch_chain_bwd(a, grid, stream);
+      h->prof.end(stream);
+    }
     const bool el_on = el && p.elastic && warp_on && lv == 0;
     if (el_on) {
       const LevelWs& T = p.L[TG];
@@ -1173,12 +1350,22 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   }
   double wg_rows = 0;
   for (int lv = 0; lv < h->nlevels; ++lv) wg_rows += p.rows[lv];
-  h->prof.begin("wgrad", (wgrad_flops_row(h) + (warp_on ? warp_fwd_flops_row(h) : 0.0)) * wg_rows, stream);
-  launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b),
-               reinterpret_cast<const WgradSegment*>(tables + p.segs_off_b),
-               reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws,
-               reinterpret_cast<unsigned long long*>(ws + p.seg_clock), stream);
-  h->prof.end(stream);
+  const bool bft_any = p.flags & NRF_FLAG_BF16;
+  if (!p.segs.empty()) {
+    h->prof.begin("wgrad", ((bft_any ? 0.0 : wgrad_flops_row(h)) + (warp_on ? warp_fwd_flops_row(h) : 0.0)) * wg_rows, stream);
+    launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b),
+                 reinterpret_cast<const WgradSegment*>(tables + p.segs_off_b),
+                 reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws,
+                 reinterpret_cast<unsigned long long*>(ws + p.seg_clock), stream);
+    h->prof.end(stream);
+  }
+  if (!p.bsegs.empty()) {
+    h->prof.begin("wgrad_bf16", wgrad_flops_row(h) * wg_rows, stream);
+    launch_wgrad_bf16(reinterpret_cast<const WgradGroup*>(tables + p.bgroups_off_b),
+                      reinterpret_cast<const WgradSegment*>(tables + p.bsegs_off_b),
+                      reinterpret_cast<const int*>(tables + p.bsegbegin_off_b), p.bwgrad_nwg, ws, stream);
+    h->prof.end(stream);
+  }
   h->prof.begin("grad_reduce", 0, stream);
   const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
   for (int pass = 0, at = 0; pass < 4; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
@@ -1498,6 +1685,8 @@ int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* 
       {"wpoints", L.wpoints}, {"d_points", L.d_points}, {"w_st_win", L.w_st_win}, {"w_st_h", L.w_st_h},
       {"w_st_wv", L.w_st_wv}, {"w_dy", L.w_dy}, {"w_dw4", L.w_dw4}, {"w_dv4", L.w_dv4},
       {"w_bits", L.w_bits}, {"bits_trunk", L.bits_trunk}, {"bits_rgbh", L.bits_rgbh},
+      {"b_pe", L.b_pe}, {"b_h", L.b_h}, {"b_bn", L.b_bn}, {"b_rgbh", L.b_rgbh}, {"b_bits", L.b_bits}, {"b_dy", L.b_dy},
+      {"b_dbn", L.b_dbn}, {"b_drgbh", L.b_drgbh}, {"b_dsmall", L.b_dsmall},
       {"timeline", h->plan.timeline + (size_t)(level & 1) * 2 * (256 + 512 + 4 * 2048)}};
   for (const auto& t : tab)
     if (!strcmp(t.n, name)) { *float_offset = (int64_t)t.v; return NRF_OK; }

@@ -86,14 +86,48 @@ void launch_time_encoder_fwd(const TimeEncArgs& a, hipStream_t stream);
 void launch_time_encoder_bwd(const TimeEncArgs& a, hipStream_t stream);
 void launch_time_encoder_wgrad(const TimeEncArgs& a, float* grad, hipStream_t stream);
 
-// bf16 forward chain (mlp_bf16.hip): one descriptor fills rows of its weight stream
+// bf16 chains (mlp_bf16.hip): one descriptor fills rows of a weight stream
 struct RcPackDesc {
   long long src_off, dst_off;   // params leaf / first row written, in floats from the workspace base
   int kind;                     // 0: k-step rows of weights, 1: the bias row
-  int src_ld, row0, krows, ncols;   // leaf column count, first row, valid rows (K) and columns
+  int src_ld, row0, krows, ncols;   // leaf column count, first row, valid K and valid M (output index of the GEMM)
   int ngroups, nout, nout_panel, o0;   // rows written, output blocks written, GEMM width in blocks, first output block
+  int transposed;               // 0: A[m][k] = leaf[row0 + k][m] (forward); 1: A[m][k] = leaf[row0 + m][k] (dgrad: W as is)
+  int pad_;
 };
 void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream);
+
+// ---- bf16 training stash (mlp_bf16.hip writes it, wgrad_bf16.hip reads it) ----
+// Unit = one GROUP of 32 samples (one wave of the bf16 chain kernels) x one BLOCK of 32 features = 2 KiB:
+//   [jp (2)][lane = n + 32 h (64)][8 bf16],  the 8 = features 32 b + 8 (2 jp + jj) + 4 h + i  in (jj, i) order
+// -- the packed B operand of k-step (b, jp) of the transposed chain, stored as it lies in the registers (1 KiB coalesced
+// per wave store).  A buffer of NB blocks is [group][b][jp][lane].
+constexpr int BF_GROUP = 32;
+constexpr int BF_BLOCK_DW = 512;   // dwords per (group, block)
+struct BfStash {
+  uint32_t* pe;      // [ngroups][2]   posenc (layer-0 / skip input)
+  uint32_t* h;       // [8][ngroups][8]  h1..h8 (post-ReLU)
+  uint32_t* bn;      // [ngroups][8]   bottleneck output (linear)
+  uint32_t* rgbh;    // [ngroups][4]   rgb hidden (post-ReLU)
+  uint32_t* bits;    // [9][ngroups][64 lanes][4 dwords]: ReLU derivative bits of trunk layers 0..7 and (index 8, two dwords
+                     // used) the rgb hidden layer; element (block o, accumulator register r) of a lane is bit
+                     // 31 - (16 (o & 1) + r) of dword o >> 1; 1 = pre-activation > 0
+  uint32_t* dy;      // [8][ngroups][8]  dpre_0..dpre_7
+  uint32_t* dbn;     // [ngroups][8]
+  uint32_t* drgbh;   // [ngroups][4]
+  uint32_t* dsmall;  // [ngroups][2]   block 0 features 0..3 = d raw (r, g, b, sigma), everything else 0
+  int ngroups;       // whole workgroup iterations: 8 * ceil(rows / 256)
+};
+
+struct ChainBwdBf16Args {
+  const float* wpk;          // dgrad weight stream (W as the A operand, K = the layer's output features)
+  const float4* d_raw4;      // [rows_pad] dL/d(raw rgb, raw sigma); 0 on pad rows
+  int S, B, rows;
+  BfStash st;
+};
+void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stream);
+// per-ray sums of dpre_rgbh from its bf16 stash -> dray [B][128] (gradient of the rgb-condition columns)
+void launch_dray_bf16(const uint32_t* drgbh, int B, int S, float* dray, hipStream_t stream);
 
 struct ChainFwdArgs {
   const float* params;       // flat canonical parameters
@@ -128,6 +162,7 @@ struct ChainFwdArgs {
   // ReLU sign bits for the dgrad pass, one bit per accumulator element, fragment-native
   uint32_t* bits_trunk;      // [8][ntiles][4 waves][64 lanes] x 4 dwords
   uint32_t* bits_rgbh;       // [ntiles][4 waves][64 lanes] x 2 dwords
+  BfStash bst;               // bf16 training chain (NRF_FLAG_BF16 | NRF_FLAG_TRAIN); pointers null otherwise
 };
 
 struct ChainBwdArgs {
@@ -291,6 +326,11 @@ void launch_median_coef(const float* weights, int B, int S, float* coef, hipStre
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   unsigned long long* seg_clock, hipStream_t stream);
 void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
+// bf16 wgrad (wgrad_bf16.hip): the same group / segment tables, "tile" = one 32-sample group of the bf16 stash, Kb / Nb
+// blocks per group for X / dY (x_tile_stride = Kb * 512, dy_tile_stride = Nb * 512 dwords); vslab_off >= 0: the
+// group also sums dY over the rows (bias gradient) into vslab[slab_idx][Nb * 32]
+void launch_wgrad_bf16(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
+                       hipStream_t stream);
 
 struct RayPrepArgs {
   const float* params;

@@ -1,0 +1,183 @@
+// Weight-gradient GEMMs of the bf16 training path:  dW[k][n] = sum_rows X[row][k] * dY[row][n]  (and the bias gradients
+// sum_rows dY[row][n]) from the two bf16 stashes the chain kernels of mlp_bf16.hip leave behind (the transpose jax.grad
+// builds for modules.MLP, modules.py:41-58).
+//
+// Bound: HBM.  Both operands are read exactly once: 2 x 4.9 KB per MLP row = 2.6 GB per 1024 x (64+128) step, against
+// 308 GFLOP (0.12 ms at the dense bf16 MFMA peak): the kernel is priced in bytes, the MFMA side only has to keep up.
+//
+// The stash holds, per 32-sample group and 32-feature block, the chain kernels' B operands as they lay in the registers:
+// sample-major, 8 consecutive-K features per lane (nrf_internal.h BfStash).  The contraction here runs over SAMPLES, so both
+// MFMA operands need 8 consecutive samples of one feature per lane -- a 16-bit transpose.  It is done by the LDS:
+//   * global_load_lds copies 16-B granules into an LDS image [sample n (32)][h (2)][j (4)][i (4)] bf16 = 64 B per sample and
+//     block (every lane picks its own source granule, the LDS side is lane-linear: 1 KiB per wave instruction, no registers);
+//   * ds_read_b64_tr_b16 (gfx950) reads it back transposed: within a group of 16 lanes, lane c receives element c & 3 of the
+//     pieces of lanes 4j + (c >> 2), j = 0..3.  With lane (r, q) of a group pointing at piece q of sample r, a lane gets
+//     4 consecutive samples of feature 32 b + (lane & 31): two reads = the 8 K-slots of v_mfma_f32_32x32x16_bf16, for the A
+//     operand (X) and the B operand (dY) alike.  A 32-lane half covers 256 contiguous bytes per read: conflict free.
+// Work split: the stream-K tables of the fp32 kernel (nrf_internal.h WgradGroup / WgradSegment, "tile" = one 32-sample
+// group); one workgroup of 8 waves holds a [Kb*32][Nb*32] fp32 partial in registers and flushes it to a slab per segment;
+// reduce_kernel (wgrad.hip) sums the slabs.  Operands arrive through a ring of four 32 KiB LDS buffers, three chunks in
+// flight per CU, one barrier per chunk.
+#include "nrf_internal.h"
+
+namespace nrf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+namespace {
+
+constexpr int WB_RING = 4;                   // LDS buffers (chunks of one 32-sample group)
+constexpr int WB_CHUNK = 32 * 1024;          // bytes per buffer: up to 16 blocks of 2 KiB (X then dY)
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// operand fragment (block image at `img`, k-step ks): two transposing reads = K-slots 0..3, 4..7
+__device__ __forceinline__ bf16x8 read_frag(const char* img, int ks) {
+  struct { s16x4 lo, hi; } v;
+  const char* p = img + ks * 1024;
+  v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p));
+  v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 256));
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+// sum of the 8 bf16 of a fragment (the lane's 8 samples of one dY column)
+__device__ __forceinline__ float frag_sum(const bf16x8& f) {
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 u = __builtin_bit_cast(u32x4, f);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += __uint_as_float(u[i] << 16) + __uint_as_float(u[i] & 0xFFFF0000u);
+  return s;
+}
+
+// NRB x 2 output blocks per wave; CPW = global_load_lds instructions per wave and chunk (= ceil(2 (Kb + Nb) / 8))
+template <int NRB, int CPW>
+__device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const WgradSegment& sg, float* ws, char* lds, int kb0, int nb0,
+                                                bool active) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int Kb = G.Kb, Nb = G.Nb;
+  const int npieces = 2 * (Kb + Nb);          // 1 KiB pieces per chunk: (operand, block, half of the samples)
+  const char* xbase = reinterpret_cast<const char*>(ws + G.x_off);
+  const char* ybase = reinterpret_cast<const char*>(ws + G.dy_off);
+  // source granule of LDS slot `lane`: sample n0 + (lane >> 2), h = (lane >> 1) & 1, jp = lane & 1
+  const int src_lane = (lane & 1) * 1024 + ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+  auto stage = [&](int ci) {
+    const int t = sg.tile_begin + ci;
+    char* buf = lds + (ci % WB_RING) * WB_CHUNK;
+    const char* xt = xbase + (size_t)t * G.x_tile_stride * 4;
+    const char* yt = ybase + (size_t)t * G.dy_tile_stride * 4;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      int p = wave + 8 * i;
+      p = p < npieces ? p : npieces - 1;      // the tail re-copies the last piece: every wave issues CPW copies
+      const int isy = p >= 2 * Kb;
+      const int pp = isy ? p - 2 * Kb : p;
+      const int b = pp >> 1, half = pp & 1;
+      const char* src = (isy ? yt : xt) + b * 2048 + half * 256 + src_lane;   // half: samples 16..31 = 16 lanes x 16 B further
+      char* dst = buf + (isy ? Kb * 2048 : 0) + b * 2048 + half * 1024;
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_t*)dst, 16, 0, 2);
+    }
+  };
+
+  f32x16 acc[NRB][2];
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
+  float bsum[2] = {0.f, 0.f};
+  const bool want_bias = G.vslab_off >= 0 && kb0 == 0 && active;
+
+  // transposing-read base of this lane inside a block image: group (mhalf, kg) of 16 lanes, lane (r, q) in it
+  const int kg = lane >> 5, mhalf = (lane >> 4) & 1, r4 = (lane >> 2) & 3, q = lane & 3;
+  const int frag_lane = (8 * kg + r4) * 64 + (q & 1) * 32 + (2 * mhalf + (q >> 1)) * 8;
+
+  const int nchunks = sg.tile_end - sg.tile_begin;
+  for (int c = 0; c < WB_RING - 1 && c < nchunks; ++c) stage(c);
+  for (int ci = 0; ci < nchunks; ++ci) {
+    if (ci + WB_RING - 2 <= nchunks - 1) wait_vm<(WB_RING - 2) * CPW>();   // chunk ci has landed, two later ones may fly
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();              // ... for every wave, and nobody still reads the buffer refilled next
+    asm volatile("" ::: "memory");
+    if (ci + WB_RING - 1 < nchunks) stage(ci + WB_RING - 1);
+    if (active) {
+      const char* buf = lds + (ci % WB_RING) * WB_CHUNK + frag_lane;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a[NRB], b[2];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) a[rb] = read_frag(buf + (kb0 + rb) * 2048, ks);
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) b[cb] = read_frag(buf + (Kb + nb0 + cb) * 2048, ks);
+        if (want_bias) { bsum[0] += frag_sum(b[0]); bsum[1] += frag_sum(b[1]); }
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+      }
+    }
+  }
+  if (!active) return;
+  const int j = lane & 31, h = lane >> 5;
+  const int ld = Nb * 32;
+  float* slab = ws + G.slab_off + (size_t)sg.slab_idx * (Kb * 32) * ld;
+#pragma unroll
+  for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int k = 32 * (kb0 + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        slab[(size_t)k * ld + 32 * (nb0 + cb) + j] = acc[rb][cb][reg];
+      }
+  if (want_bias) {   // lanes (n, kg = 0 / 1) hold different samples of column n
+    float* bs = ws + G.vslab_off + (size_t)sg.slab_idx * ld;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const float t = bsum[cb] + __shfl_xor(bsum[cb], 32);
+      if (h == 0) bs[32 * (nb0 + cb) + j] = t;
+    }
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512) void wgrad_bf16_kernel(const WgradGroup* __restrict__ groups, const WgradSegment* __restrict__ segs,
+                                                         const int* __restrict__ seg_begin, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) char wb_lds[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int s0 = seg_begin[blockIdx.x], s1 = seg_begin[blockIdx.x + 1];
+  for (int si = s0; si < s1; ++si) {
+    const WgradSegment sg = segs[si];
+    const WgradGroup G = groups[sg.group];
+    // 8 waves tile the [Kb][Nb] block grid: n-groups of 2 column blocks, the rest along k (as wgrad.hip)
+    const int ngn = G.Nb / 2;            // 1, 2 or 4
+    const int ngk = 8 / ngn;             // 8, 4 or 2
+    const int wn = wave % ngn, wk = wave / ngn;
+    const int nrb = (G.Kb + ngk - 1) / ngk;   // 4, 2 or 1
+    const int kb0 = wk * nrb, nb0 = 2 * wn;
+    const bool active = kb0 < G.Kb;
+    const int cpw = (2 * (G.Kb + G.Nb) + 7) / 8;   // 4, 3 or 2
+    if (nrb == 4)                  wgrad_bf16_body<4, 4>(G, sg, ws, wb_lds, kb0, nb0, active);
+    else if (nrb == 2)             wgrad_bf16_body<2, 3>(G, sg, ws, wb_lds, kb0, nb0, active);
+    else if (cpw == 3)             wgrad_bf16_body<1, 3>(G, sg, ws, wb_lds, kb0, nb0, active);
+    else                           wgrad_bf16_body<1, 2>(G, sg, ws, wb_lds, kb0, nb0, active);
+    __syncthreads();   // the next segment restages LDS
+  }
+}
+
+void launch_wgrad_bf16(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
+                       hipStream_t stream) {
+  const size_t lds = (size_t)WB_RING * WB_CHUNK;
+  (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws);
+}
+
+}  // namespace nrf

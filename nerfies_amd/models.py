@@ -189,12 +189,13 @@ class NerfModel:
     return self._layout
 
   def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0, elastic: bool = False,
-                jacobian: bool = False) -> torch.Tensor:
-    key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic), bool(jacobian))
+                jacobian: bool = False, bf16: bool = False) -> torch.Tensor:
+    bf16 = bool(bf16 and train)   # only the TRAINING layout depends on it (bf16 stash instead of the fp32 one)
+    key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic), bool(jacobian), bf16)
     ws = self._ws.get(key)
     if ws is None:
       nbytes = C.c_size_t(0)
-      flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jacobian else 0)
+      flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jacobian else 0) | (L.NRF_FLAG_BF16 if bf16 else 0)
       L.check(self.lib.nrf_workspace_bytes_ex(self.handle, num_rays, flags,
                                               int(num_background_points), int(bool(elastic)), C.byref(nbytes)), self.lib)
       ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
@@ -320,7 +321,7 @@ class NerfModel:
         setattr(lo, k, _ptr(t))
       ret[name] = d
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
-    ws = self.workspace(B, train, device, jacobian=bool(jac_levels))
+    ws = self.workspace(B, train, device, jacobian=bool(jac_levels), bf16=bf16)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0) | \
         (L.NRF_FLAG_BF16 if bf16 else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jac_levels else 0)
@@ -383,7 +384,7 @@ class NerfModel:
     wr = None
     if warp_reg is not None:
       wr = L.WarpReg(float(warp_reg.get('weight', 0.0)), float(warp_reg.get('alpha', -2.0)), float(warp_reg.get('scale', 0.001)))
-    ws = self.workspace(rays.num_rays, True, device, nbg, el is not None)
+    ws = self.workspace(rays.num_rays, True, device, nbg, el is not None, bf16=bf16)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     L.check(self.lib.nrf_train_step_loss_grad_ex(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
                                                  C.byref(rnd), C.byref(bg) if bg is not None else None,

@@ -97,11 +97,13 @@ def psum_gradients(grad: torch.Tensor, stats: torch.Tensor, fused: Optional[torc
 def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[str, Any],
                scalar_params: ScalarParams, use_elastic_loss: bool = False, elastic_reduce_method: str = 'median',
                elastic_loss_type: str = 'log_svals', use_background_loss: bool = False,
-               use_warp_reg_loss: bool = False, *, rngs: Optional[Dict[str, Any]] = None):
+               use_warp_reg_loss: bool = False, *, rngs: Optional[Dict[str, Any]] = None, bf16: bool = False):
   """One optimisation step (training.py:138-271).  `batch` holds this rank's ray shard
   ('rgb','origins','directions','metadata').  Returns (new_state, stats, rng_key).
   `rngs` (extra, parity runs): explicit uniforms {'coarse': (B,N_c), 'fine': (B,N_f)} instead of the streams derived
-  from `rng_key` (the reference's threefry stream is not reproducible without JAX)."""
+  from `rng_key` (the reference's threefry stream is not reproducible without JAX).  `bf16` (extra, no reference
+  counterpart; BASELINE config D): the NeRF MLPs run forward / dgrad / wgrad on bfloat16 MFMA operands with a bfloat16
+  activation stash; master weights, loss, compositing, the gradient all-reduce and Adam stay float32."""
   if use_elastic_loss and elastic_loss_type not in L.ELASTIC_TYPE:
     raise L.NrfError(f"elastic_loss_type {elastic_loss_type!r} is not built (one of {sorted(L.ELASTIC_TYPE)}; 'nr' produces "
                      'NaNs in the reference itself, training.py:58)')
@@ -120,7 +122,7 @@ def train_step(model: models.NerfModel, rng_key, state: TrainState, batch: Dict[
     background = {'points': pts + noise, 'warp_ids': ids, 'weight': scalar_params.background_loss_weight}
   grad, stats = model.loss_and_grad(opt.target, batch, warp_extra=state.warp_extra,
                                     rngs=rngs if rngs is not None else {'fine': fine_key, 'coarse': coarse_key},
-                                    grad_out=opt.grad, stats_out=opt.stats,
+                                    grad_out=opt.grad, stats_out=opt.stats, bf16=bf16,
                                     background=background,
                                     elastic={'weight': scalar_params.elastic_loss_weight, 'reduce_method': elastic_reduce_method,
                                              'loss_type': elastic_loss_type} if use_elastic_loss else None,

@@ -119,8 +119,33 @@ def annealed_sinusoidal_encode(x: Tensor, num_freqs: int, alpha) -> Tensor:
   return torch.cat([ident, feats], -1)
 
 
+# Test hook on every Dense: None = the reference's arithmetic.  A callable (p, x) -> y lets a test restate a REDUCED-PRECISION
+# mode of the HIP path operand for operand (tests/test_gpu_bf16_train.py: bfloat16 rounding of activations, weights and of
+# the back-propagated pre-activation gradients, exactly where csrc/mlp_bf16.hip rounds them).
+_DENSE_HOOK = None
+
+
+class dense_hook:
+  """with dense_hook(fn): ... -- every dense(p, x) call returns fn(p, x)."""
+
+  def __init__(self, fn):
+    self.fn = fn
+
+  def __enter__(self):
+    global _DENSE_HOOK
+    self.prev, _DENSE_HOOK = _DENSE_HOOK, self.fn
+    return self
+
+  def __exit__(self, *exc):
+    global _DENSE_HOOK
+    _DENSE_HOOK = self.prev
+    return False
+
+
 def dense(p: Dict[str, Tensor], x: Tensor) -> Tensor:
   """flax nn.Dense: y = x @ kernel[in,out] + bias (modules.py:42-58)."""
+  if _DENSE_HOOK is not None:
+    return _DENSE_HOOK(p, x)
   return x @ p['kernel'] + p['bias']
 
 

@@ -1,0 +1,257 @@
+"""bf16 training path (NRF_FLAG_TRAIN | NRF_FLAG_BF16; BASELINE configs[3] "bf16 MLP with fp32 composite"): forward with
+the bf16 stash, bf16 dgrad chain, bf16 wgrad with LDS transpose reads (csrc/mlp_bf16.hip, csrc/wgrad_bf16.hip).
+
+The reference has no reduced-precision mode, so parity is established in two steps:
+  1. against the float64 oracle evaluated with the SAME roundings -- activations and weights rounded to bfloat16 as GEMM
+     operands, the back-propagated pre-activation gradients rounded to bfloat16 before they are used (for dX, dW and db
+     alike), biases / the per-ray condition term / everything outside the MLP exact -- the HIP path must agree per leaf to
+     1e-2 of the leaf's max-abs entry (measured ~1e-3: fp32 vs fp64 accumulation and one-ulp bf16 ties).  This pins the
+     kernels' dataflow (stash layout, masks, transposes) independently of how much bf16 itself costs;
+  2. against the fp32 path on identical rays: what bf16 costs -- loss within 1e-3, every gradient leaf's direction within
+     cos >= 0.99 -- and a short training run: PSNR on held-out rays within 0.1 dB of the fp32 run (SURVEY 8d gate)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from oracle import nerfies_oracle as O  # noqa: E402
+import helpers as H  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+class _RoundFwd(torch.autograd.Function):
+  """x -> bfloat16(x) (RNE), gradient passed through (the master copy is float32)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return x.to(torch.bfloat16).to(x.dtype)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g
+
+
+class _RoundBwd(torch.autograd.Function):
+  """identity whose incoming gradient is rounded to bfloat16 (the dY stash)."""
+
+  @staticmethod
+  def forward(ctx, x):
+    return x.view_as(x)
+
+  @staticmethod
+  def backward(ctx, g):
+    return g.to(torch.bfloat16).to(g.dtype)
+
+
+def bf16_dense_for(spec):
+  """csrc/mlp_bf16.hip's arithmetic of one Dense of the NeRF MLP: bf16 operands (for the rgb hidden layer only the
+  bottleneck columns: the per-ray condition columns are folded into an exact fp32 term by ray_prep), exact bias, dY rounded."""
+  tw, rw = spec.nerf_trunk_width, spec.nerf_rgb_branch_width
+
+  def dense(p, x):
+    w = p['kernel']
+    nq = tw if (w.shape[1] == rw and w.shape[0] > tw and rw != tw) else w.shape[0]
+    y = _RoundFwd.apply(x[..., :nq]) @ _RoundFwd.apply(w[:nq])
+    if nq < w.shape[0]:
+      y = y + x[..., nq:] @ w[nq:]
+    return _RoundBwd.apply(y + p['bias'])
+  return dense
+
+
+def _setup(B, seed=3, **kw):
+  spec = O.ModelSpec(**dict(dict(num_coarse_samples=64, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=True), **kw))
+  p = O.init_params(spec, seed=seed, trained_like=True, dtype=torch.float64)
+  b = O.synthetic_batch(B, seed=seed + 1, dtype=torch.float64)
+  g = torch.Generator().manual_seed(seed + 2)
+  t_rand = torch.rand(B, spec.num_coarse_samples, generator=g).double()
+  u = torch.rand(B, spec.num_fine_samples, generator=g).double()
+  model, fp = H.gpu_model(spec, p, B)
+  rngs = {'coarse': t_rand.float().to(DEV), 'fine': u.float().to(DEV)}
+  return spec, p, b, t_rand, u, model, fp, rngs
+
+
+CASES = [(37, {}), (401, {}), (50, dict(num_nerf_point_freqs=10, use_camera_metadata=True)),
+         (24, dict(nerf_trunk_width=128, nerf_rgb_branch_width=64, num_coarse_samples=32, num_fine_samples=32))]
+
+
+@pytest.mark.parametrize('B,kw', CASES)
+def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
+  """Step 1a: loss, rendered outputs and every stashed activation against the float64 oracle with the same roundings.
+  float32 vs float64 accumulation moves a pre-activation by ~1e-7 relative, which flips the bfloat16 rounding of about
+  one element in 3000 by one ulp (0.4 %), and later layers inherit those: per layer the relative L2 distance stays below
+  5e-3, the largest deviation below 2 % of the layer's scale, at least 95 % of the elements within one ulp."""
+  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, **kw)
+  gb = H.gpu_batch(b)
+  grad, stats = model.loss_and_grad(fp, gb, rngs=rngs, bf16=True)
+  torch.cuda.synchronize()
+  ws = model.workspace(B, True, DEV, bf16=True)
+  S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
+  z_fine = torch.from_numpy(H._ws_words(model, ws, 'z', 1, B * S[1]).view('float32').reshape(B, S[1]).copy()).double()
+  acts = {}
+
+  def record(name, layer, pre):
+    acts[(name, layer)] = H.bf16_round(torch.relu(pre.detach()))
+    return torch.relu(pre)
+  with H.host_threads(64), O.dense_hook(bf16_dense_for(spec)), O.relu_hook(record):
+    loss, ostats, _, ret = O.loss_and_grad(p, spec, b, t_rand=t_rand, u=u, fixed_fine_z=z_fine)
+  assert abs(stats[4].item() - loss.item()) < 5e-5, (stats[4].item(), loss.item())
+  tw, rw = spec.nerf_trunk_width, spec.nerf_rgb_branch_width
+  for lv, name in enumerate(('coarse', 'fine')):
+    rows = B * S[lv]
+    hs = H.bf16_stash(model, ws, 'b_h', lv, 8, 8, rows)
+    rg = H.bf16_stash(model, ws, 'b_rgbh', lv, 1, 4, rows)[0]
+    def close(got, want, what):
+      # one-ulp bf16 ties (float32 vs float64 accumulation, v_sin_f32 vs sin in the posenc) propagate: a unit near its kink
+      # may differ by a multiple of its own value, never by more than a few bf16 ulps of the layer's scale
+      err = (got - want).abs()
+      assert err.max().item() <= 2e-2 * want.abs().max().item(), (what, err.max().item(), want.abs().max().item())
+      assert (err.norm() / want.norm()).item() <= 5e-3, (what, (err.norm() / want.norm()).item())
+      assert ((err > 2.0 ** -7 * want.abs() + 1e-6 * want.abs().max()).float().mean().item()) < 0.05, what
+    for l in range(8):
+      close(hs[l][:, :tw], acts[(f'{name}/MLP_0', l)], (name, l))
+      assert (hs[l][:, tw:] == 0).all()   # padded units of a narrower trunk stay dead
+    close(rg[:, :rw], acts[(f'{name}/MLP_1', 0)], (name, 'rgb hidden'))
+  out = model.apply({'params': fp}, gb, {}, rngs=rngs, return_weights=True, bf16=True)
+  for lv in ('coarse', 'fine'):
+    np.testing.assert_allclose(out[lv]['weights'].cpu().numpy(), ret[lv]['weights'].detach().numpy(), atol=1e-4)
+    np.testing.assert_allclose(out[lv]['rgb'].cpu().numpy(), ret[lv]['rgb'].detach().numpy(), atol=1e-3)
+
+
+@pytest.mark.parametrize('B,kw', CASES)
+def test_bf16_backward_matches_float64_given_the_stash(B, kw):
+  """Step 1b: the dgrad chain and the transposing wgrad kernel against a float64 evaluation of the SAME quantities from
+  the kernels' own forward stash (bfloat16 activations X, bfloat16 d raw, bfloat16 weights, every dpre rounded to
+  bfloat16 before use): all weight / bias gradient leaves to 2e-3 of the leaf's max-abs.  (The end-to-end comparison with
+  the rounded oracle is not used for the gradients: the one-ulp rounding ties of step 1a, harmless in the rendered
+  colour, are amplified by the cancellation inside d sigma = T (c_i - C_behind) to percents of the density gradient.)"""
+  from nerfies_amd import params as P
+  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, **kw)
+  grad, stats = model.loss_and_grad(fp, H.gpu_batch(b), rngs=rngs, bf16=True)
+  torch.cuda.synchronize()
+  ws = model.workspace(B, True, DEV, bf16=True)
+  S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
+  got = P.tree_from_flat(grad.cpu(), model.layout)
+  tw, rw, P_ = spec.nerf_trunk_width, spec.nerf_rgb_branch_width, 3 + 6 * spec.num_nerf_point_freqs
+  q = H.bf16_round
+  worst = ('', 0.0)
+  for lv, name in enumerate(('nerf_mlps_coarse', 'nerf_mlps_fine')):
+    rows = B * S[lv]
+    prm = O.tree_map(lambda t: t.float().double(), p[name])     # the float32 master weights
+    W = lambda path: H.leaf(prm, path)
+    pe = H.bf16_stash(model, ws, 'b_pe', lv, 1, 2, rows)[0][:, :P_]
+    h = H.bf16_stash(model, ws, 'b_h', lv, 8, 8, rows)
+    h = [t[:, :tw] for t in h]
+    bn = H.bf16_stash(model, ws, 'b_bn', lv, 1, 8, rows)[0][:, :tw]
+    rgbh = H.bf16_stash(model, ws, 'b_rgbh', lv, 1, 4, rows)[0][:, :rw]
+    draw = H.bf16_stash(model, ws, 'b_dsmall', lv, 1, 2, rows)[0][:, :4]
+    dlog, dsig = draw[:, :3], draw[:, 3:4]
+    want = {}
+    want['MLP_1/logit/kernel'], want['MLP_1/logit/bias'] = rgbh.T @ dlog, dlog.sum(0)
+    want['MLP_2/logit/kernel'], want['MLP_2/logit/bias'] = h[7].T @ dsig, dsig.sum(0)
+    d = q((dlog @ q(W('MLP_1/logit/kernel')).T) * (rgbh > 0))
+    want['MLP_1/hidden_0/kernel[:tw]'], want['MLP_1/hidden_0/bias'] = bn.T @ d, d.sum(0)
+    d = q(d @ q(W('MLP_1/hidden_0/kernel')[:tw]).T)
+    want['bottleneck/kernel'], want['bottleneck/bias'] = h[7].T @ d, d.sum(0)
+    wa = W('MLP_2/logit/kernel')[:tw]
+    wa = q(wa) + q(wa - q(wa))                                  # the alpha row is a (hi, lo) bfloat16 pair
+    d = q((d @ q(W('bottleneck/kernel')).T + dsig @ wa.T) * (h[7] > 0))
+    for l in range(7, -1, -1):
+      x = h[l - 1] if l > 0 else pe
+      wk = W(f'MLP_0/hidden_{l}/kernel')
+      gk = x.T @ d
+      if l == 4:
+        gk = torch.cat([gk, pe.T @ d], 0)
+      want[f'MLP_0/hidden_{l}/kernel'], want[f'MLP_0/hidden_{l}/bias'] = gk, d.sum(0)
+      if l > 0:
+        d = q((d @ q(wk[:tw]).T) * (h[l - 1] > 0))
+    for path, w in want.items():
+      sl = path.endswith('[:tw]')
+      have = H.leaf(got[name], path.replace('[:tw]', '')).double()
+      have = have[:tw] if sl else have
+      scale = max(w.abs().max().item(), 1e-30)
+      err = (have.reshape(w.shape) - w).abs().max().item() / scale
+      worst = max(worst, (f'{name}/{path}', err), key=lambda t: t[1])
+      assert err < 2e-3, (name, path, err, scale)
+  print(f'[bf16 backward given the stash, B={B}] worst leaf {worst[0]}: {worst[1]:.2e}')
+
+
+def test_bf16_gradient_against_the_fp32_path():
+  from nerfies_amd import params as P
+  B = 128
+  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, seed=9)
+  gb = H.gpu_batch(b)
+  g32, s32 = model.loss_and_grad(fp, gb, rngs=rngs)
+  g32, s32 = g32.clone(), s32.clone()
+  g16, s16 = model.loss_and_grad(fp, gb, rngs=rngs, bf16=True)
+  assert torch.isfinite(g16).all()
+  assert abs(s16[4].item() - s32[4].item()) < 1e-3
+  t32, t16 = P.tree_from_flat(g32.cpu(), model.layout), P.tree_from_flat(g16.cpu(), model.layout)
+  cos_min = 1.0
+  for path, a in O.tree_leaves_with_path(t32):
+    c = torch.nn.functional.cosine_similarity(a.flatten().double(), H.leaf(t16, path).flatten().double(), dim=0).item()
+    cos_min = min(cos_min, c)
+    assert c > 0.99, (path, c)
+  print(f'[bf16 vs fp32 gradients] loss {s16[4].item():.6f} / {s32[4].item():.6f}, min leaf cosine {cos_min:.5f}')
+  # the two training modes share the flat layout / Adam: switching per step is allowed and the fp32 result is unchanged
+  g32b, _ = model.loss_and_grad(fp, gb, rngs=rngs)
+  assert (g32b - g32).abs().max().item() <= 1e-6 * g32.abs().max().item()   # (atomics in the per-ray sums: not bitwise)
+
+
+def _scene_rgb(o, d):
+  """a smooth view-dependent target the network can fit"""
+  return torch.sigmoid(torch.stack([2.0 * torch.sin(3.0 * o[:, 0] + 2.0 * d[:, 1]), 2.0 * torch.cos(2.0 * o[:, 1] - 3.0 * d[:, 2]),
+                                    1.5 * torch.sin(4.0 * o[:, 2] + d[:, 0])], -1))
+
+
+def test_bf16_training_reaches_the_fp32_psnr():
+  """SURVEY 8d gate for the bf16 mode.  400 Adam steps on the same ray stream from the same init, PSNR of the trained
+  models on held-out rays rendered by the fp32 eval path.  Two training runs that differ only in rounding diverge
+  chaotically (two FLOAT32 runs with different stratified-sampling keys end +-0.3 dB apart on this scene), so the gate is
+  one-sided and uses the fp32 spread as its reference: the bf16 run must reach the worse of two fp32 runs minus 0.1 dB,
+  and its loss over the last 100 steps must be within 5 % of theirs."""
+  from nerfies_amd import models, training
+  B, K = 512, 400
+
+  class Cfg:
+    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 32, 64, 6
+    sigma_activation, use_stratified_sampling, use_viewdirs = 'softplus', True, True
+  g = torch.Generator().manual_seed(0)
+  n_train = 64 * B
+  o = (torch.rand(n_train + 4096, 3, generator=g) - 0.5).to(DEV)
+  d = torch.nn.functional.normalize(torch.randn(n_train + 4096, 3, generator=g), dim=-1).to(DEV)
+  rgb = _scene_rgb(o, d)
+  em, _ = models.construct_nerf(7, type('E', (Cfg,), {'use_stratified_sampling': False}), 4096, [0], [0], [0], 0.05, 1.0, device=DEV)
+  test = {'origins': o[n_train:], 'directions': d[n_train:], 'metadata': {}}
+  runs = {}
+  for mode, key0 in (('f32', 1), ('f32b', 1001), ('bf16', 1)):
+    model, fp = models.construct_nerf(7, Cfg, B, [0], [0], [0], 0.05, 1.0, device=DEV)
+    state = training.TrainState(optimizer=training.Optimizer(fp))
+    sp = training.ScalarParams(learning_rate=1e-3)
+    key, losses = key0, []
+    for k in range(K):
+      i0 = (k % 64) * B
+      batch = {'origins': o[i0:i0 + B], 'directions': d[i0:i0 + B], 'rgb': rgb[i0:i0 + B], 'metadata': {}}
+      state, stats, key = training.train_step(model, key, state, batch, sp, bf16=(mode == 'bf16'))
+      losses.append(stats['fine']['loss/rgb'])
+    losses = torch.stack(losses).cpu().numpy()
+    psnr = {}
+    for tag, kw in (('f32', {}), ('bf16', dict(bf16=True))):   # the same weights rendered by both inference modes
+      out = em.apply({'params': fp}, test, {}, **kw)
+      psnr[tag] = -10.0 * np.log10(((out['fine']['rgb'] - rgb[n_train:]) ** 2).mean().item())
+    runs[mode] = (psnr, losses)
+  (pa, la), (pb, lb), (p16, l16) = runs['f32'], runs['f32b'], runs['bf16']
+  print(f'[bf16 training] held-out PSNR: fp32 runs {pa["f32"]:.3f} / {pb["f32"]:.3f} dB, bf16-trained {p16["f32"]:.3f} dB; the same weights '
+        f'rendered with bf16 operands: {pa["bf16"] - pa["f32"]:+.3f} / {p16["bf16"] - p16["f32"]:+.3f} dB; mean loss of the last 100 steps '
+        f'{la[-100:].mean():.5f} / {lb[-100:].mean():.5f} / {l16[-100:].mean():.5f}')
+  assert min(pa['f32'], pb['f32']) > 20.0                       # the scene is learnt at all
+  assert p16['f32'] >= min(pa['f32'], pb['f32']) - 0.1
+  assert l16[-100:].mean() <= 1.05 * max(la[-100:].mean(), lb[-100:].mean())
+  for psnr, _ in runs.values():                                  # inference-mode gate: bf16 rendering of given weights costs < 0.1 dB
+    assert abs(psnr['bf16'] - psnr['f32']) <= 0.1

@@ -27,8 +27,10 @@ import torch.distributed as dist
 RAYS_PER_GPU = 1024
 N_COARSE, N_FINE, POINT_FREQS = 64, 128, 8
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (the opt-in bf16 modes)
+PEAK_HBM_GBS = 8000.0           # HBM3E spec (~6300 achievable)
 # profile name -> kernel symbol in profiles/hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 run)
-TRAFFIC_KERNEL = {'wgrad': 'nrf::wgrad_kernel'}
+TRAFFIC_KERNEL = {'wgrad': 'nrf::wgrad_kernel', 'wgrad_bf16': 'nrf::wgrad_bf16_kernel'}
 
 
 def kernel_source_sha():
@@ -300,10 +302,11 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--burn-in-s', type=float, default=3.0,
                   help='seconds of untimed steps of the same workload before the warm-up + timed steps (steady-state clocks)')
-  ap.add_argument('--mode', default='train', choices=['train', 'eval', 'vrig'],
+  ap.add_argument('--mode', default='train', choices=['train', 'train_bf16', 'eval', 'vrig'],
                   help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
                        '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
-                       'SE3 warp F_w=6 + camera code + elastic + background regularisers)')
+                       'SE3 warp F_w=6 + camera code + elastic + background regularisers); train_bf16: the headline workload with '
+                       'bfloat16 MLP operands and stash (opt-in mode, never the default line; BASELINE configs[3] precision)')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -327,8 +330,9 @@ def main():
   torch.cuda.set_device(dev)
 
   from nerfies_amd import models, training
-  if args.mode != 'train':
+  if args.mode not in ('train', 'train_bf16'):
     return side_mode(args, world, rank, dev)
+  bf16 = args.mode == 'train_bf16'
   model, fp = models.construct_nerf(0, Cfg, RAYS_PER_GPU, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
   state = training.TrainState(optimizer=training.Optimizer(fp))
   sp = training.ScalarParams(learning_rate=1e-3)
@@ -343,7 +347,7 @@ def main():
   box = {'state': state, 'key': key, 'stats': None}
 
   def step():
-    box['state'], box['stats'], box['key'] = training.train_step(model, box['key'], box['state'], batch, sp)
+    box['state'], box['stats'], box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, bf16=bf16)
 
   # untimed burn-in at the same workload (>= --burn-in-s seconds) so the short timed window below sits at steady-state
   # clocks and power; the sampler keeps running through the timed region
@@ -385,7 +389,7 @@ def main():
   model.profile_enable(True)
   prof_steps = max(5, min(args.steps, 20))
   for _ in range(prof_steps):
-    state, stats, key = training.train_step(model, key, state, batch, sp)
+    state, stats, key = training.train_step(model, key, state, batch, sp, bf16=bf16)
   torch.cuda.synchronize()
   prof = model.profile_read()
   model.profile_enable(False)
@@ -402,18 +406,30 @@ def main():
     dom_ms = dom['ms'] / dom['launches']
     achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
     traffic, traffic_src = hbm_traffic(dom['name'])
+    peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
+    roofline = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
+                'frac': achieved / peak_tf, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms,
+                'flops_per_launch': dom['flops_per_launch']}
+    if dom['name'] == 'wgrad_bf16':
+      # HBM-bound: the kernel's algorithmic traffic is both bf16 stashes read once -- per MLP row X = posenc 64 + h1..h8 8x256 +
+      # bottleneck 256 + rgb hidden 128 features, dY = dpre0..7 8x256 + d bottleneck 256 + d rgb hidden 128 + d raw 4, 2 B each
+      rows = RAYS_PER_GPU * (N_COARSE + (N_COARSE + N_FINE))
+      alg_bytes = rows * 2 * ((64 + 8 * 256 + 256 + 128) + (8 * 256 + 256 + 128 + 4))
+      gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
+      roofline = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+                  'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'bytes_per_launch': alg_bytes}
     out = {
         'metric': 'train rays/sec (192 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': 'gpu_quarterhd.gin shape: 1024 rays/GPU x (64+128) samples, F_p=8, warp off, '
-                               'stratified, fwd+MSE+bwd+grad all-reduce+Adam', 'rays_per_gpu': RAYS_PER_GPU,
+                               'stratified, fwd+MSE+bwd+grad all-reduce+Adam' +
+                               (' [opt-in bf16 mode: bfloat16 MLP operands and activation / dY stash; fp32 master weights, '
+                                'posenc, compositing, loss, all-reduce, Adam]' if bf16 else ''), 'rays_per_gpu': RAYS_PER_GPU,
                    'global_batch': world * RAYS_PER_GPU, 'parallelism': f'ray-shard dp{world}'},
-        'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': PEAK_FP32_MFMA_TFLOPS,
-                     'unit': 'TFLOP/s', 'frac': achieved / PEAK_FP32_MFMA_TFLOPS, 'traffic': traffic,
-                     'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']},
+        'roofline': roofline,
         'step_tflops': step_flops / (ms_per_step * 1e-3) / 1e12,
-        'step_frac_of_fp32_mfma_peak': step_flops / (ms_per_step * 1e-3) / 1e12 / (PEAK_FP32_MFMA_TFLOPS * world),
+        ('step_frac_of_bf16_mfma_peak' if bf16 else 'step_frac_of_fp32_mfma_peak'): step_flops / (ms_per_step * 1e-3) / 1e12 / (peak_tf * world),
         'kernels': kernels, 'final_loss_fine': loss,
         'steady_state': {'burn_in_steps': burn_steps, 'burn_in_s': args.burn_in_s, 'timed_window_s': elapsed,
                          'during_timed_window': clocks},

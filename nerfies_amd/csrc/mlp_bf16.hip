@@ -189,6 +189,9 @@ __device__ __forceinline__ void bf_pack(unsigned (&out)[NG][NB][8], const f32x16
 // NB blocks of one group: [b][jp][lane] x 16 B, non-temporal (written once, read by another kernel much later)
 template <int NB>
 __device__ __forceinline__ void bf_store_blocks(uint32_t* group_base, const unsigned (&v)[NB][8], int lane) {
+#ifdef BF_EXP_NOSTORE   // timing attribution only (results are wrong)
+  return;
+#endif
   u32x4v* p = reinterpret_cast<u32x4v*>(group_base) + lane;
 #pragma unroll
   for (int b = 0; b < NB; ++b)
@@ -202,6 +205,9 @@ __device__ __forceinline__ void bf_store_blocks(uint32_t* group_base, const unsi
 // pre > 0 (the sign bit of 0 - pre: +0 and -0 both give 0, as jax's relu gradient does); a v_sub + a v_alignbit per element
 template <int NB>
 __device__ __forceinline__ void bf_signbits(unsigned (&mb)[(NB + 1) / 2], const f32x16 (&acc)[NB]) {
+#ifdef BF_EXP_NOBITS    // timing attribution only (results are wrong)
+  return;
+#endif
 #pragma unroll
   for (int o = 0; o < NB; ++o)
 #pragma unroll
@@ -210,6 +216,9 @@ __device__ __forceinline__ void bf_signbits(unsigned (&mb)[(NB + 1) / 2], const 
 // acc = 0 where the stashed pre-activation was not positive
 template <int NB>
 __device__ __forceinline__ void bf_mask(f32x16 (&acc)[NB], const unsigned (&mb)[(NB + 1) / 2]) {
+#ifdef BF_EXP_NOBITS
+  return;
+#endif
 #pragma unroll
   for (int o = 0; o < NB; ++o)
 #pragma unroll

@@ -501,8 +501,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   // ---- the same stream-K cut for the bf16 groups: HBM-bound, cost = blocks streamed per 32-sample group ----
   std::vector<int> bnsplit(bspecs.size(), 0);
   if (!bspecs.empty()) {
-    const double bc_seg = env_cost("NRF_BCOST_SEG", 24.0);   // opening a segment (pipeline fill + 256 KiB slab flush), in block units
-    auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb); };
+    // measured on config A (scripts/exp_bf16_cost.sh): a chunk costs (Kb + Nb) + 12 block units -- the per-chunk barrier and
+    // HBM latency are worth 24 KiB of streaming -- : wgrad 0.87 ms with a pure byte model, 0.61 ms with this one
+    const double bc_seg = env_cost("NRF_BCOST_SEG", 16.0);   // opening a segment (pipeline fill + 256 KiB slab flush), in block units
+    const double bc_chunk = env_cost("NRF_BCOST_CHUNK", 12.0);   // per-chunk fixed cost (barrier + issue), in block units
+    auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb) + bc_chunk; };
     double total = 0;
     for (auto& sp : bspecs) total += bcost(sp) * p.L[sp.lv].b_ngroups;
     const int nwg = G;

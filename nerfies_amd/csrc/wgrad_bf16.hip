@@ -8,16 +8,19 @@
 // The stash holds, per 32-sample group and 32-feature block, the chain kernels' B operands as they lay in the registers:
 // sample-major, 8 consecutive-K features per lane (nrf_internal.h BfStash).  The contraction here runs over SAMPLES, so both
 // MFMA operands need 8 consecutive samples of one feature per lane -- a 16-bit transpose.  It is done by the LDS:
-//   * global_load_lds copies 16-B granules into an LDS image [sample n (32)][h (2)][j (4)][i (4)] bf16 = 64 B per sample and
-//     block (every lane picks its own source granule, the LDS side is lane-linear: 1 KiB per wave instruction, no registers);
+//   * global_load_lds copies the stash into an LDS image of 64-B chunks, chunk (n4, h, jp) = samples 4 n4 .. 4 n4 + 3 of
+//     sub-block (h, jp) = 64 contiguous bytes of the stash, placed at n4 * 256 + (2 h + jp) * 64.  Four consecutive lanes of a
+//     copy fetch one chunk, i.e. one 64-B request (a first version gathered single 16-B granules into a sample-major image:
+//     every lane a request of its own, the L2 request rate capped the kernel at 3.0 TB/s); the LDS side is lane-linear, 1 KiB
+//     per wave instruction, no registers;
 //   * ds_read_b64_tr_b16 (gfx950) reads it back transposed: within a group of 16 lanes, lane c receives element c & 3 of the
 //     pieces of lanes 4j + (c >> 2), j = 0..3.  With lane (r, q) of a group pointing at piece q of sample r, a lane gets
 //     4 consecutive samples of feature 32 b + (lane & 31): two reads = the 8 K-slots of v_mfma_f32_32x32x16_bf16, for the A
-//     operand (X) and the B operand (dY) alike.  A 32-lane half covers 256 contiguous bytes per read: conflict free.
+//     operand (X) and the B operand (dY) alike.  A 32-lane half reads the four chunks of one n4: 256 bytes, every bank once.
 // Work split: the stream-K tables of the fp32 kernel (nrf_internal.h WgradGroup / WgradSegment, "tile" = one 32-sample
 // group); one workgroup of 8 waves holds a [Kb*32][Nb*32] fp32 partial in registers and flushes it to a slab per segment;
-// reduce_kernel (wgrad.hip) sums the slabs.  Operands arrive through a ring of four 32 KiB LDS buffers, three chunks in
-// flight per CU, one barrier per chunk.
+// reduce_kernel (wgrad.hip) sums the slabs.  Operands arrive through a 128 KiB LDS ring of 4 (8 x 8 blocks) to 10 (narrow groups)
+// chunks, all but one of them in flight, one barrier per chunk.
 #include "nrf_internal.h"
 
 namespace nrf {
@@ -30,8 +33,7 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 namespace {
 
-constexpr int WB_RING = 4;                   // LDS buffers (chunks of one 32-sample group)
-constexpr int WB_CHUNK = 32 * 1024;          // bytes per buffer: up to 16 blocks of 2 KiB (X then dY)
+constexpr int WB_LDS = 128 * 1024;           // operand ring: RING chunks (one 32-sample group each) of (Kb + Nb) x 2 KiB, X then dY
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -55,21 +57,25 @@ __device__ __forceinline__ float frag_sum(const bf16x8& f) {
   return s;
 }
 
-// NRB x 2 output blocks per wave; CPW = global_load_lds instructions per wave and chunk (= ceil(2 (Kb + Nb) / 8))
-template <int NRB, int CPW>
+// NRB x 2 output blocks per wave; CPW = global_load_lds instructions per wave and chunk (= ceil(2 (Kb + Nb) / 8)); RING =
+// chunks the LDS ring holds (128 KiB / chunk bytes: the BYTES in flight per CU stay the same for narrow groups, whose
+// chunks would otherwise be latency-bound: 2.2 us per chunk whatever its size)
+template <int NRB, int CPW, int RING>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const WgradSegment& sg, float* ws, char* lds, int kb0, int nb0,
                                                 bool active) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Kb = G.Kb, Nb = G.Nb;
   const int npieces = 2 * (Kb + Nb);          // 1 KiB pieces per chunk: (operand, block, half of the samples)
+  const int chunk_bytes = (Kb + Nb) * 2048;
   const char* xbase = reinterpret_cast<const char*>(ws + G.x_off);
   const char* ybase = reinterpret_cast<const char*>(ws + G.dy_off);
-  // source granule of LDS slot `lane`: sample n0 + (lane >> 2), h = (lane >> 1) & 1, jp = lane & 1
-  const int src_lane = (lane & 1) * 1024 + ((lane >> 2) + 32 * ((lane >> 1) & 1)) * 16;
+  // source granule of LDS slot `lane` of a 1 KiB piece (16 samples): n = n0 + 4 (lane >> 4) + (lane & 3), h = (lane >> 3) & 1,
+  // jp = (lane >> 2) & 1; stash granule (n, h, jp) of a block sits at jp * 1024 + (n + 32 h) * 16
+  const int src_lane = ((lane >> 2) & 1) * 1024 + (4 * (lane >> 4) + (lane & 3) + 32 * ((lane >> 3) & 1)) * 16;
   auto stage = [&](int ci) {
     const int t = sg.tile_begin + ci;
-    char* buf = lds + (ci % WB_RING) * WB_CHUNK;
+    char* buf = lds + (ci % RING) * chunk_bytes;
     const char* xt = xbase + (size_t)t * G.x_tile_stride * 4;
     const char* yt = ybase + (size_t)t * G.dy_tile_stride * 4;
 #pragma unroll
@@ -97,18 +103,20 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
 
   // transposing-read base of this lane inside a block image: group (mhalf, kg) of 16 lanes, lane (r, q) in it
   const int kg = lane >> 5, mhalf = (lane >> 4) & 1, r4 = (lane >> 2) & 3, q = lane & 3;
-  const int frag_lane = (8 * kg + r4) * 64 + (q & 1) * 32 + (2 * mhalf + (q >> 1)) * 8;
+  // piece q of sample 8 kg + r4 (+ 4 for the second read): h' = q & 1, j' = 2 mhalf + (q >> 1)  ->  chunk (n4 = 2 kg, h', jp = mhalf),
+  // sample r4 of it, half jj = q >> 1
+  const int frag_lane = (2 * kg) * 256 + (2 * (q & 1) + mhalf) * 64 + r4 * 16 + (q >> 1) * 8;
 
   const int nchunks = sg.tile_end - sg.tile_begin;
-  for (int c = 0; c < WB_RING - 1 && c < nchunks; ++c) stage(c);
+  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage(c);
   for (int ci = 0; ci < nchunks; ++ci) {
-    if (ci + WB_RING - 2 <= nchunks - 1) wait_vm<(WB_RING - 2) * CPW>();   // chunk ci has landed, two later ones may fly
+    if (ci + RING - 2 <= nchunks - 1) wait_vm<(RING - 2) * CPW>();   // chunk ci has landed, RING - 2 later ones may fly
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();              // ... for every wave, and nobody still reads the buffer refilled next
     asm volatile("" ::: "memory");
-    if (ci + WB_RING - 1 < nchunks) stage(ci + WB_RING - 1);
+    if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
     if (active) {
-      const char* buf = lds + (ci % WB_RING) * WB_CHUNK + frag_lane;
+      const char* buf = lds + (ci % RING) * chunk_bytes + frag_lane;
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 a[NRB], b[2];
@@ -165,17 +173,17 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const WgradGroup* __res
     const int kb0 = wk * nrb, nb0 = 2 * wn;
     const bool active = kb0 < G.Kb;
     const int cpw = (2 * (G.Kb + G.Nb) + 7) / 8;   // 4, 3 or 2
-    if (nrb == 4)                  wgrad_bf16_body<4, 4>(G, sg, ws, wb_lds, kb0, nb0, active);
-    else if (nrb == 2)             wgrad_bf16_body<2, 3>(G, sg, ws, wb_lds, kb0, nb0, active);
-    else if (cpw == 3)             wgrad_bf16_body<1, 3>(G, sg, ws, wb_lds, kb0, nb0, active);
-    else                           wgrad_bf16_body<1, 2>(G, sg, ws, wb_lds, kb0, nb0, active);
+    if (nrb == 4)                  wgrad_bf16_body<4, 4, 4>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 8 blocks: 32 KiB chunks
+    else if (nrb == 2)             wgrad_bf16_body<2, 3, 5>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 4: 24 KiB
+    else if (cpw == 3)             wgrad_bf16_body<1, 3, 6>(G, sg, ws, wb_lds, kb0, nb0, active);    // 2 x 8, 8 x 2: 20 KiB
+    else                           wgrad_bf16_body<1, 2, 10>(G, sg, ws, wb_lds, kb0, nb0, active);   // 4 x 2: 12 KiB
     __syncthreads();   // the next segment restages LDS
   }
 }
 
 void launch_wgrad_bf16(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                        hipStream_t stream) {
-  const size_t lds = (size_t)WB_RING * WB_CHUNK;
+  const size_t lds = (size_t)WB_LDS;
   (void)hipFuncSetAttribute((const void*)wgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws);
 }

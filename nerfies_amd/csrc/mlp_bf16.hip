@@ -73,19 +73,9 @@ __device__ __forceinline__ void bf_dma(const char* src_lane, int off, char* lds,
 }
 
 template <int K>
-__device__ __forceinline__ void bf_wait_vm() {   // s_waitcnt vmcnt(K), K a compile-time constant <= 15 here
+__device__ __forceinline__ void bf_wait_vm() {   // s_waitcnt vmcnt(K), K a compile-time constant
   static_assert(K >= 0 && K <= 15, "vmcnt immediate");
-  if constexpr (K == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (K == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (K == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (K == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (K == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (K == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-  else if constexpr (K == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (K == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-  else if constexpr (K == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-  else if constexpr (K == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else static_assert(K == 0, "add the immediate");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
 }
 
 // acc[g][o] = sum over the NIN input blocks (+ bias), both sample groups.  Chunk 0 carries the bias k-step first when
@@ -420,9 +410,11 @@ namespace {
 //   G2  rgbh^T    K = 128 -> 256:                                          2 x DG
 //   G3  bn^T      K = 256 -> 256, first chunk carries the alpha row:      DG3, 3 x DG
 //   L7..L1        K = 256 -> 256:                                          4 x DG each
-constexpr int DG1 = 16 * KB, DG = 32 * KB, DG3 = 40 * KB;
+//   warp on, after L1:  P0  W0^T   K = 256 -> 64 (d posenc through layer 0),  P4  W4[256:]^T  K = 256 -> 64 (skip rows):  4 x DP each
+constexpr int DG1 = 16 * KB, DG = 32 * KB, DG3 = 40 * KB, DP = 8 * KB;
 }  // namespace
 
+template <bool DPTS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_bwd_bf16_kernel(const ChainBwdBf16Args A) {
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   constexpr int NW = 8;
@@ -494,21 +486,71 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll 1
     for (int l = TRUNK_DEPTH - 1; l >= 1; --l) {
       f32x16 acc[1][8];
-      if (l > 1) bf_gemm<1, NW, 8, 8, false, DG, DG>(acc, dy, st, bf_lds, lane, wave);
-      else       bf_gemm<1, NW, 8, 8, false, DG1, DG, true>(acc, dy, st, bf_lds, lane, wave);   // then the stream restarts: G1, G2
+      if (l > 1)      bf_gemm<1, NW, 8, 8, false, DG, DG>(acc, dy, st, bf_lds, lane, wave);
+      else if (DPTS)  bf_gemm<1, NW, 8, 8, false, DP, DP>(acc, dy, st, bf_lds, lane, wave);          // then the d posenc GEMMs
+      else            bf_gemm<1, NW, 8, 8, false, DG1, DG, true>(acc, dy, st, bf_lds, lane, wave);   // then the stream restarts: G1, G2
       const u32x4v mq = bits_of(l - 1);
       const unsigned mb[4] = {mq.x, mq.y, mq.z, mq.w};
       bf_mask<8>(acc[0], mb);
       bf_pack<1, 8, false>(dy, acc);
       bf_store_blocks<8>(S.dy + ((size_t)(l - 1) * S.ngroups + gidx) * 8 * BF_BLOCK_DW, dy[0], lane);
     }
+    // ---- warp on: d posenc = W0 . dpre_0 + W4[256:] . dpre_4 (two 256 -> 64 GEMMs), chain rule through SinusoidalEncoder
+    //      (modules.py:213-228) -> d points, float32, for the warp field's backward ----
+    if constexpr (DPTS) {
+      f32x16 ape[1][2];
+      bf_gemm<1, NW, 8, 2, false, DP, DP>(ape, dy, st, bf_lds, lane, wave);   // dy = dpre_0
+      {   // dpre_4 back from its stash (stored four GEMMs ago by this wave; every vmcnt wait since has retired it)
+        const u32x4v* src = reinterpret_cast<const u32x4v*>(S.dy + ((size_t)SKIP_LAYER * S.ngroups + gidx) * 8 * BF_BLOCK_DW) + lane;
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+          for (int jp = 0; jp < 2; ++jp) {
+            const u32x4v q = src[(b * 2 + jp) * 64];
+            dy[0][b][4 * jp] = q.x; dy[0][b][4 * jp + 1] = q.y; dy[0][b][4 * jp + 2] = q.z; dy[0][b][4 * jp + 3] = q.w;
+          }
+      }
+      bf_gemm<1, NW, 8, 2, false, DG1, DG, true, false>(ape, dy, st, bf_lds, lane, wave);   // += ; then the stream restarts
+      const int r = row < A.rows ? row : A.rows - 1;
+      const float x[3] = {A.points[3 * r], A.points[3 * r + 1], A.points[3 * r + 2]};
+      const float half_pi = 1.57079632679489661923f;
+      float dx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int e = 32 * o + 8 * (rr >> 2) + 4 * h + (rr & 3);   // posenc feature of this accumulator register
+          const float g = ape[0][o][rr];
+          if (e < 3) {
+            dx[0] += e == 0 ? g : 0.f; dx[1] += e == 1 ? g : 0.f; dx[2] += e == 2 ? g : 0.f;
+          } else if (e < A.P) {
+            const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, c = rem >= 3 ? rem - 3 : rem;
+            const float fr = (float)(1 << f);
+            const float a = __fmul_rn(c == 0 ? x[0] : c == 1 ? x[1] : x[2], fr);
+            // d sin(a) = fr cos(a) = fr sin(a + pi/2);  d sin(a + pi/2) = fr sin(a + pi)
+            const float dv = fr * __sinf(rem >= 3 ? __fadd_rn(a, 2.f * half_pi) : __fadd_rn(a, half_pi)) * g;
+            dx[0] += c == 0 ? dv : 0.f; dx[1] += c == 1 ? dv : 0.f; dx[2] += c == 2 ? dv : 0.f;
+          }
+        }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dx[c] += __shfl_xor(dx[c], 32);   // the two lane halves hold different features of the sample
+      if (h == 0 && row < A.rows_pad) {
+        float* o = A.d_points + (size_t)row * 3;
+        o[0] = dx[0]; o[1] = dx[1]; o[2] = dx[2];
+      }
+    }
   }
 }
 
 void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stream) {
   const size_t lds = 3 * BF_BUF_BYTES;
-  (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel, dim3(grid), dim3(512), lds, stream, a);
+  if (a.d_points) {
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<true>, dim3(grid), dim3(512), lds, stream, a);
+  } else {
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<false>, dim3(grid), dim3(512), lds, stream, a);
+  }
 }
 
 // dray[ray][f] = sum over the ray's samples of dpre_rgbh[sample][f]  (gradient of the per-ray rgb-condition term), read back

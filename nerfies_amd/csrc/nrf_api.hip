@@ -591,12 +591,16 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       if (bft) {
         // dgrad stream (nerf_mlp_bwd_bf16_kernel): A = W as stored, [m = the layer's input feature][k = its output feature];
         // gemm(leaf, ld, row0, valid K, valid M, K blocks, M blocks, bias leaf)
-        p.L[lv].bf_wpkT = take((size_t)(16 + 64 + 8 + 128 + 7 * 128 + 64) * 256);
+        p.L[lv].bf_wpkT = take((size_t)(16 + 64 + 8 + 128 + 7 * 128 + 2 * 32 + 64) * 256);
         base = p.L[lv].bf_wpkT; at = 0; tr = 1;
         gemm(po.logit_k, 3, 0, 3, RGB_W, 2, 4, -1);                        // G1: K padded to one 4-k-step chunk (3 valid)
         gemm(po.rgbh_k, RGB_W, 0, RGB_W, TRUNK_W, 4, 8, -1);               // G2: rows 0..255 of [256+R, 128]
         gemm(po.bn_k, TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, po.alpha_k);     // G3: + the alpha row (w_alpha as the "bias")
         for (int l = TRUNK_DEPTH - 1; l >= 1; --l) gemm(po.trunk_k[l], TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, -1);
+        if (h->warp) {   // d posenc: W0 and the skip layer's posenc rows as A [m = posenc feature (P valid)][k = output feature]
+          gemm(po.trunk_k[0], TRUNK_W, 0, TRUNK_W, h->P, 8, 2, -1);
+          gemm(po.trunk_k[d.nerf_skip_layer], TRUNK_W, TRUNK_W, TRUNK_W, h->P, 8, 2, -1);
+        }
       }
     }
     p.bf_desc = take(p.bfpack.size() * sizeof(RcPackDesc) / 4 + 16);
@@ -1046,8 +1050,6 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   const bool warp_on = h->warp && !(flags & NRF_FLAG_NO_WARP);   // models.py:296 use_warp argument
   if (warp_on && !scalars) return fail(NRF_E_NULL, "nrf_step_scalars (warp_alpha) required with the warp field");
   if (h->warp && !warp_on && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
-  if ((flags & NRF_FLAG_BF16) && train && h->warp)
-    return fail(NRF_E_UNSUPPORTED, "bf16 training is built for the canonical NeRF (use_warp off): the bf16 dgrad does not yet return d points");
   if ((flags & NRF_FLAG_BF16) && h->A > 0) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is not built for use_alpha_condition");
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
   const bool encoded = rays->warp_codes || rays->appearance_codes || rays->camera_codes;
@@ -1209,8 +1211,12 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       memset(&ba, 0, sizeof(ba));
       ba.wpk = ws + L.bf_wpkT; ba.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
       ba.S = p.S[lv]; ba.B = B; ba.rows = p.rows[lv]; ba.st = bf_stash(p, lv, ws);
+      if (warp_on) {
+        ba.points = ws + L.wpoints; ba.d_points = ws + L.d_points; ba.rows_pad = p.ntiles[lv] * TILE_ROWS;
+        ba.F = d.num_nerf_point_freqs; ba.P = h->P;
+      }
       const int nit = (p.rows[lv] + 255) / 256;
-      h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, false) * p.rows[lv], stream);
+      h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
       launch_chain_bwd_bf16(ba, nit < h->num_cus ? nit : h->num_cus, stream);
       h->prof.end(stream);
       launch_dray_bf16(ba.st.drgbh, B, p.S[lv], ws + L.dray, stream);

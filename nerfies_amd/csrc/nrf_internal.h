@@ -124,6 +124,10 @@ struct ChainBwdBf16Args {
   const float4* d_raw4;      // [rows_pad] dL/d(raw rgb, raw sigma); 0 on pad rows
   int S, B, rows;
   BfStash st;
+  // warp on: gradient w.r.t. the (warped) sample points through both posenc inputs of the trunk (float32, for the warp kernels)
+  const float* points;       // [rows][3] the points the forward encoded, or nullptr
+  float* d_points;           // [rows_pad][3]
+  int rows_pad, F, P;
 };
 void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stream);
 // per-ray sums of dpre_rgbh from its bf16 stash -> dray [B][128] (gradient of the rgb-condition columns)

@@ -322,6 +322,8 @@ class NerfModel:
       ret[name] = d
     scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
     ws = self.workspace(B, train, device, jacobian=bool(jac_levels), bf16=bf16)
+    if train:
+      self._train_ws = ws   # the stash `backward` differentiates (fp32 or bf16 layout)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0) | \
         (L.NRF_FLAG_BF16 if bf16 else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jac_levels else 0)
@@ -338,7 +340,9 @@ class NerfModel:
     grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
     dc = None if d_rgb_coarse is None else _f32(d_rgb_coarse, device)
     df = None if d_rgb_fine is None else _f32(d_rgb_fine, device)
-    ws = self.workspace(rays.num_rays, True, device)
+    ws = getattr(self, '_train_ws', None)
+    if ws is None:
+      ws = self.workspace(rays.num_rays, True, device)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     L.check(self.lib.nrf_backward(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(dc), _ptr(df), _ptr(grad), _ptr(ws),
                                   ws.numel() * 4, stream), self.lib)

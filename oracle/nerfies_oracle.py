@@ -123,6 +123,7 @@ def annealed_sinusoidal_encode(x: Tensor, num_freqs: int, alpha) -> Tensor:
 # mode of the HIP path operand for operand (tests/test_gpu_bf16_train.py: bfloat16 rounding of activations, weights and of
 # the back-propagated pre-activation gradients, exactly where csrc/mlp_bf16.hip rounds them).
 _DENSE_HOOK = None
+_SCOPE = None   # 'nerf_mlp' while nerf_mlp() runs: lets a dense hook tell the NeRF MLPs from the warp field's
 
 
 class dense_hook:
@@ -197,6 +198,7 @@ def nerf_mlp(p: Dict[str, Any], x: Tensor, alpha_condition: Optional[Tensor],
   Flax auto-names: MLP_0 = trunk, MLP_1 = rgb branch, MLP_2 = alpha branch
   (construction order modules.py:124-140).
   """
+  global _SCOPE
   B, S, _ = x.shape
   x = x.reshape(B * S, -1)
 
@@ -204,15 +206,19 @@ def nerf_mlp(p: Dict[str, Any], x: Tensor, alpha_condition: Optional[Tensor],
     return c[:, None, :].expand(B, S, c.shape[-1]).reshape(B * S, -1)
 
   sub = (lambda k: None) if name is None else (lambda k: f'{name}/{k}')
-  h = mlp(p['MLP_0'], x, cfg.nerf_trunk_depth, cfg.nerf_skips, False, sub('MLP_0'))
-  if alpha_condition is not None or rgb_condition is not None:
-    bottleneck = dense(p['bottleneck'], h)
-  alpha_in = (torch.cat([bottleneck, bcast(alpha_condition)], -1)
-              if alpha_condition is not None else h)
-  alpha = mlp(p['MLP_2'], alpha_in, 0, (), True)
-  rgb_in = (torch.cat([bottleneck, bcast(rgb_condition)], -1)
-            if rgb_condition is not None else h)
-  rgb = mlp(p['MLP_1'], rgb_in, cfg.nerf_rgb_branch_depth, (), True, sub('MLP_1'))
+  prev, _SCOPE = _SCOPE, 'nerf_mlp'
+  try:
+    h = mlp(p['MLP_0'], x, cfg.nerf_trunk_depth, cfg.nerf_skips, False, sub('MLP_0'))
+    if alpha_condition is not None or rgb_condition is not None:
+      bottleneck = dense(p['bottleneck'], h)
+    alpha_in = (torch.cat([bottleneck, bcast(alpha_condition)], -1)
+                if alpha_condition is not None else h)
+    alpha = mlp(p['MLP_2'], alpha_in, 0, (), True)
+    rgb_in = (torch.cat([bottleneck, bcast(rgb_condition)], -1)
+              if rgb_condition is not None else h)
+    rgb = mlp(p['MLP_1'], rgb_in, cfg.nerf_rgb_branch_depth, (), True, sub('MLP_1'))
+  finally:
+    _SCOPE = prev
   return rgb.reshape(B, S, -1), alpha.reshape(B, S, -1)
 
 

@@ -1,7 +1,8 @@
 """NRF_FLAG_BF16 inference mode (mlp_bf16.hip): bfloat16 MLP operands, fp32 accumulation and compositing.  There is no
 reference counterpart (BASELINE config D names it as a new-framework option), so the checks are (a) against the fp64
 oracle and the fp32 HIP path at bf16-sized tolerances, (b) against the oracle run on bf16-ROUNDED weights, which isolates
-the kernel's own arithmetic from the weight quantisation, (c) structural: ragged sizes, the training flag is refused."""
+the kernel's own arithmetic from the weight quantisation, (c) structural: ragged sizes, the training flag (the bf16
+training path proper: tests/test_gpu_bf16_train.py)."""
 import numpy as np
 import pytest
 import torch
@@ -54,11 +55,21 @@ def test_bf16_kernel_arithmetic_is_exact_up_to_activation_rounding():
   assert err_q < 1e-2 and err_q <= err + 2e-3, (err_q, err)
 
 
-def test_bf16_is_inference_only_and_composes_with_the_renderer():
+def test_bf16_composes_with_training_and_the_renderer():
   from nerfies_amd import evaluation, lib as L, training
   spec, model, fp, gb, _, _ = _setup(70)
-  with pytest.raises(L.NrfError):
-    model.apply({'params': fp}, gb, {}, train=True, bf16=True)
+  # the training flag keeps the bf16 stash (tests/test_gpu_bf16_train.py): same forward arithmetic, and nrf_backward follows
+  tr = model.apply({'params': fp}, gb, {}, train=True, bf16=True)
+  inf = model.apply({'params': fp}, gb, {}, bf16=True)
+  for lv in ('coarse', 'fine'):
+    np.testing.assert_allclose(tr[lv]['rgb'].cpu().numpy(), inf[lv]['rgb'].cpu().numpy(), atol=1e-6)
+  tr = model.apply({'params': fp}, gb, {}, train=True, bf16=True)
+  d = torch.full_like(tr['fine']['rgb'], 0.01)
+  g16 = model.backward({'params': fp}, gb, d, d).clone()
+  model.apply({'params': fp}, gb, {}, train=True)
+  g32 = model.backward({'params': fp}, gb, d, d)
+  assert torch.isfinite(g16).all()
+  assert torch.nn.functional.cosine_similarity(g16, g32, dim=0).item() > 0.99
   rays = {'origins': gb['origins'].reshape(7, 10, 3), 'directions': gb['directions'].reshape(7, 10, 3)}
   state = training.TrainState(optimizer=training.Optimizer(fp))
   img = evaluation.render_image(state, rays, evaluation.GraphedChunkRenderer(model, bf16=True), 1, 0, chunk=32)

@@ -57,6 +57,8 @@ def bf16_dense_for(spec):
 
   def dense(p, x):
     w = p['kernel']
+    if O._SCOPE != 'nerf_mlp':   # the warp field stays float32 in the bf16 mode
+      return x @ w + p['bias']
     nq = tw if (w.shape[1] == rw and w.shape[0] > tw and rw != tw) else w.shape[0]
     y = _RoundFwd.apply(x[..., :nq]) @ _RoundFwd.apply(w[:nq])
     if nq < w.shape[0]:
@@ -78,7 +80,10 @@ def _setup(B, seed=3, **kw):
 
 
 CASES = [(37, {}), (401, {}), (50, dict(num_nerf_point_freqs=10, use_camera_metadata=True)),
-         (24, dict(nerf_trunk_width=128, nerf_rgb_branch_width=64, num_coarse_samples=32, num_fine_samples=32))]
+         (24, dict(nerf_trunk_width=128, nerf_rgb_branch_width=64, num_coarse_samples=32, num_fine_samples=32)),
+         (45, dict(use_warp=True, num_warp_freqs=6, use_camera_metadata=True, num_coarse_samples=48, num_fine_samples=48)),
+         (21, dict(use_warp=True, num_nerf_point_freqs=10, num_coarse_samples=32, num_fine_samples=32))]
+WARP_ALPHA = 4.0
 
 
 @pytest.mark.parametrize('B,kw', CASES)
@@ -89,7 +94,7 @@ def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
   5e-3, the largest deviation below 2 % of the layer's scale, at least 95 % of the elements within one ulp."""
   spec, p, b, t_rand, u, model, fp, rngs = _setup(B, **kw)
   gb = H.gpu_batch(b)
-  grad, stats = model.loss_and_grad(fp, gb, rngs=rngs, bf16=True)
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=True)
   torch.cuda.synchronize()
   ws = model.workspace(B, True, DEV, bf16=True)
   S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
@@ -100,7 +105,7 @@ def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
     acts[(name, layer)] = H.bf16_round(torch.relu(pre.detach()))
     return torch.relu(pre)
   with H.host_threads(64), O.dense_hook(bf16_dense_for(spec)), O.relu_hook(record):
-    loss, ostats, _, ret = O.loss_and_grad(p, spec, b, t_rand=t_rand, u=u, fixed_fine_z=z_fine)
+    loss, ostats, _, ret = O.loss_and_grad(p, spec, b, warp_alpha=WARP_ALPHA, t_rand=t_rand, u=u, fixed_fine_z=z_fine)
   assert abs(stats[4].item() - loss.item()) < 5e-5, (stats[4].item(), loss.item())
   tw, rw = spec.nerf_trunk_width, spec.nerf_rgb_branch_width
   for lv, name in enumerate(('coarse', 'fine')):
@@ -118,7 +123,7 @@ def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
       close(hs[l][:, :tw], acts[(f'{name}/MLP_0', l)], (name, l))
       assert (hs[l][:, tw:] == 0).all()   # padded units of a narrower trunk stay dead
     close(rg[:, :rw], acts[(f'{name}/MLP_1', 0)], (name, 'rgb hidden'))
-  out = model.apply({'params': fp}, gb, {}, rngs=rngs, return_weights=True, bf16=True)
+  out = model.apply({'params': fp}, gb, {'alpha': WARP_ALPHA}, rngs=rngs, return_weights=True, bf16=True)
   for lv in ('coarse', 'fine'):
     np.testing.assert_allclose(out[lv]['weights'].cpu().numpy(), ret[lv]['weights'].detach().numpy(), atol=1e-4)
     np.testing.assert_allclose(out[lv]['rgb'].cpu().numpy(), ret[lv]['rgb'].detach().numpy(), atol=1e-3)
@@ -134,7 +139,7 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
   colour, are amplified by the cancellation inside d sigma = T (c_i - C_behind) to percents of the density gradient.)"""
   from nerfies_amd import params as P
   spec, p, b, t_rand, u, model, fp, rngs = _setup(B, **kw)
-  grad, stats = model.loss_and_grad(fp, H.gpu_batch(b), rngs=rngs, bf16=True)
+  grad, stats = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=True)
   torch.cuda.synchronize()
   ws = model.workspace(B, True, DEV, bf16=True)
   S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
@@ -163,7 +168,9 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
     wa = W('MLP_2/logit/kernel')[:tw]
     wa = q(wa) + q(wa - q(wa))                                  # the alpha row is a (hi, lo) bfloat16 pair
     d = q((d @ q(W('bottleneck/kernel')).T + dsig @ wa.T) * (h[7] > 0))
+    dpre = {}
     for l in range(7, -1, -1):
+      dpre[l] = d
       x = h[l - 1] if l > 0 else pe
       wk = W(f'MLP_0/hidden_{l}/kernel')
       gk = x.T @ d
@@ -180,17 +187,33 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
       err = (have.reshape(w.shape) - w).abs().max().item() / scale
       worst = max(worst, (f'{name}/{path}', err), key=lambda t: t[1])
       assert err < 5e-3, (name, path, err, scale)
+    if spec.use_warp:   # d points = chain rule of the posenc applied to d posenc = dpre_0 . W0^T + dpre_4 . W4[256:]^T
+      rows_pad = (rows + 63) // 64 * 64
+      x = torch.from_numpy(H._ws_words(model, ws, 'wpoints', lv, rows_pad * 3).view('float32').reshape(rows_pad, 3)[:rows].copy()).double()
+      have = torch.from_numpy(H._ws_words(model, ws, 'd_points', lv, rows_pad * 3).view('float32').reshape(rows_pad, 3)[:rows].copy()).double()
+      dpe = dpre[0] @ q(W('MLP_0/hidden_0/kernel')).T + dpre[4] @ q(W('MLP_0/hidden_4/kernel')[tw:]).T
+      dx = dpe[:, :3].clone()
+      for f in range(spec.num_nerf_point_freqs):
+        a = (x.float() * float(2 ** f)).double()
+        dx += 2.0 ** f * (torch.cos(a) * dpe[:, 3 + 6 * f:6 + 6 * f] - torch.sin(a) * dpe[:, 6 + 6 * f:9 + 6 * f])
+      err = (have - dx).abs().max().item() / dx.abs().max().item()
+      worst = max(worst, (f'{name}/d_points', err), key=lambda t: t[1])
+      assert err < 5e-3, (name, 'd_points', err)
   print(f'[bf16 backward given the stash, B={B}] worst leaf {worst[0]}: {worst[1]:.2e}')
 
 
-def test_bf16_gradient_against_the_fp32_path():
+@pytest.mark.parametrize('kw,cos_floor', [({}, 0.99), (dict(use_warp=True, num_warp_freqs=6), 0.97)])
+def test_bf16_gradient_against_the_fp32_path(kw, cos_floor):
   from nerfies_amd import params as P
   B = 128
-  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, seed=9)
+  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, seed=9, **kw)
   gb = H.gpu_batch(b)
-  g32, s32 = model.loss_and_grad(fp, gb, rngs=rngs)
+  extra = dict(warp_extra={'alpha': WARP_ALPHA}, rngs=rngs)
+  if kw:   # the regularisers run on the float32 warp kernels whatever the MLP mode
+    extra['elastic'] = {'weight': 0.01, 'reduce_method': 'weight'}
+  g32, s32 = model.loss_and_grad(fp, gb, **extra)
   g32, s32 = g32.clone(), s32.clone()
-  g16, s16 = model.loss_and_grad(fp, gb, rngs=rngs, bf16=True)
+  g16, s16 = model.loss_and_grad(fp, gb, bf16=True, **extra)
   assert torch.isfinite(g16).all()
   assert abs(s16[4].item() - s32[4].item()) < 1e-3
   t32, t16 = P.tree_from_flat(g32.cpu(), model.layout), P.tree_from_flat(g16.cpu(), model.layout)
@@ -198,10 +221,10 @@ def test_bf16_gradient_against_the_fp32_path():
   for path, a in O.tree_leaves_with_path(t32):
     c = torch.nn.functional.cosine_similarity(a.flatten().double(), H.leaf(t16, path).flatten().double(), dim=0).item()
     cos_min = min(cos_min, c)
-    assert c > 0.99, (path, c)
-  print(f'[bf16 vs fp32 gradients] loss {s16[4].item():.6f} / {s32[4].item():.6f}, min leaf cosine {cos_min:.5f}')
+    assert c > cos_floor, (path, c)
+  print(f'[bf16 vs fp32 gradients {kw}] loss {s16[4].item():.6f} / {s32[4].item():.6f}, min leaf cosine {cos_min:.5f}')
   # the two training modes share the flat layout / Adam: switching per step is allowed and the fp32 result is unchanged
-  g32b, _ = model.loss_and_grad(fp, gb, rngs=rngs)
+  g32b, _ = model.loss_and_grad(fp, gb, **extra)
   assert (g32b - g32).abs().max().item() <= 1e-6 * g32.abs().max().item()   # (atomics in the per-ray sums: not bitwise)
 
 

@@ -162,6 +162,21 @@ __device__ __forceinline__ int next_tile(int* __restrict__ counter, int* slot, i
   return t;
 }
 
+// Static but UNEVEN split (k_old > 0): the grid is two workgroups per CU; workgroup b < C = gridDim / 2 (dispatched first: the
+// "older" one of its CU, which wins the MFMA arbitration) takes k_old of the K = ceil(ntiles / C) tiles c + k C of CU slot
+// c = b mod C, the younger one the rest -- both then finish together instead of the older one leaving the younger alone
+// for the last ~12 % of the kernel.  k_old = 0: the even round-robin split.
+struct TileIter { int first, step, end; };
+__device__ __forceinline__ TileIter tile_iter(int ntiles, int k_old) {
+  if (k_old <= 0) return {(int)blockIdx.x, (int)gridDim.x, ntiles};
+  const int C = gridDim.x >> 1, c = blockIdx.x % C;
+  const bool old = (int)blockIdx.x < C;
+  const int K = (ntiles + C - 1) / C;
+  const int k0 = old ? 0 : k_old, k1 = old ? k_old : K;
+  const int end = k1 * C < ntiles ? k1 * C : ntiles;
+  return {c + k0 * C, C, end};
+}
+
 // acc = bias[n] broadcast down the rows: the bias add rides in the MFMA accumulator for free.
 template <int NCB>
 __device__ __forceinline__ void bias_acc(f32x16 (&acc)[2][NCB], const float* __restrict__ bias, int ncol0, int lane) {

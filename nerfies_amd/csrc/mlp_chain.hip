@@ -63,7 +63,9 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
   unsigned long long wg_t0 = 0, wg_w0 = 0;
   if (A.timeline && tid == 0) { wg_t0 = clock64(); wg_w0 = wall_clock64(); }
   int* tslot = reinterpret_cast<int*>(pe);   // free between tiles
-  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
+  const TileIter ti = tile_iter(A.ntiles, A.k_old);
+  for (int tile = A.tile_counter ? next_tile(A.tile_counter, tslot) : ti.first; tile < (A.tile_counter ? A.ntiles : ti.end);
+       tile = A.tile_counter ? next_tile(A.tile_counter, tslot, tile) : tile + ti.step) {
     STAMP();   // tile start
     // ---- prologue: sample point + SinusoidalEncoder (modules.py:213-228) ----
     {
@@ -320,8 +322,10 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
   const int wv = wave * 2 * 8 * 1024;                           // bytes: this wave's slice of a tile
 
   int* tslot = reinterpret_cast<int*>(dr);   // free between tiles
+  const TileIter ti = tile_iter(A.ntiles, A.k_old);
 #pragma unroll 1
-  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
+  for (int tile = A.tile_counter ? next_tile(A.tile_counter, tslot) : ti.first; tile < (A.tile_counter ? A.ntiles : ti.end);
+       tile = A.tile_counter ? next_tile(A.tile_counter, tslot, tile) : tile + ti.step) {
     if (tid < TILE_ROWS) {
       const float4 d = A.d_raw4[(size_t)tile * TILE_ROWS + tid];
       dr[tid] = d.x; dr[TILE_ROWS + tid] = d.y; dr[2 * TILE_ROWS + tid] = d.z; dr[3 * TILE_ROWS + tid] = d.w;

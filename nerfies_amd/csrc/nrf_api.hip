@@ -300,6 +300,20 @@ enum { CT_WARP_FWD = 0, CT_MLP_FWD = 2, CT_TAN_FWD = 4, CT_MLP_BWD = 5, CT_WARP_
 // Measured (r01): pulling tiles from a global counter is 4-6 % SLOWER than the static round-robin split for the
 // chain kernels (fine forward 1.99 vs 1.87 ms) although it removes the tail where the younger workgroup of a CU
 // runs alone -- so static is the default and NRF_DYNAMIC_TILES=1 keeps the other path testable.
+// Uneven static tile split of the NeRF chain kernels (chain_common.h tile_iter): tiles the older workgroup of a CU takes out
+// of the K = ceil(ntiles / CUs) of its CU, when the launch is exactly two workgroups per CU and K >= 4.  NRF_OLD_SHARE
+// overrides the share (0 = even split).
+int k_old_for(int ntiles, int grid, int num_cus, double dflt_share) {
+  if (grid != 2 * num_cus) return 0;
+  const int K = (ntiles + num_cus - 1) / num_cus;
+  if (K < 4) return 0;
+  static const char* e = getenv("NRF_OLD_SHARE");
+  const double share = e ? atof(e) : dflt_share;
+  if (share <= 0.0) return 0;
+  int k = (int)floor(K * share + 0.5);
+  return k < 1 ? 1 : (k > K - 1 ? K - 1 : k);
+}
+
 int* tile_counter_or_null(float* base, int idx) {
   static const bool dynamic = getenv("NRF_DYNAMIC_TILES") != nullptr;
   return dynamic ? reinterpret_cast<int*>(base) + idx : nullptr;
@@ -1130,6 +1144,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
         launch_jacobian(ja, stream);
       }
     }
+    a.k_old = k_old_for(p.ntiles[lv], grid, h->num_cus, 0.0);
     pf.begin(lv == 0 ? "mlp_fwd_coarse" : "mlp_fwd_fine", fwd_flops_row(h) * p.rows[lv], stream);
     if (bf16) {   // one workgroup per CU (90 KiB of weight staging), 256 samples per workgroup iteration
       a.wpk = ws + L.bf_wpk;
@@ -1235,6 +1250,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     a.alpha_on_bn = h->A > 0 ? 1 : 0;
     a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_BWD + lv);
     const int grid = p.ntiles[lv] < 2 * h->num_cus ? p.ntiles[lv] : 2 * h->num_cus;   // two workgroups per CU
+    a.k_old = k_old_for(p.ntiles[lv], grid, h->num_cus, 0.0);
     if (!bft) {
       h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
       launch_chain_bwd(a, grid, stream);

@@ -148,6 +148,7 @@ struct ChainFwdArgs {
   int F, P, PK;              // point freqs, 3+6F, P rounded up to a multiple of 16
   int sigma_act;
   int* tile_counter;         // zeroed before the launch: dynamic tile hand-out (chain_common.h next_tile)
+  int k_old;                 // > 0: uneven static split, tiles of the older workgroup of a CU (chain_common.h tile_iter)
   unsigned long long* timeline;   // debug: [4 waves][64] shader-clock stamps of workgroup 0 (or nullptr)
   // use_alpha_condition (modules.py:152-157): the alpha head reads [bottleneck, appearance code]; alpha_ct[ray] =
   // code . W_alpha[256:] (ray_prep), nullptr -> the head reads the trunk output
@@ -188,6 +189,7 @@ struct ChainBwdArgs {
   const float* st_pe;        // posenc stash of the forward pass
   int F, P, PK;
   int* tile_counter;
+  int k_old;                 // as ChainFwdArgs
   int alpha_on_bn;           // use_alpha_condition: d raw sigma enters at the bottleneck instead of the trunk output
 };
 

@@ -5,11 +5,13 @@
 # Passes are separate processes: bench line, rocprofv3 kernel trace, three PMC passes (SQ / FETCH_SIZE / WRITE_SIZE never
 # share a pass, never combined with a trace domain), then the secondary workloads.
 TAG=${1:-r02}
-MODES=${2:-"train eval eval_bf16 vrig train_bf16"}
+MODES=${2:-"train eval eval_bf16 vrig vrig_bf16 train_bf16"}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
 summ() { f=$(find $1 -name '*.db' | head -1); [ -n "$f" ] && python scripts/rocpd_summary.py $f $2; }
+# gpurun copies back at most 64 MiB: the rocpd databases are dropped once summarised (hbm traffic is extracted first)
+clean() { rm -rf "$@"; }
 SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 for mode in $MODES; do
   case $mode in
@@ -17,9 +19,11 @@ for mode in $MODES; do
     eval)       ARGS="--mode eval";              ENV="";               SUF="_eval" ;;
     eval_bf16)  ARGS="--mode eval";              ENV="BENCH_BF16=1";   SUF="_eval_bf16" ;;
     vrig)       ARGS="--mode vrig";              ENV="";               SUF="_vrig" ;;
+    vrig_bf16)  ARGS="--mode vrig";              ENV="BENCH_BF16=1";   SUF="_vrig_bf16" ;;
     train_bf16) ARGS="--mode train_bf16";        ENV="";               SUF="_train_bf16" ;;
   esac
-  env $ENV python bench.py $ARGS --steps 50 --warmup 5 > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
+  NOCPU="--no-cpu-baseline"; [ "$mode" = train ] && NOCPU=""
+  env $ENV python bench.py $ARGS --steps 50 --warmup 5 $NOCPU > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
   head -c 400 $O/${TAG}_bench${SUF}.json; echo
   rm -rf $O/prof_${TAG}${SUF} $O/pmc1_${TAG}${SUF} $O/pmc2_${TAG}${SUF} $O/pmc3_${TAG}${SUF}
   env $ENV rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}${SUF} -o kt -- python bench.py $ARGS --steps 10 --warmup 2 --burn-in-s 0 --no-cpu-baseline > $O/prof_${TAG}${SUF}.log 2>&1
@@ -35,5 +39,6 @@ for mode in $MODES; do
     [ -n "$fdb" ] && [ -n "$wdb" ] && python scripts/make_hbm_traffic.py $fdb $wdb $O/${TAG}${SUF}_hbm_traffic.json \
       "profiles/${TAG}${SUF}_pmc_fetch.md, profiles/${TAG}${SUF}_pmc_write.md (bench.py $ARGS --steps 3)"
   fi
+  clean $O/prof_${TAG}${SUF} $O/pmc1_${TAG}${SUF} $O/pmc2_${TAG}${SUF} $O/pmc3_${TAG}${SUF}
 done
 ls $O/${TAG}_*

@@ -26,8 +26,9 @@ def parse_flags(argv=None):
   p.add_argument('--gin_bindings', action='append', default=None, help='Gin parameter bindings.')
   p.add_argument('--gin_configs', action='append', default=[], help='Gin config files.')
   p.add_argument('--max_steps', type=int, default=None, help='stop early (smoke runs); default TrainConfig.max_steps')
-  p.add_argument('--bf16', action='store_true', help='eval.py only: render with bfloat16 MLP operands (NRF_FLAG_BF16, ~5x faster, '
-                 '~1e-2 on colour; no reference counterpart)')
+  p.add_argument('--bf16', action='store_true', help='bfloat16 MLP operands (NRF_FLAG_BF16; no reference counterpart): train.py trains '
+                 'with a bfloat16 activation / gradient stash (fp32 master weights, loss, Adam; ~3.5x the fp32 step), eval.py renders '
+                 'with them (~5x faster, ~1e-2 on colour)')
   return p.parse_args(argv)
 
 
@@ -118,7 +119,8 @@ def main(argv=None):
       state, stats, key = training.train_step(
           model, key, state, batch, scalar_params, use_elastic_loss=train_config.use_elastic_loss,
           elastic_reduce_method=train_config.elastic_reduce_method, elastic_loss_type=train_config.elastic_loss_type,
-          use_background_loss=train_config.use_background_loss, use_warp_reg_loss=train_config.use_warp_reg_loss)
+          use_background_loss=train_config.use_background_loss, use_warp_reg_loss=train_config.use_warp_reg_loss,
+          bf16=flags.bf16)
       if step % train_config.print_every == 0 or step % train_config.log_every == 0:
         torch.cuda.synchronize(device)            # only when the numbers are read
     tracker.toc('total')

@@ -555,22 +555,34 @@ void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stre
 
 // dray[ray][f] = sum over the ray's samples of dpre_rgbh[sample][f]  (gradient of the per-ray rgb-condition term), read back
 // from the bf16 stash: [group][b (4)][jp][lane = n + 32 h][(jj, i)], feature f = 32 b + 8 (2 jp + jj) + 4 h + i.
-__global__ __launch_bounds__(128) void dray_bf16_kernel(const uint32_t* __restrict__ drgbh, int S, float* __restrict__ dray) {
-  const int ray = blockIdx.x, f = threadIdx.x;
-  const int b = f >> 5, j = (f >> 3) & 3, h = (f >> 2) & 1, i = f & 3;
-  const unsigned short* base = reinterpret_cast<const unsigned short*>(drgbh);
-  const size_t in_group = ((size_t)(b * 2 + (j >> 1)) * 64 + 32 * h) * 8 + (j & 1) * 4 + i;   // + n * 8
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) {
+// One workgroup per ray; thread (granule gi = (b, jp, h), sample lane sl): 16 consecutive threads read 16 consecutive samples
+// of one granule column = 256 contiguous bytes; 8 float partial sums per thread, folded over the sample lanes through LDS.
+__global__ __launch_bounds__(256) void dray_bf16_kernel(const uint32_t* __restrict__ drgbh, int S, float* __restrict__ dray) {
+  __shared__ float sm[16][RGB_W + 1];
+  const int ray = blockIdx.x, sl = threadIdx.x & 15, gi = threadIdx.x >> 4;
+  const int b = gi >> 2, jp = (gi >> 1) & 1, h = gi & 1;
+  const uint4* base = reinterpret_cast<const uint4*>(drgbh);
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k = sl; k < S; k += 16) {
     const size_t row = (size_t)ray * S + k;
-    const unsigned short v = base[(row >> 5) * (4 * BF_BLOCK_DW * 2) + in_group + (row & 31) * 8];
-    s += __uint_as_float((unsigned)v << 16);
+    const uint4 v = base[(row >> 5) * (4 * BF_BLOCK_DW / 4) + (b * 2 + jp) * 64 + (int)(row & 31) + 32 * h];
+    const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[2 * i] += __uint_as_float(u[i] << 16); acc[2 * i + 1] += __uint_as_float(u[i] & 0xFFFF0000u); }
   }
-  dray[(size_t)ray * RGB_W + f] = s;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sm[sl][32 * b + 8 * (2 * jp + (e >> 2)) + 4 * h + (e & 3)] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < RGB_W) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sm[q][threadIdx.x];
+    dray[(size_t)ray * RGB_W + threadIdx.x] = t;
+  }
 }
 
 void launch_dray_bf16(const uint32_t* drgbh, int B, int S, float* dray, hipStream_t stream) {
-  hipLaunchKernelGGL(dray_bf16_kernel, dim3(B), dim3(128), 0, stream, drgbh, S, dray);
+  hipLaunchKernelGGL(dray_bf16_kernel, dim3(B), dim3(256), 0, stream, drgbh, S, dray);
 }
 
 namespace {

@@ -94,7 +94,8 @@ EvalConfig.num_val_eval = 1
 """
 
 
-def test_train_and_eval_drivers_end_to_end(tmp_path, capsys):
+@pytest.mark.parametrize('extra', [[], ['--bf16']])   # --bf16: bf16 training mode, then bf16-operand rendering in eval.py
+def test_train_and_eval_drivers_end_to_end(tmp_path, capsys, extra):
   sys.path.insert(0, ROOT)
   import eval as eval_driver
   import train as train_driver
@@ -103,7 +104,7 @@ def test_train_and_eval_drivers_end_to_end(tmp_path, capsys):
   datasets.write_synthetic_scene(cap, num_frames=4, size=(24, 16))
   cfg = tmp_path / 'run.gin'
   cfg.write_text(GIN)
-  args = ['--base_folder', exp, '--data_dir', cap, '--gin_configs', str(cfg)]
+  args = ['--base_folder', exp, '--data_dir', cap, '--gin_configs', str(cfg)] + extra
   gin.clear_config()
   state = train_driver.main(args + ['--max_steps', '20'])
   assert state.optimizer.step == 20 and os.path.exists(os.path.join(exp, 'checkpoints', 'checkpoint_20'))

@@ -120,15 +120,23 @@ class ClockSampler:
     return out or None
 
 
-def burn_in(step, seconds):
-  """Untimed steps of the same workload for >= `seconds` (clocks / power settle), synchronising every 16 steps."""
+def burn_in(step, seconds, world=1, device=None):
+  """Untimed steps of the same workload for >= `seconds` (clocks / power settle), in rounds of 16 steps.  A step contains
+  the gradient all-reduce, so with world > 1 every rank must run the SAME number of rounds: the decision to go on is itself
+  all-reduced (MAX of the ranks' elapsed times)."""
   t0, n = time.perf_counter(), 0
-  while time.perf_counter() - t0 < seconds:
+  while True:
     for _ in range(16):
       step()
     torch.cuda.synchronize()
     n += 16
-  return n
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+      t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      elapsed = t.item()
+    if elapsed >= seconds:
+      return n
 
 
 class Cfg:
@@ -253,7 +261,7 @@ def side_mode(args, world, rank, dev):
     workload = ('gpu_vrig_paper.gin shape: 768 rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, elastic loss '
                 "(reduce 'weight', w=0.001) on the coarse samples, background points 16384/world (w=1), stratified")
   if args.burn_in_s > 0:
-    burn_in(step, args.burn_in_s)
+    burn_in(step, args.burn_in_s, world, dev)
   for _ in range(args.warmup):
     step()
   barrier()
@@ -354,7 +362,7 @@ def main():
   # untimed burn-in at the same workload (>= --burn-in-s seconds) so the short timed window below sits at steady-state
   # clocks and power; the sampler keeps running through the timed region
   sampler = ClockSampler(local_rank if world > 1 else 0)
-  burn_steps = burn_in(step, args.burn_in_s) if args.burn_in_s > 0 else 0
+  burn_steps = burn_in(step, args.burn_in_s, world, dev) if args.burn_in_s > 0 else 0
   for _ in range(args.warmup):
     step()
   barrier()

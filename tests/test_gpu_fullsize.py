@@ -1,7 +1,8 @@
-"""Size-independent properties at BASELINE.json's full sizes, where the fp64 oracle is too slow to be the checker:
-config A (1024 rays x (64+128) samples, warp off) and the gpu_vrig_paper shape (768 rays x (128+128), SE3 warp).
-Every property below holds for the reference by construction (rays are independent, the loss is a mean, the VJP is
-linear); the oracle-backed parity tests at small sizes are in tests/test_gpu_parity.py."""
+"""Size-independent properties at BASELINE.json's full sizes: config A (1024 rays x (64+128) samples, warp off) and the
+gpu_vrig_paper shape (768 rays x (128+128), SE3 warp).  Every property below holds for the reference by construction (rays
+are independent, the loss is a mean, the VJP is linear).  The oracle-backed parity tests at small sizes are in
+tests/test_gpu_parity.py; since round 2 the float64 oracle itself is ALSO run at these full shapes (and config D's),
+tests/test_gpu_pinned.py -- the properties here stay as the cheap, oracle-free cross-check."""
 import numpy as np
 import pytest
 import torch

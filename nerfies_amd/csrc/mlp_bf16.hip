@@ -95,6 +95,18 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[NG][NOUT], const unsigned 
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) acc[g][o] = zero;
   }
+  // A fragments: ONE register set, refilled fragment by fragment: right after the MFMA that consumed fragment o of row r
+  // has issued, the LDS read of fragment o of the NEXT row goes out into the same registers (8 MFMAs = 256 clocks ahead of its
+  // use).  The chunk barrier sits in front of the LAST row of a chunk -- whose fragments are in registers by then -- so the
+  // first row of the next chunk is prefetched under the last row's MFMAs as well: the LDS latency is exposed once per GEMM,
+  // not once per chunk, and the fragment registers are half of a double-buffered row (the two-set version spilled ~200
+  // VGPRs, whose scratch traffic also made every vmcnt wait stricter than the prefetch distance intended).
+  bf16x8 af[NOUT];
+  {
+    const char* wb0 = lds + st.cur * BF_BUF_BYTES + lane * 16;
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) af[o] = *reinterpret_cast<const bf16x8*>(wb0 + o * 1024);
+  }
 #pragma unroll
   for (int c = 0; c < NCHUNK; ++c) {
     constexpr int BODY = 4 * NOUT * 1024;
@@ -103,23 +115,31 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[NG][NOUT], const unsigned 
     const int n1 = c + 1 < NCHUNK ? BODY : NEXT1;
     const int off1 = (WRAP && c + 1 == NCHUNK) ? 0 : st.soff + this_bytes;
     const int off2 = (WRAP && c + 2 == NCHUNK) ? 0 : (WRAP && c + 2 == NCHUNK + 1) ? NEXT1 : off1 + n1;
-    const int buf2 = st.cur >= 1 ? st.cur - 1 : 2;   // (cur + 2) % 3
+    const int buf1 = st.cur == 2 ? 0 : st.cur + 1;   // (cur + 1) % 3
+    const int buf2 = st.cur >= 1 ? st.cur - 1 : 2;   // (cur + 2) % 3: last read in chunk c - 1, released by its barrier
     if (c + 2 < NCHUNK) bf_dma<BODY, NW>(st.src, off2, lds, buf2, wave);
     else if (c + 2 == NCHUNK) bf_dma<NEXT1, NW>(st.src, off2, lds, buf2, wave);
     else bf_dma<NEXT2, NW>(st.src, off2, lds, buf2, wave);
     const char* wb = lds + st.cur * BF_BUF_BYTES + lane * 16;
+    const char* wbn = lds + buf1 * BF_BUF_BYTES + lane * 16;
     constexpr int NB = BIAS ? 1 : 0;
     const int nrows = 4 + ((BIAS && c == 0) ? 1 : 0);   // k-step rows of this chunk (bias row first)
-    // A fragments of row r+1 are read from LDS while row r is multiplied (two register sets)
-    bf16x8 af[2][NOUT];
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) af[0][o] = *reinterpret_cast<const bf16x8*>(wb + o * 1024);
 #pragma unroll
     for (int r = 0; r < 4 + NB; ++r) {
       if (r < nrows) {
-        if (r + 1 < nrows) {
-#pragma unroll
-          for (int o = 0; o < NOUT; ++o) af[(r + 1) & 1][o] = *reinterpret_cast<const bf16x8*>(wb + ((r + 1) * NOUT + o) * 1024);
+        const bool last = r + 1 == nrows;
+        if (last) {
+          // chunk c+1 (issued one chunk ago) must have landed; chunk c+2's copies (issued at the top of this chunk) may stay in
+          // flight; this wave's own LDS reads of chunk c are complete (lgkmcnt) ...
+          if (c + 2 < NCHUNK) bf_wait_vm<bf_copies(BODY, NW)>();
+          else if (c + 2 == NCHUNK) bf_wait_vm<bf_copies(NEXT1, NW)>();
+          else bf_wait_vm<bf_copies(NEXT2, NW)>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          // ... and everyone's: chunk c+1 is visible to all, and nobody reads chunk c's buffer any more (the next chunk's
+          // prefetch refills it).  A bare s_barrier: __syncthreads() adds a workgroup fence, i.e. vmcnt(0), which would drain
+          // the two-ahead prefetch every chunk.
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
         }
         __builtin_amdgcn_sched_barrier(0);
         const bool bias_row = BIAS && c == 0 && r == 0;
@@ -130,29 +150,25 @@ __device__ __forceinline__ void bf_gemm(f32x16 (&acc)[NG][NOUT], const unsigned 
         for (int g = 0; g < NG; ++g)
           bop[g] = bias_row ? as_bf16x8(bias_b0, 0u, 0u, 0u)        // B = 1 in k-slots 0, 1 (bias hi + lo)
                             : as_bf16x8(in[g][b][4 * s2], in[g][b][4 * s2 + 1], in[g][b][4 * s2 + 2], in[g][b][4 * s2 + 3]);
+        const bool more = !last || c + 1 < NCHUNK;   // a next row inside this GEMM
+        const char* nx = last ? wbn : wb + (r + 1) * NOUT * 1024;
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o)
+        for (int o = 0; o < NOUT; ++o) {
 #pragma unroll
           for (int g = 0; g < NG; ++g) {
 #ifdef BF_NOMFMA
-            acc[g][o][0] += __builtin_bit_cast(u32x4v, af[r & 1][o]).x * 1e-30f + __builtin_bit_cast(u32x4v, bop[g]).x * 1e-30f;
+            acc[g][o][0] += __builtin_bit_cast(u32x4v, af[o]).x * 1e-30f + __builtin_bit_cast(u32x4v, bop[g]).x * 1e-30f;
 #else
-            acc[g][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[r & 1][o], bop[g], acc[g][o], 0, 0, 0);
+            acc[g][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o], bop[g], acc[g][o], 0, 0, 0);
 #endif
           }
+          if (more) af[o] = *reinterpret_cast<const bf16x8*>(nx + o * 1024);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    // chunk c+1 (issued one chunk ago) must have landed; chunk c+2's copies (just issued) may stay in flight
-    if (c + 2 < NCHUNK) bf_wait_vm<bf_copies(BODY, NW)>();
-    else if (c + 2 == NCHUNK) bf_wait_vm<bf_copies(NEXT1, NW)>();
-    else bf_wait_vm<bf_copies(NEXT2, NW)>();
-    // ... everyone's share has, and nobody still reads the buffer the next chunk's prefetch replaces.  A bare s_barrier:
-    // __syncthreads() adds a workgroup fence, i.e. vmcnt(0), which would drain the two-ahead prefetch every chunk.
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
     st.soff = off1;
-    st.cur = st.cur == 2 ? 0 : st.cur + 1;
+    st.cur = buf1;
   }
 }
 

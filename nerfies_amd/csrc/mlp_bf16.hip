@@ -46,6 +46,12 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, p);
 }
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned relu_pk(unsigned p) {
+  const s16x2 z = {0, 0};
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
+}
+
 __device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
   const u32x4v v = {a, b, c, d};
   return __builtin_bit_cast(bf16x8, v);
@@ -186,8 +192,10 @@ __device__ __forceinline__ void bf_pack(unsigned (&out)[NG][NB][8], const f32x16
         out[g][o][q] = __float_as_uint(a) ^ __float_as_uint(b);
         continue;
 #endif
-        if (RELU) { a = __builtin_amdgcn_fmed3f(a, 0.f, __builtin_inff()); b = __builtin_amdgcn_fmed3f(b, 0.f, __builtin_inff()); }
-        out[g][o][q] = pack_bf16(a, b);
+        // ReLU AFTER the pack, on both halves at once: a negative bf16 is a negative int16 (v_pk_max_i16 with 0); rounding to
+        // nearest keeps the sign, so relu(round(x)) = round(relu(x))
+        const unsigned pk = pack_bf16(a, b);
+        out[g][o][q] = RELU ? relu_pk(pk) : pk;
       }
 }
 

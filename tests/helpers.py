@@ -24,7 +24,7 @@ def config_from_spec(spec):
       appearance_metadata_dims=spec.num_appearance_features, camera_metadata_dims=spec.num_camera_features,
       use_warp=spec.use_warp, num_warp_freqs=spec.num_warp_freqs, num_warp_features=spec.num_warp_features,
       warp_field_type=spec.warp_field_type, use_alpha_condition=spec.use_alpha_condition, use_rgb_condition=spec.use_rgb_condition,
-      noise_std=spec.noise_std)
+      noise_std=spec.noise_std, warp_metadata_encoder_type=spec.warp_metadata_encoder_type)
 
 
 def gpu_model(spec, oparams, batch_size=0):
@@ -39,7 +39,7 @@ def gpu_model(spec, oparams, batch_size=0):
 
 def gpu_batch(batch):
   out = {k: v.to(DEV).float() for k, v in batch.items() if torch.is_tensor(v)}
-  out['metadata'] = {k: v.to(DEV) for k, v in batch.get('metadata', {}).items()}
+  out['metadata'] = {k: (v.to(DEV).float() if v.is_floating_point() else v.to(DEV)) for k, v in batch.get('metadata', {}).items()}
   return out
 
 
@@ -171,7 +171,7 @@ def leaf(tree, path):
 
 
 def run_pinned(spec, B, alpha, seed=3, strat=True, elastic=None, background=None, params=None, batch=None, t_rand=None, u=None,
-               warp_reg=None):
+               warp_reg=None, time_alpha=None):
   """GPU loss_and_grad, masks read back, fp64 oracle pinned to them.  Returns a dict of everything compared."""
   from nerfies_amd import params as P
   p64 = params if params is not None else O.init_params(spec, seed=seed, trained_like=True, dtype=torch.float64)
@@ -206,7 +206,9 @@ def run_pinned(spec, B, alpha, seed=3, strat=True, elastic=None, background=None
     nz_f = torch.randn(B, spec.num_coarse_samples + spec.num_fine_samples, generator=g2).double()
     rngs = dict(rngs or {}, noise_coarse=nz_c.float().to(DEV), noise_fine=nz_f.float().to(DEV))
     okw.update(noise_coarse=nz_c, noise_fine=nz_f)
-  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha}, rngs=rngs, **gkw)
+  if time_alpha is not None:   # warp_extra['time_alpha'] (TimeEncoder window, models.py:252-254)
+    okw['time_alpha'] = time_alpha
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': alpha, 'time_alpha': time_alpha or 0.0}, rngs=rngs, **gkw)
   torch.cuda.synchronize()
   masks = gpu_relu_masks(model, spec, B, nbg, elastic is not None)
   hook = PinnedRelu(masks)
@@ -234,7 +236,7 @@ def run_pinned(spec, B, alpha, seed=3, strat=True, elastic=None, background=None
     scale = max(og.abs().max().item(), 1e-30)
     errs[path] = ((leaf(got, path).double() - og).abs().max().item() / scale, scale)
   return dict(model=model, fp=fp, gb=gb, rngs=rngs, stats=stats.cpu(), loss=loss.item(), ostats=ostats, ret=ret, errs=errs, hook=hook,
-              alpha=alpha, tol=grad_tol(spec))
+              alpha=alpha, time_alpha=time_alpha, tol=grad_tol(spec))
 
 
 def assert_pinned(r, label, loss_tol=1e-5):
@@ -251,7 +253,8 @@ def assert_pinned(r, label, loss_tol=1e-5):
 
 def assert_forward(r, spec, atol=1e-4):
   """The rendered outputs of a (non-training) forward on the same rays against the pinned oracle's."""
-  out = r['model'].apply({'params': r['fp']}, r['gb'], {'alpha': r['alpha']}, rngs=r['rngs'], return_weights=True)
+  out = r['model'].apply({'params': r['fp']}, r['gb'], {'alpha': r['alpha'], 'time_alpha': r.get('time_alpha') or 0.0}, rngs=r['rngs'],
+                         return_weights=True)
   for lv in out:
     for k in ('rgb', 'depth', 'acc', 'weights'):
       np.testing.assert_allclose(out[lv][k].cpu().numpy(), r['ret'][lv][k].detach().numpy(), atol=atol, err_msg=f'{lv}/{k}')

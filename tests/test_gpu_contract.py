@@ -274,3 +274,38 @@ def test_train_step_reports_every_reference_stat():
   held = stats['fine']['loss/rgb']
   training.train_step(model, key, state, gb, sp, use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
   assert held.item() == keep
+
+
+# ---------------------------------------------------------------------------------------------
+# 'time' warp metadata encoder: modules.TimeEncoder (modules.py:297-322) through SE3Field.encode_metadata
+# (warping.py:256-259, 311-313) with metadata['time'] (models.py:252-254); csrc/time_encoder.hip
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw,B,alpha,time_alpha', [
+    (dict(num_nerf_point_freqs=4, num_coarse_samples=16, num_fine_samples=16), 9, 3.0, 1.0),
+    (dict(num_nerf_point_freqs=8, num_warp_freqs=6, num_warp_features=5, use_camera_metadata=True, num_coarse_samples=32, num_fine_samples=32), 33, 4.5, 0.4),
+    (dict(num_nerf_point_freqs=6, warp_field_type='translation', num_coarse_samples=24, num_fine_samples=24), 12, 2.0, 0.0)])
+def test_time_encoder_forward_and_gradients(kw, B, alpha, time_alpha):
+  """Forward outputs and every gradient leaf -- the six TimeEncoder layers included -- against the float64 oracle (ReLU
+  branches of the NeRF / warp trunks pinned to the HIP path's, tests/helpers.run_pinned)."""
+  spec = O.ModelSpec(use_warp=True, use_stratified_sampling=True, warp_metadata_encoder_type='time', **kw)
+  r = H.run_pinned(spec, B, alpha, seed=17, time_alpha=time_alpha)
+  H.assert_pinned(r, f'time encoder B={B}')
+  H.assert_forward(r, spec)
+  enc = [k for k in r['errs'] if k.startswith('warp_field/metadata_encoder/mlp/')]
+  assert len(enc) == 14 and all(r['errs'][k][1] > 0 for k in enc if k.endswith('kernel'))   # 6 hidden + logit, kernel + bias; all carry gradient
+  assert not any('embed' in k for k in r['errs'] if k.startswith('warp_field'))              # no GLO table in this configuration
+
+
+def test_time_encoder_codes_can_be_supplied_encoded():
+  """metadata_encoded=True with the time encoder: the caller's codes replace the encoder's output (warping.py:378-381)."""
+  spec = O.ModelSpec(use_warp=True, warp_metadata_encoder_type='time', num_coarse_samples=16, num_fine_samples=16)
+  p = O.init_params(spec, seed=2, trained_like=True)
+  b = O.synthetic_batch(10, seed=3)
+  model, fp = H.gpu_model(spec, p, 10)
+  gb = H.gpu_batch(b)
+  by_time = model.apply({'params': fp}, gb, {'alpha': 3.0, 'time_alpha': 1.0})
+  codes = O.time_encode(p['warp_field']['metadata_encoder'], b['metadata']['time'].double(), spec.num_time_encoder_freqs, 1.0)
+  enc = dict(gb)
+  enc['metadata'] = {'time': codes.float().to(DEV)}   # models.py:252-254: the warp metadata of a 'time' model is metadata['time']
+  by_codes = model.apply({'params': fp}, enc, {'alpha': 3.0, 'time_alpha': 1.0}, metadata_encoded=True)
+  np.testing.assert_allclose(_np(by_codes['fine']['rgb']), _np(by_time['fine']['rgb']), atol=2e-5)

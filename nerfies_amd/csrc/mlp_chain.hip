@@ -299,8 +299,23 @@ void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t s
 // small_part layout (floats): db_trunk[8][256] | db_bn[256] | db_rgbh[128] | db_logit[3] | db_alpha
 constexpr int SP_DB_TRUNK = 0, SP_DB_BN = 2048, SP_DB_RGBH = 2304, SP_DB_LOGIT = 2432, SP_DB_ALPHA = 2435;
 
-__global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// per-lane bias-gradient accumulators of one workgroup, carried across its tiles of one level
+struct BwdAcc {
+  float db_trunk[TRUNK_DEPTH][2];
+  float db_bn[2];
+  float db_rgbh;
+  float dsum[4];   // threads < 64: column sums of d_raw (logit / alpha bias grads)
+};
+__device__ __forceinline__ void bwd_acc_zero(BwdAcc& c) {
+#pragma unroll
+  for (int l = 0; l < TRUNK_DEPTH; ++l) c.db_trunk[l][0] = c.db_trunk[l][1] = 0.f;
+  c.db_bn[0] = c.db_bn[1] = 0.f;
+  c.db_rgbh = 0.f;
+  c.dsum[0] = c.dsum[1] = c.dsum[2] = c.dsum[3] = 0.f;
+}
+
+// one 64-row tile of level A (tile = index inside the level)
+__device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, float* smem, BwdAcc& C) {
   float* act = smem;                 // [256][64] swizzled: current dpre tile
   float* dr = smem + ACT_FLOATS;     // [4][64]: d raw rgb (3) and d raw sigma of the tile rows
   const int tid = threadIdx.x;
@@ -309,23 +324,13 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
   const int j = lane & 31, h = lane >> 5;
   const float* __restrict__ prm = A.params;
   const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
-
-  // per-lane bias-gradient accumulators, carried across this workgroup's tiles
-  float db_trunk[TRUNK_DEPTH][2];
-#pragma unroll
-  for (int l = 0; l < TRUNK_DEPTH; ++l) db_trunk[l][0] = db_trunk[l][1] = 0.f;
-  float db_bn[2] = {0.f, 0.f};
-  float db_rgbh = 0.f;
-  float dsum[4] = {0.f, 0.f, 0.f, 0.f};   // threads < 64: column sums of d_raw (logit / alpha bias grads)
-
   const size_t layer_fl = (size_t)A.ntiles * FRAG_TILE_256;   // floats per trunk layer
   const int wv = wave * 2 * 8 * 1024;                           // bytes: this wave's slice of a tile
-
-  int* tslot = reinterpret_cast<int*>(dr);   // free between tiles
-  const TileIter ti = tile_iter(A.ntiles, A.k_old);
-#pragma unroll 1
-  for (int tile = A.tile_counter ? next_tile(A.tile_counter, tslot) : ti.first; tile < (A.tile_counter ? A.ntiles : ti.end);
-       tile = A.tile_counter ? next_tile(A.tile_counter, tslot, tile) : tile + ti.step) {
+  float (&db_trunk)[TRUNK_DEPTH][2] = C.db_trunk;
+  float (&db_bn)[2] = C.db_bn;
+  float& db_rgbh = C.db_rgbh;
+  float (&dsum)[4] = C.dsum;
+  {
     if (tid < TILE_ROWS) {
       const float4 d = A.d_raw4[(size_t)tile * TILE_ROWS + tid];
       dr[tid] = d.x; dr[TILE_ROWS + tid] = d.y; dr[2 * TILE_ROWS + tid] = d.z; dr[3 * TILE_ROWS + tid] = d.w;
@@ -513,7 +518,20 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
       }
     }
   }
+}
 
+// the per-workgroup partials of level A -> small_part[blockIdx.x]
+__device__ __forceinline__ void bwd_flush(const ChainBwdArgs& A, float* smem, const BwdAcc& C) {
+  float* dr = smem + ACT_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const float (&db_trunk)[TRUNK_DEPTH][2] = C.db_trunk;
+  const float (&db_bn)[2] = C.db_bn;
+  const float db_rgbh = C.db_rgbh;
+  const float (&dsum)[4] = C.dsum;
+  __syncthreads();   // dr may still be read by the tile just finished
   // ---- flush the per-workgroup partials ----
   float* sp = A.small_part + (size_t)blockIdx.x * SMALL_PART;
 #pragma unroll
@@ -543,12 +561,46 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs
     for (int q = 0; q < TILE_ROWS; ++q) s += dr[tid * TILE_ROWS + q];
     sp[tid < 3 ? SP_DB_LOGIT + tid : SP_DB_ALPHA] = s;
   }
+  __syncthreads();
 }
 
-void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)(ACT_FLOATS + (a.d_points ? a.PK : 4) * TILE_ROWS) * sizeof(float);
+// ONE launch for the coarse and the fine MLP (the two backward passes are independent: no gradient flows from the fine
+// pass into the coarse MLP): global tiles [0, nt0) are level 0, [nt0, ntot) level 1, dealt round-robin, so a
+// workgroup runs its 2 coarse tiles and goes straight on with its 6 fine ones (config A) instead of ramping up and draining
+// twice.  The bias partials are flushed per level.  The level's arguments are indexed in the kernarg segment (scalar loads,
+// one copy of the tile code).
+struct ChainBwdArgs2 { ChainBwdArgs a[2]; int nt0, ntot; };
+__global__ __launch_bounds__(256, 2) void nerf_mlp_bwd_kernel(const ChainBwdArgs2 P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  BwdAcc C;
+  bwd_acc_zero(C);
+  const int nt0 = P.nt0, ntot = P.ntot;
+  int cur = -1;
+  if ((int)blockIdx.x >= nt0 && nt0 > 0) bwd_flush(P.a[0], smem, C);   // no coarse tile for this workgroup: its partial is zero
+#pragma unroll 1
+  for (int g = blockIdx.x; g < ntot; g += gridDim.x) {
+    const int lv = g >= nt0 ? 1 : 0;
+    if (lv != cur) {
+      if (cur == 0) { bwd_flush(P.a[0], smem, C); bwd_acc_zero(C); }
+      cur = lv;
+    }
+    bwd_tile(P.a[lv], g - (lv ? nt0 : 0), smem, C);
+  }
+  if (cur == 0) {
+    bwd_flush(P.a[0], smem, C);
+    if (ntot > nt0) { bwd_acc_zero(C); bwd_flush(P.a[1], smem, C); }
+  } else if (cur == 1) {
+    bwd_flush(P.a[1], smem, C);
+  }
+}
+
+void launch_chain_bwd(const ChainBwdArgs& a0, const ChainBwdArgs* a1, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)(ACT_FLOATS + (a0.d_points ? a0.PK : 4) * TILE_ROWS) * sizeof(float);
   (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(256), lds, stream, a);
+  ChainBwdArgs2 p;
+  p.a[0] = a0; p.a[1] = a1 ? *a1 : a0;
+  p.nt0 = a0.ntiles; p.ntot = p.nt0 + (a1 ? a1->ntiles : 0);
+  hipLaunchKernelGGL(nerf_mlp_bwd_kernel, dim3(grid), dim3(256), lds, stream, p);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -358,7 +358,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   // ---- wgrad groups (training) ----
   struct GroupSpec { int lv; int xk; size_t* xoff; int xstride; int kvalid; int Kb; int yk; size_t* yoff; int ystride; int Nb;
                      int vec; int64_t dst; int dst_ld; int rows; int cols; int units; size_t xadd, yadd;
-                     size_t* vecoff = nullptr; int accumulate = 0; };
+                     size_t* vecoff = nullptr; int accumulate = 0;
+                     size_t* vecoff2 = nullptr; int64_t dst2 = -1; };   // second vector column set against the same X
   std::vector<GroupSpec> specs;
   const int Kb_pe = (h->PK + 31) / 32;          // posenc stash tiles hold whole 32-feature blocks
   const int PKS = Kb_pe * 32;
@@ -384,10 +385,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     GroupSpec gw = {lv, SRC_FRAG128, &L.w_st_h, FRAG_TILE_128, WARP_W, 4, 0, nullptr, 0, 0, 3,
                     w.w_k, 3, WARP_W, 3, 6, (size_t)(WARP_DEPTH - 1) * wl, 0};
     gw.vecoff = &L.w_dw4;
+    gw.vecoff2 = &L.w_dv4; gw.dst2 = w.v_k;   // both heads read h6: one pass over its stash
     push(gw);
-    GroupSpec gv = gw;
-    gv.dst = w.v_k; gv.vecoff = &L.w_dv4;
-    push(gv);
   };
   // bf16 training: the NeRF MLP groups go to the bf16 wgrad kernel (X / dY = bf16 stash buffers of Kb / Nb blocks per
   // 32-sample group); bias = the group also owns the bias gradient (column sums of its dY)
@@ -779,8 +778,16 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         g.slab_off = 0;
         r.src_off = g.vslab_off + (s.vec == 1 ? 3 : 0);
         r.src_ld = 4; r.part_stride = (int64_t)g.Kb * 32 * 4; r.nparts = 2 * g.nsplit;
+        g.vec2_off = -1;
+        if (s.vecoff2) {
+          g.vec2_off = (int64_t)*s.vecoff2;
+          g.vslab2_off = (int64_t)take((size_t)g.nsplit * 2 * g.Kb * 32 * 4);
+          ReduceDesc r2 = r;
+          r2.dst_off = s.dst2; r2.src_off = g.vslab2_off;
+          (r2.accumulate == 0 ? p.reduce : r2.accumulate == 1 ? reduce2 : r2.accumulate == 2 ? reduce3 : reduce4).push_back(r2);
+        }
       } else {
-        g.vec_off = -1; g.vslab_off = 0;
+        g.vec_off = -1; g.vslab_off = 0; g.vec2_off = -1;
         g.slab_off = (int64_t)take((size_t)g.nsplit * g.Kb * 32 * g.Nb * 32);
         r.src_off = g.slab_off; r.src_ld = g.Nb * 32; r.part_stride = (int64_t)g.Kb * 32 * g.Nb * 32; r.nparts = g.nsplit;
       }
@@ -808,7 +815,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       memset(&g, 0, sizeof(g));
       g.x_off = (int64_t)(*sp.xoff + sp.xadd); g.x_tile_stride = sp.Kb * BF_BLOCK_DW; g.Kb = sp.Kb; g.x_kvalid = sp.rows;
       g.dy_off = (int64_t)(*sp.yoff + sp.yadd); g.dy_tile_stride = sp.Nb * BF_BLOCK_DW; g.Nb = sp.Nb;
-      g.ntiles = p.L[sp.lv].b_ngroups; g.nsplit = bnsplit[i]; g.vec_off = -1;
+      g.ntiles = p.L[sp.lv].b_ngroups; g.nsplit = bnsplit[i]; g.vec_off = -1; g.vec2_off = -1;
       g.slab_off = (int64_t)take((size_t)g.nsplit * sp.Kb * 32 * sp.Nb * 32);
       g.vslab_off = sp.bias_dst >= 0 ? (int64_t)take((size_t)g.nsplit * sp.Nb * 32) : -1;
       p.bgroups.push_back(g);
@@ -831,7 +838,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
       const LevelWs& L = p.L[lv];
-      const int grid = p.ntiles[lv] < 2 * G ? p.ntiles[lv] : 2 * G;   // chain kernels: two workgroups per CU
+      int nt_mlp = 0;
+      for (int q = 0; q < h->nlevels; ++q) nt_mlp += p.ntiles[q];
+      const int grid = nt_mlp < 2 * G ? nt_mlp : 2 * G;   // ONE dgrad launch over the tiles of all levels, two workgroups per CU
       auto small = [&](int64_t dst, int cols, int sp_off) {
         if (bft) return;   // the bf16 wgrad kernel sums the bias columns itself
         ReduceDesc r;
@@ -852,9 +861,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         r.src_off = (int64_t)L.cond_grad; r.src_ld = 128; r.part_stride = 0; r.nparts = 1;
         p.reduce.push_back(r);
       }
-      if (h->warp) warp_bias_descs(lv, grid, lv > 0 ? 1 : 0);
+      if (h->warp && lv == 0) {   // ONE SE3 dgrad launch (coarse + fine + background tiles), one set of bias partials
+        const int nt_w = nt_mlp + (bgN > 0 ? p.ntiles[BG] : 0);
+        warp_bias_descs(0, nt_w < 2 * G ? nt_w : 2 * G, 0);
+      }
     }
-    if (h->warp && bgN > 0) warp_bias_descs(BG, p.ntiles[BG] < 2 * G ? p.ntiles[BG] : 2 * G, 2);
   }
   p.nreduce_pass[0] = (int)p.reduce.size();
   p.nreduce_pass[1] = (int)reduce2.size();
@@ -1004,6 +1015,7 @@ double warp_fwd_flops_row(nrf_handle h) {
   return 2.0 * (Wi * 128 + 3 * 16384.0 + (128 + Wi) * 128 + 16384.0 + 128 * 6);
 }
 double warp_dgrad_flops_row(nrf_handle h) { return 2.0 * (128 * 6 + 5 * 16384.0 + 2.0 * h->G * 128); }
+double warp_fwd_flops_row_or0(nrf_handle h) { return h->warp ? warp_fwd_flops_row(h) : 0.0; }
 double wgrad_flops_row(nrf_handle h) {
   const double P = h->P, R = h->R;
   return 2.0 * (2 * P * 256 + 7 * 65536.0 + 65536.0 + (256 + R) * 128 + 256 + 128 * 3);
@@ -1045,13 +1057,15 @@ void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_ray
   ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_FWD);
   const int tgrid = ta.ntiles < gmul * h->num_cus ? ta.ntiles : gmul * h->num_cus;
   h->prof.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[lv], stream);
-  launch_warp_fwd(ta, true, tgrid, stream);
+  launch_warp_fwd(ta, nullptr, true, tgrid, stream);
   h->prof.end(stream);
 }
 
+WarpFwdArgs bg_fwd_args(nrf_handle h, const float* params, const nrf_background* bg, float alpha, float* ws);
+
 int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
                  const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream, int bgN = 0,
-                 int elastic = 0) {
+                 int elastic = 0, const nrf_background* bg = nullptr) {
   CK(validate_rays(h, rays));
   if (!params_x || !ws) return fail(NRF_E_NULL, "params / workspace is null");
   query_device(h);
@@ -1073,7 +1087,8 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   if (!jac && out && (out->coarse.warp_jacobian || out->fine.warp_jacobian)) return fail(NRF_E_STATE, "warp_jacobian outputs need NRF_FLAG_WARP_JACOBIAN");
   CK(upload_tables(h, ws, stream));
   const char* tables = reinterpret_cast<const char*>(ws + p.tables);
-  if (hipMemsetAsync(ws + p.counters, 0, 64 * sizeof(int), stream) != hipSuccess) return fail(NRF_E_HIP, "zero tile counters");
+  if (tile_counter_or_null(ws + p.counters, 0) &&   // NRF_DYNAMIC_TILES experiment only
+      hipMemsetAsync(ws + p.counters, 0, 64 * sizeof(int), stream) != hipSuccess) return fail(NRF_E_HIP, "zero tile counters");
   const float* params = params_x;
   if (h->embed) {   // narrower model: run on its zero-padded image (nrf_internal.h EmbedDesc)
     if (hipMemsetAsync(ws + p.iparams, 0, (size_t)h->nparams * sizeof(float), stream) != hipSuccess) return fail(NRF_E_HIP, "zero padded params");
@@ -1128,8 +1143,15 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
     const int gmul = getenv("NRF_GRID_MUL") ? atoi(getenv("NRF_GRID_MUL")) : 2;
     const int grid = p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus;   // two workgroups per CU
     if (warp_on) {
-      pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * p.rows[lv], stream);
-      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train || jac), train || jac, grid, stream);
+      // the background-point batch of the fused train step rides in the coarse launch (its 256 tiles under-fill the chip)
+      const bool with_bg = lv == 0 && train && bg && p.bgN > 0;
+      WarpFwdArgs bga;
+      if (with_bg) bga = bg_fwd_args(h, params, bg, scalars->warp_alpha, ws);
+      const int wnt = p.ntiles[lv] + (with_bg ? p.ntiles[BG] : 0);
+      const int wgrid = wnt < gmul * h->num_cus ? wnt : gmul * h->num_cus;
+      pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * (p.rows[lv] + (with_bg ? p.bgN : 0)), stream);
+      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train || jac), with_bg ? &bga : nullptr,
+                      train || jac, wgrid, stream);
       pf.end(stream);
       a.points = ws + L.wpoints;
       // forward-mode Jacobian of the warp: on the coarse samples for the elastic regulariser (models.py:345), per level
@@ -1181,10 +1203,31 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   return NRF_OK;
 }
 
+// SE3 field on the (already noised) background points, one warp id per point (training.compute_background_loss,
+// training.py:117-135): forward arguments of the BG level
+WarpFwdArgs bg_fwd_args(nrf_handle h, const float* params, const nrf_background* bg, float alpha, float* ws) {
+  const WsPlan& p = h->plan;
+  const LevelWs& L = p.L[BG];
+  WarpFwdArgs fa;
+  memset(&fa, 0, sizeof(fa));
+  fa.params = params; fa.po = h->wpo; fa.wpk = ws + p.warp_wpk; fa.pk = h->wpk;
+  fa.points_in = bg->points; fa.point_ids = bg->warp_ids; fa.points_out = ws + L.wpoints;
+  fa.embed_table = params + h->wpo.embed;
+  fa.S = 1; fa.B = p.bgN; fa.rows = p.bgN; fa.ntiles = p.ntiles[BG];
+  fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = alpha;
+  fa.st_win = ws + L.w_st_win; fa.st_h = ws + L.w_st_h; fa.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
+  fa.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
+  return fa;
+}
+
 // d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
+// Launch order (round 3): the reverse passes of the two levels are independent, so every kernel type runs ONCE
+// over the tiles of all levels -- composite_bwd x levels, ONE NeRF-MLP dgrad launch (coarse + fine tiles), the regularisers'
+// point gradients, ONE SE3 dgrad launch (coarse + fine + background tiles), the tangent pass, then wgrad / reduce.
 int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const float* const d_rgb[2], const float* target,
                   float* grad_x, float* stats, float* ws, hipStream_t stream, const nrf_background* bg = nullptr,
-                  const nrf_step_scalars* scalars = nullptr, const nrf_elastic* el = nullptr, const nrf_warp_reg* wr = nullptr) {
+                  const nrf_step_scalars* scalars = nullptr, const nrf_elastic* el = nullptr, const nrf_warp_reg* wr = nullptr,
+                  bool bg_forward_done = false) {
   WsPlan& p = h->plan;
   const nrf_model_desc& d = h->d;
   const int B = p.B;
@@ -1194,34 +1237,38 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   // in the padded layout and copied out at the end
   const float* params = h->embed ? ws + p.iparams : params_x;
   float* grad = h->embed ? ws + p.igrad : grad_x;
-  hipError_t e = hipMemsetAsync(grad, 0, (size_t)h->nparams * sizeof(float), stream);
-  if (e != hipSuccess) return fail_hip(e, "zero grad");
-  e = hipMemsetAsync(ws + p.mse, 0, 64 * sizeof(float), stream);
-  if (e != hipSuccess) return fail_hip(e, "zero mse");
-  e = hipMemsetAsync(reinterpret_cast<int*>(ws + p.counters) + CT_MLP_BWD, 0, (64 - CT_MLP_BWD) * sizeof(int), stream);
-  if (e != hipSuccess) return fail_hip(e, "zero tile counters");
-  if (warp_on && h->time_enc) {
-    e = hipMemsetAsync(ws + p.t_dcodes, 0, (size_t)B * h->G * sizeof(float), stream);
-    if (e != hipSuccess) return fail_hip(e, "zero time-code gradient");
-  }
   const bool wr_on = wr && warp_on;
-  if (wr_on) {
-    e = hipMemsetAsync(ws + p.wr_sums, 0, 64 * sizeof(float), stream);
-    if (e != hipSuccess) return fail_hip(e, "zero warp_reg sums");
+  const bool bg_on = bg && p.bgN > 0;
+  const bool el_on = el && p.elastic && warp_on;
+  const bool bft = p.flags & NRF_FLAG_BF16;
+  {   // everything that is accumulated into, zeroed by one launch
+    ZeroArgs z;
+    memset(&z, 0, sizeof(z));
+    z.add(grad, h->nparams);
+    z.add(ws + p.mse, 64);
+    if (warp_on && h->time_enc) z.add(ws + p.t_dcodes, (long long)B * h->G);
+    if (wr_on) z.add(ws + p.wr_sums, 64);
+    if (el_on) z.add(ws + p.el_sums, 64);
+    if (bg_on) z.add(ws + p.bg_loss, 64);
+    for (int lv = 0; lv < h->nlevels; ++lv) z.add(ws + p.L[lv].dray, (long long)B * RGB_W);
+    launch_zero_ranges(z, stream);
   }
+  const int G2 = 2 * h->num_cus;   // chain kernels: two workgroups per CU
+  h->prof.begin("composite_bwd", 0, stream);
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
-    e = hipMemsetAsync(ws + L.dray, 0, (size_t)B * RGB_W * sizeof(float), stream);
-    if (e != hipSuccess) return fail_hip(e, "zero dray");
     const float loss_scale = 2.0f / (3.0f * (float)B);   // d/d rgb of mean over (B,3) (training.py:172)
-    h->prof.begin("composite_bwd", 0, stream);
     launch_composite_bwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
                          d.use_white_background, d.use_sample_at_infinity, d.sigma_activation, ws + L.rgb, target,
                          target ? nullptr : d_rgb[lv], loss_scale, reinterpret_cast<float4*>(ws + L.d_raw4),
                          p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, h->A > 0 ? ws + L.dsig_ray : nullptr, stream);
-    h->prof.end(stream);
-    const bool bft = p.flags & NRF_FLAG_BF16;
-    if (bft) {   // bf16 dgrad chain: dpre of every layer into the bf16 dY stash, then the per-ray condition sums
+  }
+  h->prof.end(stream);
+  double mlp_rows = 0;
+  for (int lv = 0; lv < h->nlevels; ++lv) mlp_rows += p.rows[lv];
+  if (bft) {   // bf16 dgrad chains: dpre of every layer into the bf16 dY stash, then the per-ray condition sums
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      const LevelWs& L = p.L[lv];
       ChainBwdBf16Args ba;
       memset(&ba, 0, sizeof(ba));
       ba.wpk = ws + L.bf_wpkT; ba.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
@@ -1236,86 +1283,122 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       h->prof.end(stream);
       launch_dray_bf16(ba.st.drgbh, B, p.S[lv], ws + L.dray, stream);
     }
-    ChainBwdArgs a;
-    memset(&a, 0, sizeof(a));
-    a.params = params; a.po = h->po[lv]; a.wpk = ws + L.wpk; a.pk = h->pk;
-    a.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
-    a.S = p.S[lv]; a.B = B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
-    a.bits_trunk = reinterpret_cast<const uint32_t*>(ws + L.bits_trunk);
-    a.bits_rgbh = reinterpret_cast<const uint32_t*>(ws + L.bits_rgbh);
-    a.dy_trunk = ws + L.dy_trunk; a.dy_bn = ws + L.dy_bn; a.dy_rgbh = ws + L.dy_rgbh; a.dray = ws + L.dray;
-    a.small_part = ws + L.small_part;
-    if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
-    a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
-    a.alpha_on_bn = h->A > 0 ? 1 : 0;
-    a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_BWD + lv);
-    const int grid = p.ntiles[lv] < 2 * h->num_cus ? p.ntiles[lv] : 2 * h->num_cus;   // two workgroups per CU
-    a.k_old = k_old_for(p.ntiles[lv], grid, h->num_cus, 0.0);
-    if (!bft) {
-      h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
-      launch_chain_bwd(a, grid, stream);
-      h->prof.end(stream);
+  } else {
+    ChainBwdArgs ca[2];
+    int nt_all = 0;
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      const LevelWs& L = p.L[lv];
+      ChainBwdArgs& a = ca[lv];
+      memset(&a, 0, sizeof(a));
+      a.params = params; a.po = h->po[lv]; a.wpk = ws + L.wpk; a.pk = h->pk;
+      a.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
+      a.S = p.S[lv]; a.B = B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
+      a.bits_trunk = reinterpret_cast<const uint32_t*>(ws + L.bits_trunk);
+      a.bits_rgbh = reinterpret_cast<const uint32_t*>(ws + L.bits_rgbh);
+      a.dy_trunk = ws + L.dy_trunk; a.dy_bn = ws + L.dy_bn; a.dy_rgbh = ws + L.dy_rgbh; a.dray = ws + L.dray;
+      a.small_part = ws + L.small_part;
+      if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
+      a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
+      a.alpha_on_bn = h->A > 0 ? 1 : 0;
+      nt_all += p.ntiles[lv];
     }
-    const bool el_on = el && p.elastic && warp_on && lv == 0;
-    if (el_on) {
-      const LevelWs& T = p.L[TG];
-      e = hipMemsetAsync(ws + p.el_sums, 0, 64 * sizeof(float), stream);
-      if (e != hipSuccess) return fail_hip(e, "zero elastic sums");
-      ElasticArgs ea;
-      memset(&ea, 0, sizeof(ea));
-      ea.prim_win = ws + L.w_st_win; ea.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
-      ea.tan_wv = reinterpret_cast<const float4*>(ws + T.w_st_wv); ea.coef = ws + L.weights;
-      if (el->reduce_method == NRF_ELASTIC_MEDIAN) {   // training.py:182-188
-        launch_median_coef(ws + L.weights, B, p.S[0], ws + p.el_coef, stream);
-        ea.coef = ws + p.el_coef; ea.res_selected = 1;
-      }
-      ea.tan_dw4 = reinterpret_cast<float4*>(ws + T.w_dw4); ea.tan_dv4 = reinterpret_cast<float4*>(ws + T.w_dv4);
-      ea.prim_dw4 = reinterpret_cast<float4*>(ws + L.el_dw4); ea.prim_dv4 = reinterpret_cast<float4*>(ws + L.el_dv4);
-      ea.sums = ws + p.el_sums;
-      ea.rows = p.rows[0]; ea.rows_pad = p.ntiles[0] * TILE_ROWS; ea.PKS = (h->PKw + 31) / 32 * 32;
-      ea.eps = el->eps; ea.alpha = el->loss_alpha; ea.scale = el->loss_scale; ea.gscale = el->loss_weight / (float)B;
-      ea.loss_type = el->loss_type;
-      h->prof.begin("elastic", 0, stream);
-      launch_elastic(ea, stream);
-      h->prof.end(stream);
+    h->prof.begin("mlp_dgrad", dgrad_flops_row(h, warp_on) * mlp_rows, stream);
+    launch_chain_bwd(ca[0], h->nlevels > 1 ? &ca[1] : nullptr, nt_all < G2 ? nt_all : G2, stream);
+    h->prof.end(stream);
+  }
+  if (el_on) {   // training.compute_elastic_loss on the coarse samples
+    const LevelWs& L = p.L[0];
+    const LevelWs& T = p.L[TG];
+    ElasticArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.prim_win = ws + L.w_st_win; ea.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+    ea.tan_wv = reinterpret_cast<const float4*>(ws + T.w_st_wv); ea.coef = ws + L.weights;
+    if (el->reduce_method == NRF_ELASTIC_MEDIAN) {   // training.py:182-188
+      launch_median_coef(ws + L.weights, B, p.S[0], ws + p.el_coef, stream);
+      ea.coef = ws + p.el_coef; ea.res_selected = 1;
     }
-    if (wr_on)   // use_warp_reg_loss (training.py:199-212): + d loss / d warped point at the median-depth sample of each ray
+    ea.tan_dw4 = reinterpret_cast<float4*>(ws + T.w_dw4); ea.tan_dv4 = reinterpret_cast<float4*>(ws + T.w_dv4);
+    ea.prim_dw4 = reinterpret_cast<float4*>(ws + L.el_dw4); ea.prim_dv4 = reinterpret_cast<float4*>(ws + L.el_dv4);
+    ea.sums = ws + p.el_sums;
+    ea.rows = p.rows[0]; ea.rows_pad = p.ntiles[0] * TILE_ROWS; ea.PKS = (h->PKw + 31) / 32 * 32;
+    ea.eps = el->eps; ea.alpha = el->loss_alpha; ea.scale = el->loss_scale; ea.gscale = el->loss_weight / (float)B;
+    ea.loss_type = el->loss_type;
+    h->prof.begin("elastic", 0, stream);
+    launch_elastic(ea, stream);
+    h->prof.end(stream);
+  }
+  if (wr_on)   // use_warp_reg_loss (training.py:199-212): + d loss / d warped point at the median-depth sample of each ray
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      const LevelWs& L = p.L[lv];
       launch_warp_reg(ws + L.weights, ws + L.points_raw, ws + L.wpoints, B, p.S[lv], wr->loss_alpha, wr->loss_scale,
                       wr->loss_weight / (float)B, ws + L.d_points, ws + p.wr_sums + 2 * lv, stream);
-    if (warp_on) {
-      WarpBwdArgs wa;
-      memset(&wa, 0, sizeof(wa));
-      wa.params = params; wa.po = h->wpo; wa.wpk = ws + p.warp_wpk; wa.pk = h->wpk;
-      wa.nt_prim = p.ntiles[lv];
-      wa.tile_counter = tile_counter_or_null(ws + p.counters, CT_WARP_BWD + lv);
-      if (el_on) { wa.extra_dw4 = reinterpret_cast<const float4*>(ws + L.el_dw4); wa.extra_dv4 = reinterpret_cast<const float4*>(ws + L.el_dv4); }
-      wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
-      wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
-      wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
-      wa.warp_ids = h->time_enc ? nullptr : rays->warp_ids;   // TimeEncoder: the code gradient is per ray
-      wa.S = p.S[lv]; wa.B = B; wa.rows = p.rows[lv]; wa.ntiles = p.ntiles[lv];
-      wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
-      wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
-      wa.grad_embed = h->time_enc ? ws + p.t_dcodes : grad + h->wpo.embed; wa.small_part = ws + L.w_small_part;
-      h->prof.begin(lv == 0 ? "warp_dgrad_coarse" : "warp_dgrad_fine", warp_dgrad_flops_row(h) * p.rows[lv], stream);
-      launch_warp_bwd(wa, grid, stream);
-      h->prof.end(stream);
-      if (el_on) {   // reverse of the tangent pass
-        const LevelWs& T = p.L[TG];
-        WarpBwdArgs ta = wa;
-        ta.tangent = 1; ta.nt_prim = p.ntiles[0]; ta.ntiles = p.ntiles[TG]; ta.rows = p.rows[TG];
-        ta.extra_dw4 = ta.extra_dv4 = nullptr;
-        ta.d_points = nullptr; ta.st_win = nullptr; ta.st_wv = nullptr;
-        ta.dy = ws + T.w_dy; ta.d_w4 = reinterpret_cast<float4*>(ws + T.w_dw4); ta.d_v4 = reinterpret_cast<float4*>(ws + T.w_dv4);
-        ta.small_part = nullptr;
-        ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_BWD);
-        const int tgrid = p.ntiles[TG] < 2 * h->num_cus ? p.ntiles[TG] : 2 * h->num_cus;
-        h->prof.begin("warp_tangent_dgrad", 3.0 * warp_dgrad_flops_row(h) * p.rows[0], stream);
-        launch_warp_bwd(ta, tgrid, stream);
-        h->prof.end(stream);
-      }
     }
-    h->prof.begin("cond_wgrad", 0, stream);
+  // ---- background regulariser (training.compute_background_loss, training.py:117-135): the SE3 field on the
+  //      (already noised) background points with one warp id per point; general loss of |x' - x|^2 ----
+  if (bg_on) {
+    const LevelWs& L = p.L[BG];
+    if (!bg_forward_done) {   // nrf_forward + nrf_backward path: the fused train step ran it inside the coarse warp launch
+      const int grid = p.ntiles[BG] < G2 ? p.ntiles[BG] : G2;
+      h->prof.begin("warp_fwd_bg", warp_fwd_flops_row(h) * p.bgN, stream);
+      launch_warp_fwd(bg_fwd_args(h, params, bg, scalars->warp_alpha, ws), nullptr, true, grid, stream);
+      h->prof.end(stream);
+    }
+    launch_background_loss(bg->points, ws + L.wpoints, p.bgN, p.ntiles[BG] * TILE_ROWS, bg->loss_alpha, bg->loss_scale,
+                           bg->loss_weight, ws + L.d_points, ws + p.bg_loss, stream);
+  }
+  if (warp_on) {
+    WarpBwdArgs wa[3];
+    int nlev = 0, nt_all = 0;
+    double rows_all = 0;
+    auto common = [&](WarpBwdArgs& w, int lv) {
+      const LevelWs& L = p.L[lv];
+      memset(&w, 0, sizeof(w));
+      w.params = params; w.po = h->wpo; w.wpk = ws + p.warp_wpk; w.pk = h->wpk;
+      w.nt_prim = p.ntiles[lv];
+      w.d_points = ws + L.d_points; w.st_win = ws + L.w_st_win;
+      w.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+      w.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
+      w.S = p.S[lv]; w.rows = p.rows[lv]; w.ntiles = p.ntiles[lv];
+      w.F = h->Fw; w.G = h->G; w.Win = h->Win; w.PKw = h->PKw;
+      w.dy = ws + L.w_dy; w.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); w.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
+      w.small_part = ws + p.L[0].w_small_part;   // one set of bias partials for the whole launch
+      nt_all += p.ntiles[lv]; rows_all += p.rows[lv];
+    };
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      WarpBwdArgs& w = wa[nlev++];
+      common(w, lv);
+      w.B = B;
+      w.warp_ids = h->time_enc ? nullptr : rays->warp_ids;   // TimeEncoder: the code gradient is per ray
+      w.grad_embed = h->time_enc ? ws + p.t_dcodes : grad + h->wpo.embed;
+      if (el_on && lv == 0) { w.extra_dw4 = reinterpret_cast<const float4*>(ws + p.L[0].el_dw4); w.extra_dv4 = reinterpret_cast<const float4*>(ws + p.L[0].el_dv4); }
+    }
+    if (bg_on) {
+      WarpBwdArgs& w = wa[nlev++];
+      common(w, BG);
+      w.B = p.bgN; w.S = 1;
+      w.point_ids = bg->warp_ids;
+      w.grad_embed = grad + h->wpo.embed;
+    }
+    h->prof.begin("warp_dgrad", warp_dgrad_flops_row(h) * rows_all, stream);
+    launch_warp_bwd(wa[0], nlev > 1 ? &wa[1] : nullptr, nlev > 2 ? &wa[2] : nullptr, nt_all < G2 ? nt_all : G2, stream);
+    h->prof.end(stream);
+    if (el_on) {   // reverse of the tangent pass
+      const LevelWs& T = p.L[TG];
+      WarpBwdArgs ta = wa[0];
+      ta.tangent = 1; ta.nt_prim = p.ntiles[0]; ta.ntiles = p.ntiles[TG]; ta.rows = p.rows[TG];
+      ta.extra_dw4 = ta.extra_dv4 = nullptr;
+      ta.d_points = nullptr; ta.st_win = nullptr; ta.st_wv = nullptr;
+      ta.dy = ws + T.w_dy; ta.d_w4 = reinterpret_cast<float4*>(ws + T.w_dw4); ta.d_v4 = reinterpret_cast<float4*>(ws + T.w_dv4);
+      ta.small_part = nullptr;
+      const int tgrid = p.ntiles[TG] < G2 ? p.ntiles[TG] : G2;
+      h->prof.begin("warp_tangent_dgrad", 3.0 * warp_dgrad_flops_row(h) * p.rows[0], stream);
+      launch_warp_bwd(ta, nullptr, nullptr, tgrid, stream);
+      h->prof.end(stream);
+    }
+  }
+  h->prof.begin("cond_wgrad", 0, stream);
+  for (int lv = 0; lv < h->nlevels; ++lv) {
+    const LevelWs& L = p.L[lv];
     launch_cond_wgrad(ws + p.cond, ws + L.dray, B, h->R, ws + L.cond_grad, stream);
     launch_cond_embed_grad(params, ws + L.dray, rays->appearance_ids, rays->camera_ids, B, h->V,
                            h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
@@ -1323,8 +1406,8 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     if (h->A > 0)   // appearance-code rows of the alpha head and the codes' gradient through it (modules.py:152-157)
       launch_alpha_cond_grad(params, ws + p.cond, ws + L.dsig_ray, rays->appearance_ids, B, h->R, h->V, h->A, h->app_off,
                              h->po[lv].alpha_k, grad, stream);
-    h->prof.end(stream);
   }
+  h->prof.end(stream);
   if (warp_on && h->time_enc) {   // reverse of the TimeEncoder: d codes -> its six layers' weight gradients
     TimeEncArgs ta;
     memset(&ta, 0, sizeof(ta));
@@ -1333,51 +1416,12 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     launch_time_encoder_bwd(ta, stream);
     launch_time_encoder_wgrad(ta, grad, stream);
   }
-  // ---- background regulariser (training.compute_background_loss, training.py:117-135): the SE3 field on the
-  //      (already noised) background points with one warp id per point; general loss of |x' - x|^2 ----
-  const bool bg_on = bg && p.bgN > 0;
-  if (bg_on) {
-    const LevelWs& L = p.L[BG];
-    const int grid = p.ntiles[BG] < 2 * h->num_cus ? p.ntiles[BG] : 2 * h->num_cus;
-    WarpFwdArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    fa.params = params; fa.po = h->wpo; fa.wpk = ws + p.warp_wpk; fa.pk = h->wpk;
-    fa.points_in = bg->points; fa.point_ids = bg->warp_ids; fa.points_out = ws + L.wpoints;
-    fa.embed_table = params + h->wpo.embed;
-    fa.S = 1; fa.B = p.bgN; fa.rows = p.bgN; fa.ntiles = p.ntiles[BG];
-    fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = scalars->warp_alpha;
-    fa.st_win = ws + L.w_st_win; fa.st_h = ws + L.w_st_h; fa.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
-    fa.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
-    fa.tile_counter = tile_counter_or_null(ws + p.counters, CT_BG_FWD);
-    h->prof.begin("warp_fwd_bg", warp_fwd_flops_row(h) * p.bgN, stream);
-    launch_warp_fwd(fa, true, grid, stream);
-    h->prof.end(stream);
-    e = hipMemsetAsync(ws + p.bg_loss, 0, 64 * sizeof(float), stream);
-    if (e != hipSuccess) return fail_hip(e, "zero bg loss");
-    launch_background_loss(bg->points, ws + L.wpoints, p.bgN, p.ntiles[BG] * TILE_ROWS, bg->loss_alpha, bg->loss_scale,
-                           bg->loss_weight, ws + L.d_points, ws + p.bg_loss, stream);
-    WarpBwdArgs wa;
-    memset(&wa, 0, sizeof(wa));
-    wa.params = params; wa.po = h->wpo; wa.wpk = ws + p.warp_wpk; wa.pk = h->wpk;
-    wa.d_points = ws + L.d_points; wa.st_win = ws + L.w_st_win;
-    wa.st_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
-    wa.bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
-    wa.point_ids = bg->warp_ids;
-    wa.nt_prim = p.ntiles[BG];
-    wa.tile_counter = tile_counter_or_null(ws + p.counters, CT_BG_BWD);
-    wa.S = 1; wa.B = p.bgN; wa.rows = p.bgN; wa.ntiles = p.ntiles[BG];
-    wa.F = h->Fw; wa.G = h->G; wa.Win = h->Win; wa.PKw = h->PKw;
-    wa.dy = ws + L.w_dy; wa.d_w4 = reinterpret_cast<float4*>(ws + L.w_dw4); wa.d_v4 = reinterpret_cast<float4*>(ws + L.w_dv4);
-    wa.grad_embed = grad + h->wpo.embed; wa.small_part = ws + L.w_small_part;
-    h->prof.begin("warp_dgrad_bg", warp_dgrad_flops_row(h) * p.bgN, stream);
-    launch_warp_bwd(wa, grid, stream);
-    h->prof.end(stream);
-  }
-  double wg_rows = 0;
-  for (int lv = 0; lv < h->nlevels; ++lv) wg_rows += p.rows[lv];
-  const bool bft_any = p.flags & NRF_FLAG_BF16;
+  double wg_rows = mlp_rows;
+  // the SE3 groups also run over the background rows and, with the elastic regulariser, over the three tangent rows per
+  // coarse sample (warping.py:385-387 jacfwd): algorithmic work of the step, counted
+  double warp_wg_rows = warp_on ? mlp_rows + (bg_on ? p.bgN : 0) + (el_on ? 3.0 * p.rows[0] : 0.0) : 0.0;
   if (!p.segs.empty()) {
-    h->prof.begin("wgrad", ((bft_any ? 0.0 : wgrad_flops_row(h)) + (warp_on ? warp_fwd_flops_row(h) : 0.0)) * wg_rows, stream);
+    h->prof.begin("wgrad", (bft ? 0.0 : wgrad_flops_row(h)) * wg_rows + warp_fwd_flops_row_or0(h) * warp_wg_rows, stream);
     launch_wgrad(reinterpret_cast<const WgradGroup*>(tables + p.groups_off_b),
                  reinterpret_cast<const WgradSegment*>(tables + p.segs_off_b),
                  reinterpret_cast<const int*>(tables + p.segbegin_off_b), p.wgrad_nwg, ws,
@@ -1396,17 +1440,16 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   for (int pass = 0, at = 0; pass < 4; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
     if (p.nreduce_pass[pass] > 0) launch_reduce(rd + at, p.nreduce_pass[pass], ws, grad, stream);
   if (h->embed) {
-    e = hipMemsetAsync(grad_x, 0, (size_t)h->xnparams * sizeof(float), stream);
+    hipError_t e = hipMemsetAsync(grad_x, 0, (size_t)h->xnparams * sizeof(float), stream);
     if (e != hipSuccess) return fail_hip(e, "zero grad");
     launch_embed(reinterpret_cast<const EmbedDesc*>(tables + p.emb_off_b), (int)h->emb.size(), grad, grad_x, false, stream);
   }
-  const bool el_any = el && p.elastic && warp_on;
   if (stats) {
     StatsArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.mse_sums = ws + p.mse; sa.B = B;
     if (bg_on) { sa.bg_sum = ws + p.bg_loss; sa.bgN = p.bgN; sa.bg_weight = bg->loss_weight; }
-    if (el_any) {
+    if (el_on) {
       sa.el_sums = ws + p.el_sums; sa.el_rows = el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]; sa.el_jac_rows = p.rows[0];
       sa.el_weight = el->loss_weight;
     }
@@ -1568,10 +1611,10 @@ int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_ray
     bgN = bg->num_points;
   }
   CK(forward_impl(h, params, rays, scalars, rnd, nullptr, NRF_FLAG_TRAIN | flags, (float*)workspace, workspace_bytes,
-                  (hipStream_t)stream, bgN, el ? 1 : 0));
+                  (hipStream_t)stream, bgN, el ? 1 : 0, bgN > 0 ? bg : nullptr));
   const float* dr[2] = {nullptr, nullptr};
   return backward_impl(h, params, rays, dr, target_rgb, grad_params, stats, (float*)workspace, (hipStream_t)stream,
-                       bgN > 0 ? bg : nullptr, scalars, el, wr);
+                       bgN > 0 ? bg : nullptr, scalars, el, wr, /*bg_forward_done=*/bgN > 0);
 }
 
 int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32_t num_background_points,
@@ -1669,7 +1712,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   e = hipMemsetAsync(ws + q.ctr_f, 0, 16 * sizeof(int), st);
   if (e != hipSuccess) return fail_hip(e, "zero tile counter");
   a.tile_counter = tile_counter_or_null(ws + q.ctr_f, 0);
-  launch_warp_fwd(a, false, grid, st);
+  launch_warp_fwd(a, nullptr, false, grid, st);
   e = hipMemcpyAsync(warped, ws + q.out_f, (size_t)num_points * 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return fail_hip(e, "copy warped points");
   return check_launch("nrf_warp_points");

@@ -282,8 +282,10 @@ struct WgradTask {
   int tile_begin, tile_end;
   float* slab;     // [Kb*32][Nb*32]
   // optional narrow dY columns done on the VALU: vec[row] = float4 (d raw rgb, d raw sigma);
-  // vslab[2][Kb*32][4] (two row halves) accumulates X^T vec.
+  // vslab[2][Kb*32][4] (two row halves) accumulates X^T vec.  vec2 / vslab2: a second vector against the same X
+  // (SE3 heads: dL/dw and dL/dv both multiply h6) or nullptr.
   const float4* vec; float* vslab;
+  const float4* vec2; float* vslab2;
 };
 
 // A layer's wgrad GEMM, cut into `nsplit` tasks of `tiles_per` tiles.  Offsets are in floats
@@ -291,6 +293,7 @@ struct WgradTask {
 struct WgradGroup {
   int64_t x_off, dy_off, slab_off;
   int64_t vec_off, vslab_off;     // vec_off < 0: no vector columns
+  int64_t vec2_off, vslab2_off;   // vec2_off < 0: no second vector
   int x_kind, x_tile_stride, x_kvalid, Kb;
   int dy_kind, dy_tile_stride, Nb;
   int ntiles, nsplit, tiles_per, first_task;
@@ -323,9 +326,12 @@ struct PackDesc {
 // ---- launchers (all asynchronous on `stream`) ----
 void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
-void launch_chain_bwd(const ChainBwdArgs& a, int grid, hipStream_t stream);
-void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream);
-void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream);
+// a1 (optional): the fine level, run by the same launch (tiles [a0.ntiles, a0.ntiles + a1->ntiles))
+void launch_chain_bwd(const ChainBwdArgs& a0, const ChainBwdArgs* a1, int grid, hipStream_t stream);
+// a1 (optional): a second level in the same launch (background points behind the coarse samples)
+void launch_warp_fwd(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int grid, hipStream_t stream);
+// a1, a2 (optional): further levels in the same launch; bias partials of all levels go to a.small_part
+void launch_warp_bwd(const WarpBwdArgs& a, const WarpBwdArgs* a1, const WarpBwdArgs* a2, int grid, hipStream_t stream);
 void launch_elastic(const ElasticArgs& a, hipStream_t stream);
 void launch_jacobian(const JacobianArgs& a, hipStream_t stream);
 void launch_median_coef(const float* weights, int B, int S, float* coef, hipStream_t stream);
@@ -388,6 +394,14 @@ struct StatsArgs {
 void launch_finish_stats(const StatsArgs& a, hipStream_t stream);
 void launch_background_loss(const float* points, const float* warped, int N, int rows_pad, float alpha, float scale,
                             float weight, float* d_points, float* loss_sum, hipStream_t stream);
+// zero-fills up to 8 float ranges in one launch (16-byte aligned pointers)
+struct ZeroArgs {
+  float* p[8];
+  long long n[8];
+  int count;
+  void add(float* ptr, long long nfloats) { if (nfloats > 0 && count < 8) { p[count] = ptr; n[count] = nfloats; ++count; } }
+};
+void launch_zero_ranges(const ZeroArgs& a, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
                  double b2, double eps, int64_t step, double gscale, hipStream_t stream);
 

@@ -595,6 +595,23 @@ void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double
                      (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, c1, c2, (float)gscale);
 }
 
+// One launch instead of a hipMemsetAsync per buffer (round 2: seven fillBufferAligned launches per training step): range r =
+// blockIdx.y; pointers are 16-byte aligned, the tail past the last float4 is written by scalar stores.
+__global__ __launch_bounds__(256) void zero_ranges_kernel(const ZeroArgs A) {
+  float* __restrict__ p = A.p[blockIdx.y];
+  const long long n = A.n[blockIdx.y];
+  const long long n4 = n >> 2;
+  float4* __restrict__ p4 = reinterpret_cast<float4*>(p);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x)
+    p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[4 * n4 + threadIdx.x] = 0.f;
+}
+
+void launch_zero_ranges(const ZeroArgs& a, hipStream_t stream) {
+  if (a.count <= 0) return;
+  hipLaunchKernelGGL(zero_ranges_kernel, dim3(64, a.count), dim3(256), 0, stream, a);
+}
+
 namespace {
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedDesc* __restrict__ descs, const float* __restrict__ src,
                                                     float* __restrict__ dst, int to_internal) {

@@ -122,8 +122,7 @@ __device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, 
 // tangent of primal tile t along coordinate c through the trunk (no biases, ReLU derivative = the primal
 // sign bits) and emits (dw/dx_c, dv/dx_c) per row; exp_se3's part of the Jacobian is applied by elastic_kernel.
 template <bool STASH, bool TANGENT>
-__global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int tile, float* smem) {
   float* act = smem;                  // [128][64] swizzled
   float* win = smem + WACT_FLOATS;    // [PKw][64] trunk input; reused as scratch after the skip layer
   const int tid = threadIdx.x;
@@ -135,9 +134,7 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
   const int PKS = (PKw + 31) / 32 * 32;
   const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
   const size_t st_layer = (size_t)A.ntiles * FRAG_TILE_128;
-
-  int* tslot = reinterpret_cast<int*>(win);   // free between tiles
-  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
+  {
     // ---- prologue: sample point, AnnealedSinusoidalEncoder (modules.py:231-294), GLO code ----
     float x[3] = {0.f, 0.f, 0.f};
     const int row = tile * TILE_ROWS + p;
@@ -298,15 +295,34 @@ __global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs 
   }
 }
 
-void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t stream) {
+// Global tiles [0, nt0) belong to level 0, [nt0, ntot) to level 1 (dealt round-robin): the 256 tiles of the background-point
+// batch (training.py:117-135) under-fill the chip on their own (warp_fwd_bg ran at 59 TF in round 2), so they ride in the
+// launch of the coarse samples; same field, same packed weights.  The level's arguments are indexed in the kernarg segment
+// (scalar loads; one copy of the tile code).
+struct WarpFwdArgs2 { WarpFwdArgs a[2]; int nt0, ntot; };
+template <bool STASH, bool TANGENT>
+__global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs2 P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int nt0 = P.nt0, ntot = P.ntot;
+#pragma unroll 1
+  for (int g = blockIdx.x; g < ntot; g += gridDim.x) {
+    const int lv = g >= nt0 ? 1 : 0;
+    warp_fwd_tile<STASH, TANGENT>(P.a[lv], g - (lv ? nt0 : 0), smem);
+  }
+}
+
+void launch_warp_fwd(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int grid, hipStream_t stream) {
   const int pk = a.PKw < 32 ? 32 : a.PKw;   // the head scratch needs 24 rows
   const size_t lds = (size_t)(WACT_FLOATS + pk * TILE_ROWS) * sizeof(float);
   const void* fn = a.prim_win ? (const void*)se3_warp_fwd_kernel<true, true>
                               : stash ? (const void*)se3_warp_fwd_kernel<true, false> : (const void*)se3_warp_fwd_kernel<false, false>;
   (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (a.prim_win) hipLaunchKernelGGL((se3_warp_fwd_kernel<true, true>), dim3(grid), dim3(256), lds, stream, a);
-  else if (stash) hipLaunchKernelGGL((se3_warp_fwd_kernel<true, false>), dim3(grid), dim3(256), lds, stream, a);
-  else hipLaunchKernelGGL((se3_warp_fwd_kernel<false, false>), dim3(grid), dim3(256), lds, stream, a);
+  WarpFwdArgs2 p;
+  p.a[0] = a; p.a[1] = a1 ? *a1 : a;
+  p.nt0 = a.ntiles; p.ntot = p.nt0 + (a1 ? a1->ntiles : 0);
+  if (a.prim_win) hipLaunchKernelGGL((se3_warp_fwd_kernel<true, true>), dim3(grid), dim3(256), lds, stream, p);
+  else if (stash) hipLaunchKernelGGL((se3_warp_fwd_kernel<true, false>), dim3(grid), dim3(256), lds, stream, p);
+  else hipLaunchKernelGGL((se3_warp_fwd_kernel<false, false>), dim3(grid), dim3(256), lds, stream, p);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -315,12 +331,14 @@ void launch_warp_fwd(const WarpFwdArgs& a, bool stash, int grid, hipStream_t str
 // TANGENT: reverse of the tangent pass: starts from dL/d(dw/dx_c), dL/d(dv/dx_c) (written by elastic_kernel into
 // d_w4 / d_v4), same masks as the primal tile, no bias / GLO-code gradients (the tangent input does not depend
 // on them); its dY stash feeds the wgrad kernel together with the tangent activations.
+struct WarpBwdAcc { float db[WARP_DEPTH]; float hsum[6]; };   // hsum: threads < 64, column sums of (dw, dv)
+
 template <bool TANGENT>
-__global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs A) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+__device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int tile, float* smem, WarpBwdAcc& C) {
   float* act = smem;                       // [128][64] swizzled: current dpre tile
   float* dwv = smem + WACT_FLOATS;         // [8][64]: dL/dw (0..2), dL/dv (3..5) of the tile rows
   float* dcs = dwv + 8 * TILE_ROWS;        // [8][64]: dL/dcode of the tile rows
+  int* ids_s = reinterpret_cast<int*>(dcs + 8 * TILE_ROWS);   // [64]: warp id of the tile rows (-1: padding)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -331,15 +349,9 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
   const size_t layer_fl = (size_t)A.ntiles * FRAG_TILE_128;
   const int PKS = (A.PKw + 31) / 32 * 32;
   const int n = wave * 32 + j;             // this lane's trunk column
-
-  float db[WARP_DEPTH];
-#pragma unroll
-  for (int l = 0; l < WARP_DEPTH; ++l) db[l] = 0.f;
-  float hsum[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // threads < 64: column sums of (dw, dv)
-
-  int* tslot = reinterpret_cast<int*>(dwv);   // free between tiles
-#pragma unroll 1
-  for (int tile = next_tile(A.tile_counter, tslot); tile < A.ntiles; tile = next_tile(A.tile_counter, tslot, tile)) {
+  float (&db)[WARP_DEPTH] = C.db;
+  float (&hsum)[6] = C.hsum;
+  {
     const int tprim = TANGENT ? tile % A.nt_prim : tile;
     // ---- exp_se3 VJP per row ----
     if (TANGENT) {
@@ -452,36 +464,73 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
         if (q == l - 1) db[q] += bsum;
       __syncthreads();
     }
-    if (TANGENT) continue;
+    if (TANGENT) return;
     code_grad(A.po.trunk_k[0] + (int64_t)(3 + 6 * A.F) * WARP_W);
 
-    // ---- per-ray sums of d code -> scatter-add into the embedding-table gradient ----
+    // ---- sums of d code over the rows of the tile that share a warp id -> scatter-add into the embedding-table
+    //      gradient.  One atomic per (distinct id of the tile, code): the background batch carries a random id per point
+    //      (training.py:121-123), where summing runs of equal ids sent 64 x G atomics per tile to a table of a few rows
+    //      (same-address device atomics serialise at ~12 ns: round 2's warp_dgrad_bg spent more time there than in its
+    //      MFMAs).  Thread (g, q): if row q is the first of the tile with its id, it owns that id's sum. ----
 #pragma unroll
     for (int q = 0; q < 2; ++q) dcs[(2 * part + q) * TILE_ROWS + p] = dcode[q];
+    if (tid < TILE_ROWS) {
+      const int grow = tile * TILE_ROWS + tid;
+      int id = -1;
+      if (grow < A.rows) id = A.point_ids ? A.point_ids[grow] : A.warp_ids ? A.warp_ids[grow / A.S] : grow / A.S;
+      ids_s[tid] = id;
+    }
     __syncthreads();
-    if (tid < 64) {
-      const int g = tid & 7, sect = tid >> 3;      // 8 codes x 8 sections of 8 rows
-      if (g < A.G) {
-        const int row0 = 8 * sect;
-        const int nvalid = A.rows - tile * TILE_ROWS;
-        float s = 0.f;
-        int cur = -1;
-        for (int q = row0; q < row0 + 8 && q < nvalid; ++q) {
-          const int grow = tile * TILE_ROWS + q;
-          const int id = A.point_ids ? A.point_ids[grow] : A.warp_ids ? A.warp_ids[grow / A.S] : grow / A.S;
-          if (id != cur) {
-            if (cur >= 0 && s != 0.f) atomicAdd(A.grad_embed + (size_t)cur * A.G + g, s);
-            s = 0.f; cur = id;
+    {
+      const int g = tid & 7;
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        const int q = (tid >> 3) + 32 * half;
+        const int id = ids_s[q];
+        if (g < A.G && id >= 0) {
+          bool leader = true;
+          for (int e = 0; e < q; ++e) leader = leader && ids_s[e] != id;
+          if (leader) {
+            float sm = 0.f;
+            for (int e = q; e < TILE_ROWS; ++e) sm += ids_s[e] == id ? dcs[g * TILE_ROWS + e] : 0.f;
+            if (sm != 0.f) atomicAdd(A.grad_embed + (size_t)id * A.G + g, sm);
           }
-          s += dcs[g * TILE_ROWS + q];
         }
-        if (cur >= 0 && s != 0.f) atomicAdd(A.grad_embed + (size_t)cur * A.G + g, s);
       }
     }
     __syncthreads();
   }
+}
 
+// Global tiles [0, n0) are level 0 (coarse samples), [n0, n01) level 1 (fine samples), [n01, ntot) level 2 (background
+// points): ONE launch for the three reverse passes through the shared field (round 2: three launches at 72 / 83 / 24 TF).
+// The bias partials of all levels add up in the workgroup's registers and are flushed once (the leaves are shared).
+struct WarpBwdArgs3 { WarpBwdArgs a[3]; int n0, n01, ntot; };
+template <bool TANGENT>
+__global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs3 P) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* dwv = smem + WACT_FLOATS;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int n = wave * 32 + j;
+  const int n0 = P.n0, n01 = P.n01, ntot = P.ntot;
+  WarpBwdAcc C;
+#pragma unroll
+  for (int l = 0; l < WARP_DEPTH; ++l) C.db[l] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 6; ++c) C.hsum[c] = 0.f;
+#pragma unroll 1
+  for (int g = blockIdx.x; g < ntot; g += gridDim.x) {
+    const int lv = g < n0 ? 0 : g < n01 ? 1 : 2;
+    warp_bwd_tile<TANGENT>(P.a[lv], g - (lv == 0 ? 0 : lv == 1 ? n0 : n01), smem, C);
+  }
   if (TANGENT) return;
+  const WarpBwdArgs& A = P.a[0];
+  const float (&db)[WARP_DEPTH] = C.db;
+  const float (&hsum)[6] = C.hsum;
+  __syncthreads();
   // ---- flush the per-workgroup bias partials ----
   float* sp = A.small_part + (size_t)blockIdx.x * WARP_SMALL_PART;
 #pragma unroll
@@ -502,14 +551,17 @@ __global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs 
   }
 }
 
-void launch_warp_bwd(const WarpBwdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)(WACT_FLOATS + 16 * TILE_ROWS) * sizeof(float);
+void launch_warp_bwd(const WarpBwdArgs& a, const WarpBwdArgs* a1, const WarpBwdArgs* a2, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)(WACT_FLOATS + 17 * TILE_ROWS) * sizeof(float);
+  WarpBwdArgs3 p;
+  p.a[0] = a; p.a[1] = a1 ? *a1 : a; p.a[2] = a2 ? *a2 : a;
+  p.n0 = a.ntiles; p.n01 = p.n0 + (a1 ? a1->ntiles : 0); p.ntot = p.n01 + (a2 ? a2->ntiles : 0);
   if (a.tangent) {
     (void)hipFuncSetAttribute((const void*)se3_warp_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(se3_warp_bwd_kernel<true>, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(se3_warp_bwd_kernel<true>, dim3(grid), dim3(256), lds, stream, p);
   } else {
     (void)hipFuncSetAttribute((const void*)se3_warp_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(se3_warp_bwd_kernel<false>, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(se3_warp_bwd_kernel<false>, dim3(grid), dim3(256), lds, stream, p);
   }
 }
 

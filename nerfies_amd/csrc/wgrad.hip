@@ -10,36 +10,49 @@
 // LDS with global_load_lds (1 KiB per wave instruction, no staging registers, no ds_write, no
 // swizzle) and read back as MFMA operands with conflict-free ds_read_b128: the float4 a lane
 // receives is 4 consecutive rows = the k of 4 MFMA steps, identical for X and dY.
-// Double buffered, one barrier per chunk.  Partials go to slabs, summed by reduce_kernel.
+//
+// Operand ring (round 3): a chunk (32 rows of X and dY) is (Kb + Nb) x 4 KiB -- 64 KiB for a 256 x 256 layer but only
+// 32 / 24 KiB for the 128 x 128 and 64 x 128 groups of the SE3 trunk, whose 32 (16) MFMAs per wave and chunk are over in
+// ~1.7 us: with two stages the copies of the next chunk were issued one chunk ahead, less than the HBM latency under load,
+// and those groups ran latency-bound at a third of the wide groups' rate.  The ring now always fills the CU's 160 KiB:
+// RING = 2 stages for 8 x 8 blocks up to 6 for 2 x 4, all but one in flight (s_waitcnt vmcnt(N) counts the copies of the
+// later chunks), one barrier per chunk.  Partials go to slabs, summed by reduce_kernel.
 #include "nrf_internal.h"
+#include "lds_dma.h"
 
 namespace nrf {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int WG_OPER = 256 * 32;             // floats per operand per stage (256 features x 32 rows)
-constexpr int WG_STAGE = 2 * WG_OPER;
-constexpr int WG_VEC = 2 * WG_STAGE;          // float offset of the [2 stages][32 rows] float4 vec staging
-constexpr int WG_VSTRIDE = 256;               // floats per vec stage (one 1 KiB global_load_lds)
-constexpr int WG_LDS_FLOATS = WG_VEC + 2 * WG_VSTRIDE;
+constexpr int WG_LDS_BYTES = 160 * 1024;      // the whole LDS of a CU: one workgroup per CU
+constexpr int WG_PIECE = 256;                 // floats per 1 KiB copy piece (one wave instruction)
 
-typedef __attribute__((address_space(3))) void lds_void;
-
-// cache policy of the streamed operand copies (aux immediate: 1 = sc0, 2 = nt, 16 = sc1): every byte is read exactly once
+// cache policy of the streamed operand copies: non-temporal (every byte is read exactly once); NRF_WGRAD_AUX=0: default policy
 #ifndef NRF_WGRAD_AUX
 #define NRF_WGRAD_AUX 2
 #endif
+constexpr bool WG_NT = NRF_WGRAD_AUX == 2;
 
-// Issues this wave's share of the global->LDS copies of chunk `c` (32 rows) of one operand tile:
-// pieces (blk, qq), blk < nblocks, qq < 4; piece id = blk*4 + qq is dealt round-robin to the 8 waves.
-__device__ __forceinline__ void stage_operand(const float* __restrict__ tile_base, int nblocks, int c, float* lds_oper,
-                                              int wave, int lane) {
-  const int npieces = nblocks * 4;
-  for (int pid = wave; pid < npieces; pid += 8) {
-    const int blk = pid >> 2, qq = pid & 3;
-    const float* src = tile_base + ((size_t)(blk * 8 + 4 * c + qq) * 64 + lane) * 4;
-    float* dst = lds_oper + pid * 256;   // wave-uniform base; the hardware adds lane * 16 bytes
-    __builtin_amdgcn_global_load_lds(src, (lds_void*)dst, 16, 0, NRF_WGRAD_AUX);
+template <int N>
+__device__ __forceinline__ void wait_vm() { wait_vmcnt<N>(); }
+
+// Issues this wave's CPW copies of chunk `c` (32 rows) of one tile into the stage at `buf`: pieces p < 4 Kb are X (block
+// p >> 2, quarter p & 3), the rest dY; piece p lands at buf + p * 1 KiB and is dealt round-robin to the 8 waves.  Every
+// wave issues exactly CPW copies (the tail re-copies the last piece) so that one vmcnt count fits all waves.  The copies are
+// asm statements (lds_dma.h): hipcc must not count them, or it drains the ring in front of the operand reads.
+template <int CPW>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ xt, int Kb, const float* __restrict__ yt, int Nb, int c,
+                                            unsigned buf, int wave, int lane) {
+  const int npx = Kb * 4, np = (Kb + Nb) * 4;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    int p = wave + 8 * i;
+    p = p < np ? p : np - 1;
+    const bool isy = p >= npx;
+    const int pp = isy ? p - npx : p;
+    const int blk = pp >> 2, qq = pp & 3;
+    const float* src = (isy ? yt : xt) + ((size_t)(blk * 8 + 4 * c + qq) * 64 + lane) * 4;
+    lds_dma16<WG_NT>(src, buf + p * (WG_PIECE * 4));   // wave-uniform LDS base; the hardware adds lane * 16 bytes
   }
 }
 
@@ -77,7 +90,9 @@ __device__ __forceinline__ void wgrad_compute(f32x16 (&acc)[NRB][2], const float
   }
 }
 
-template <int NRB>
+// NRB x 2 output blocks per wave, CPW copies per wave and chunk (= ceil(4 (Kb + Nb) / 8)), RING stages of
+// 4 (Kb + Nb) KiB (RING x stage <= 160 KiB).
+template <int NRB, int CPW, int RING>
 __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int kb0, int nb0) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,24 +104,27 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
 
+  const int stage_floats = (T.Kb + T.Nb) * 4 * WG_PIECE;
   const int nchunks = (T.tile_end - T.tile_begin) * 2;
+  const unsigned smem_b = lds_byte_addr(smem);
   auto stage = [&](int ci) {
-    const int tile = T.tile_begin + (ci >> 1), c = ci & 1;
-    float* Xs = smem + (ci & 1) * WG_STAGE;
-    stage_operand(T.X + (size_t)tile * T.x_tile_stride, T.Kb, c, Xs, wave, lane);
-    stage_operand(T.dY + (size_t)tile * T.dy_tile_stride, T.Nb, c, Xs + WG_OPER, wave, lane);
+    const int tile = T.tile_begin + (ci >> 1);
+    stage_chunk<CPW>(T.X + (size_t)tile * T.x_tile_stride, T.Kb, T.dY + (size_t)tile * T.dy_tile_stride, T.Nb, ci & 1,
+                     smem_b + (unsigned)((ci % RING) * stage_floats * 4), wave, lane);
   };
   const bool active = kb0 < T.Kb;   // narrow K (Kb < number of k wave groups): surplus waves only stage
 
-  if (nchunks > 0) stage(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage(c);
   for (int ci = 0; ci < nchunks; ++ci) {
-    if (ci + 1 < nchunks) stage(ci + 1);
-    const float* Xs = smem + (ci & 1) * WG_STAGE;
-    if (active) wgrad_compute<NRB>(acc, Xs, Xs + WG_OPER, kb0, nb0, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's copies of the next chunk have landed
-    __syncthreads();
+    if (ci + RING - 2 <= nchunks - 1) wait_vm<(RING - 2) * CPW>();   // chunk ci has landed, RING - 2 later ones may fly
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();     // ... for every wave, and nobody still reads the stage refilled next
+    asm volatile("" ::: "memory");
+    if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
+    if (active) {
+      const float* Xs = smem + (ci % RING) * stage_floats;
+      wgrad_compute<NRB>(acc, Xs, Xs + T.Kb * 4 * WG_PIECE, kb0, nb0, lane);
+    }
   }
   if (!active) return;
 
@@ -125,31 +143,39 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int 
 
 // Vector-column task (Nb == 0): vslab[kk][k][c] = sum_rows X[row][k] * vec[row][c] -- the weight
 // gradients of the narrow heads (alpha: X = h8, vec.w ; rgb logits: X = rgb hidden, vec.xyz ;
-// SE3 w / v heads).  Thread (k = feature, kk): its float4s of a staged chunk are rows
-// 4g..4g+3 with g = (qq&1) + 2 kk + 4 (qq>>1) of the chunk.
+// SE3 w and v heads: X = h6 read ONCE against vec = dL/dw and vec2 = dL/dv).  Thread (k = feature, kk): its float4s of a
+// staged chunk are rows 4g..4g+3 with g = (qq&1) + 2 kk + 4 (qq>>1) of the chunk.  A stage = the X chunk (Kb x 4 KiB) + two
+// 1 KiB vector pieces (32 rows x float4 in plain row order; lanes 32..63 of the copy fetch 512 B of slack never read).
+template <int CPW, int RING>
 __device__ __forceinline__ void wgrad_vec_body(const WgradTask& T, float* smem) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float va[4] = {0.f, 0.f, 0.f, 0.f};
+  float va[4] = {0.f, 0.f, 0.f, 0.f}, vb[4] = {0.f, 0.f, 0.f, 0.f};
   const int nchunks = (T.tile_end - T.tile_begin) * 2;
   const int k = tid & 255, kk = tid >> 8;
+  const int xfloats = T.Kb * 4 * WG_PIECE;
+  const int stage_floats = xfloats + 2 * WG_PIECE;
+  const bool two = T.vec2 != nullptr;
+  const unsigned smem_b = lds_byte_addr(smem);
   auto stage = [&](int ci) {
     const int tile = T.tile_begin + (ci >> 1), c = ci & 1;
-    stage_operand(T.X + (size_t)tile * T.x_tile_stride, T.Kb, c, smem + (ci & 1) * WG_STAGE, wave, lane);
-    if (wave == 0) {   // 32 rows x float4, plain row order (lanes 32..63 copy 512 B of slack that is never read)
-      float* dst = smem + WG_VEC + (ci & 1) * WG_VSTRIDE;
-      const int r = lane & 31;
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(T.vec + (size_t)tile * TILE_ROWS + 32 * c + r), (lds_void*)dst, 16, 0, 0);
-    }
+    const unsigned buf = smem_b + (unsigned)((ci % RING) * stage_floats * 4);
+    stage_chunk<CPW>(T.X + (size_t)tile * T.x_tile_stride, T.Kb, nullptr, 0, c, buf, wave, lane);
+    // waves 0 / 1 issue one copy more than CPW: their vmcnt(N) then waits for MORE than it has to (safe)
+    const int r = lane & 31;
+    if (wave == 0) lds_dma16<false>(T.vec + (size_t)tile * TILE_ROWS + 32 * c + r, buf + xfloats * 4);
+    if (wave == 1 && two) lds_dma16<false>(T.vec2 + (size_t)tile * TILE_ROWS + 32 * c + r, buf + (xfloats + WG_PIECE) * 4);
   };
-  if (nchunks > 0) stage(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage(c);
   for (int ci = 0; ci < nchunks; ++ci) {
-    if (ci + 1 < nchunks) stage(ci + 1);
+    if (ci + RING - 2 <= nchunks - 1) wait_vm<(RING - 2) * CPW>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
     if (k < T.Kb * 32) {
-      const float* Xs = smem + (ci & 1) * WG_STAGE;
-      const float* vs = smem + WG_VEC + (ci & 1) * WG_VSTRIDE;
+      const float* Xs = smem + (ci % RING) * stage_floats;
+      const float* vs = Xs + xfloats;
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         const float4 xv = *reinterpret_cast<const float4*>(Xs + ((((k >> 5) * 4 + qq) * 64) + (k & 31) + 32 * kk) * 4);
@@ -160,18 +186,28 @@ __device__ __forceinline__ void wgrad_vec_body(const WgradTask& T, float* smem) 
           const float4 dv = *reinterpret_cast<const float4*>(vs + 4 * (4 * g + e));
           va[0] = fmaf(xe[e], dv.x, va[0]); va[1] = fmaf(xe[e], dv.y, va[1]);
           va[2] = fmaf(xe[e], dv.z, va[2]); va[3] = fmaf(xe[e], dv.w, va[3]);
+          if (two) {
+            const float4 dw = *reinterpret_cast<const float4*>(vs + WG_PIECE + 4 * (4 * g + e));
+            vb[0] = fmaf(xe[e], dw.x, vb[0]); vb[1] = fmaf(xe[e], dw.y, vb[1]);
+            vb[2] = fmaf(xe[e], dw.z, vb[2]); vb[3] = fmaf(xe[e], dw.w, vb[3]);
+          }
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
   }
-  if (k < T.Kb * 32)
+  if (k < T.Kb * 32) {
     *reinterpret_cast<float4*>(T.vslab + ((size_t)kk * T.Kb * 32 + k) * 4) = make_float4(va[0], va[1], va[2], va[3]);
+    if (two) *reinterpret_cast<float4*>(T.vslab2 + ((size_t)kk * T.Kb * 32 + k) * 4) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+  }
 }
 
 __device__ __forceinline__ void wgrad_run_task(const WgradTask& T, float* smem) {
-  if (T.Nb == 0) { wgrad_vec_body(T, smem); return; }
+  if (T.Nb == 0) {
+    if (T.Kb == 8)      wgrad_vec_body<4, 4>(T, smem);   // 34 KiB stages
+    else if (T.Kb == 4) wgrad_vec_body<2, 8>(T, smem);   // 18 KiB
+    else                wgrad_vec_body<4, 2>(T, smem);   // any Kb <= 8: two stages always fit
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // 8 waves tile the [Kb][Nb] block grid: n-groups of 2 column blocks, the rest along k.
   const int ngn = T.Nb / 2;            // 2 or 4
@@ -179,9 +215,13 @@ __device__ __forceinline__ void wgrad_run_task(const WgradTask& T, float* smem) 
   const int wn = wave % ngn, wk = wave / ngn;
   const int nrb = (T.Kb + ngk - 1) / ngk;   // 4, 2 or 1
   const int kb0 = wk * nrb, nb0 = 2 * wn;
-  if (nrb == 4)      wgrad_body<4>(T, smem, kb0, nb0);
-  else if (nrb == 2) wgrad_body<2>(T, smem, kb0, nb0);
-  else               wgrad_body<1>(T, smem, kb0, nb0);
+  const int cpw = ((T.Kb + T.Nb) * 4 + 7) / 8;
+  if (nrb == 4)      wgrad_body<4, 8, 2>(T, smem, kb0, nb0);   // 8 x 8 blocks: 64 KiB stages
+  else if (nrb == 2) wgrad_body<2, 6, 3>(T, smem, kb0, nb0);   // 8 x 4: 48 KiB
+  else if (cpw == 5) wgrad_body<1, 5, 4>(T, smem, kb0, nb0);   // 2 x 8 (1 x 8): 40 (36) KiB
+  else if (cpw == 4) wgrad_body<1, 4, 5>(T, smem, kb0, nb0);   // 4 x 4: 32 KiB
+  else if (cpw == 3) wgrad_body<1, 3, 6>(T, smem, kb0, nb0);   // 2 x 4 (1 x 4): 24 (20) KiB
+  else               wgrad_body<1, 8, 2>(T, smem, kb0, nb0);   // anything else with one row block per wave
 }
 
 // One workgroup per CU; each walks its share of the linearised (layer, tile) work (equal cost per
@@ -203,7 +243,9 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict
     T.tile_end = sg.tile_end;
     T.slab = ws + G.slab_off + (size_t)sg.slab_idx * (G.Kb * 32) * (G.Nb * 32);
     T.vec = G.vec_off >= 0 ? reinterpret_cast<const float4*>(ws + G.vec_off) : nullptr;
+    T.vec2 = G.vec2_off >= 0 ? reinterpret_cast<const float4*>(ws + G.vec2_off) : nullptr;
     T.vslab = ws + G.vslab_off + (size_t)sg.slab_idx * 2 * (G.Kb * 32) * 4;
+    T.vslab2 = ws + G.vslab2_off + (size_t)sg.slab_idx * 2 * (G.Kb * 32) * 4;
     wgrad_run_task(T, smem);
     __syncthreads();   // the next segment restages LDS
     if (seg_clock && threadIdx.x == 0) seg_clock[si] = wall_clock64() - t0;   // 100 MHz ticks (cost-model calibration)
@@ -212,9 +254,8 @@ __global__ __launch_bounds__(512) void wgrad_kernel(const WgradGroup* __restrict
 
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   unsigned long long* seg_clock, hipStream_t stream) {
-  const size_t lds = (size_t)WG_LDS_FLOATS * sizeof(float);
-  (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(512), lds, stream, d_groups, d_segs, d_seg_begin, ws, seg_clock);
+  (void)hipFuncSetAttribute((const void*)wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS_BYTES);
+  hipLaunchKernelGGL(wgrad_kernel, dim3(nwg), dim3(512), WG_LDS_BYTES, stream, d_groups, d_segs, d_seg_begin, ws, seg_clock);
 }
 
 // dst[r][c] = sum_parts src[part][r][c].  Wide leaves (cols, ld multiples of 4) go 4 columns per

@@ -22,6 +22,7 @@
 // reduce_kernel (wgrad.hip) sums the slabs.  Operands arrive through a 128 KiB LDS ring of 4 (8 x 8 blocks) to 10 (narrow groups)
 // chunks, all but one of them in flight, one barrier per chunk.
 #include "nrf_internal.h"
+#include "lds_dma.h"
 
 namespace nrf {
 
@@ -36,7 +37,7 @@ namespace {
 constexpr int WB_LDS = 128 * 1024;           // operand ring: RING chunks (one 32-sample group each) of (Kb + Nb) x 2 KiB, X then dY
 
 template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm() { wait_vmcnt<N>(); }
 
 // operand fragment (block image at `img`, k-step ks): two transposing reads = K-slots 0..3, 4..7
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int ks) {
@@ -73,9 +74,12 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
   // source granule of LDS slot `lane` of a 1 KiB piece (16 samples): n = n0 + 4 (lane >> 4) + (lane & 3), h = (lane >> 3) & 1,
   // jp = (lane >> 2) & 1; stash granule (n, h, jp) of a block sits at jp * 1024 + (n + 32 h) * 16
   const int src_lane = ((lane >> 2) & 1) * 1024 + (4 * (lane >> 4) + (lane & 3) + 32 * ((lane >> 3) & 1)) * 16;
+  const unsigned lds_b = lds_byte_addr(lds);
+  // The copies are asm statements (lds_dma.h): counted by hipcc, the RING - 1 chunks "in flight" were drained by a
+  // compiler-inserted vmcnt(0) in front of the operand reads of every chunk.
   auto stage = [&](int ci) {
     const int t = sg.tile_begin + ci;
-    char* buf = lds + (ci % RING) * chunk_bytes;
+    const unsigned buf = lds_b + (unsigned)((ci % RING) * chunk_bytes);
     const char* xt = xbase + (size_t)t * G.x_tile_stride * 4;
     const char* yt = ybase + (size_t)t * G.dy_tile_stride * 4;
 #pragma unroll
@@ -86,8 +90,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
       const int pp = isy ? p - 2 * Kb : p;
       const int b = pp >> 1, half = pp & 1;
       const char* src = (isy ? yt : xt) + b * 2048 + half * 256 + src_lane;   // half: samples 16..31 = 16 lanes x 16 B further
-      char* dst = buf + (isy ? Kb * 2048 : 0) + b * 2048 + half * 1024;
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src), (lds_void_t*)dst, 16, 0, 2);
+      lds_dma16<true>(src, buf + (unsigned)((isy ? Kb * 2048 : 0) + b * 2048 + half * 1024));
     }
   };
 

@@ -10,6 +10,10 @@ Inputs (rays, target colours, parameters) are resident in HBM before the timed r
   python bench.py --gpus N --steps K --warmup W
 N>1 is launched by torch.distributed.run, one rank per GPU (weak scaling: 1024 rays per GPU).
 Rank 0 prints ONE JSON line.
+
+Secondary lines (never the default): --mode train_bf16 | vrig | fullhd | eval, --bf16 (or BENCH_BF16=1) for the bfloat16
+NeRF-MLP mode of vrig / fullhd / eval, --rays-per-gpu N (e.g. 128 = one GPU's share of the north star's 1024-ray global batch
+on 8 GPUs: the strong-scaling point), --graph (the whole step replayed from one hipGraph).
 """
 import argparse
 import json
@@ -29,8 +33,11 @@ N_COARSE, N_FINE, POINT_FREQS = 64, 128, 8
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (the opt-in bf16 modes)
 PEAK_HBM_GBS = 8000.0           # HBM3E spec (~6300 achievable)
-# profile name -> kernel symbol in profiles/hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 run)
-TRAFFIC_KERNEL = {'wgrad': 'nrf::wgrad_kernel', 'wgrad_bf16': 'nrf::wgrad_bf16_kernel'}
+# profile name -> kernel symbol in profiles/hbm_traffic.json (PMC FETCH_SIZE/WRITE_SIZE of the committed rocprofv3 run).
+# Only names that are ONE launch per step are listed (a per-kernel PMC average over two different launches is not a
+# per-launch figure): the merged dgrad launches of round 3 qualify, the per-level forward launches do not.
+TRAFFIC_KERNEL = {'wgrad': 'nrf::wgrad_kernel', 'wgrad_bf16': 'nrf::wgrad_bf16_kernel', 'mlp_dgrad': 'nrf::nerf_mlp_bwd_kernel',
+                  'warp_dgrad': 'nrf::se3_warp_bwd_kernel<false>'}
 
 
 def kernel_source_sha():
@@ -43,22 +50,27 @@ def kernel_source_sha():
   return h.hexdigest()[:16]
 
 
-def hbm_traffic(profile_name):
-  """(HBM bytes per launch of the dominant kernel, provenance) from the committed PMC pass (profiles/hbm_traffic.json,
-  written by scripts/make_hbm_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  The file records the
-  hash of the kernel sources it was measured at; when the sources have changed since, the figure is stale and
-  (None, reason) is returned instead."""
+def hbm_traffic(profile_name, mode='train'):
+  """(HBM bytes per launch of the dominant kernel, provenance) from the committed PMC pass of THIS workload
+  (profiles/hbm_traffic.json: {'modes': {mode: {'source', 'kernels': {symbol: {fetch_bytes, write_bytes}}}}}, written by
+  scripts/make_hbm_traffic.py: FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE).  The file records the hash of the
+  kernel sources it was measured at; when the sources have changed since, the figure is stale and (None, reason) is
+  returned instead."""
   path = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
   sym = TRAFFIC_KERNEL.get(profile_name)
   if sym is None or not os.path.exists(path):
     return None, 'no PMC pass committed for this kernel'
   rec = json.load(open(path))
-  k = rec.get('kernels', {}).get(sym)
+  modes = rec.get('modes') or {'train': {'kernels': rec.get('kernels', {}), 'source': rec.get('source')}}
+  m = modes.get(mode)
+  if m is None:
+    return None, f'no PMC pass committed for the {mode} workload'
+  k = m.get('kernels', {}).get(sym)
   if k is None:
     return None, 'kernel not in profiles/hbm_traffic.json'
   if rec.get('csrc_sha16') != kernel_source_sha():
     return None, f"stale: measured at csrc {rec.get('csrc_sha16')}, sources are now {kernel_source_sha()}"
-  return k['fetch_bytes'] + k['write_bytes'], rec.get('source', 'profiles/hbm_traffic.json')
+  return k['fetch_bytes'] + k['write_bytes'], m.get('source') or rec.get('source', 'profiles/hbm_traffic.json')
 
 
 class ClockSampler:
@@ -149,6 +161,42 @@ class Cfg:
   use_viewdirs = True
 
 
+class CfgVrig(Cfg):   # configs/gpu_vrig_paper.gin: 128+128, F_p=8, SE3 F_w=6 G=8, camera code, elastic + background
+  num_coarse_samples, num_fine_samples = 128, 128
+  use_warp, num_warp_freqs, num_warp_features, use_camera_metadata = True, 6, 8, True
+  warp_field_type = 'se3'
+
+
+class CfgFullHD(Cfg):   # configs/gpu_fullhd.gin:24-40 + warp_defaults.gin: 256+256, F_p=10, SE3 F_w=8 G=8, appearance ids
+  num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 256, 256, 10
+  use_warp, num_warp_freqs, num_warp_features, use_appearance_metadata = True, 8, 8, True
+  warp_field_type = 'se3'
+
+
+class CfgEval(Cfg):
+  num_coarse_samples, num_fine_samples, use_stratified_sampling = 128, 128, False
+
+
+# training workloads: rays per GPU, model config, regularisers, warp alpha, the gin shape they stand for
+TRAIN_MODES = {
+    'train': dict(rays=RAYS_PER_GPU, cfg=Cfg, reg=False, alpha=0.0, metric='train rays/sec (192 samples/ray)',
+                  workload='gpu_quarterhd.gin shape: {rays} rays/GPU x (64+128) samples, F_p=8, warp off, stratified, '
+                           'fwd+MSE+bwd+grad all-reduce+Adam'),
+    'vrig': dict(rays=768, cfg=CfgVrig, reg=True, alpha=6.0, elastic_w=0.001,
+                 metric='train rays/sec (256 samples/ray, SE3 warp + elastic + background regularisers)',
+                 workload="gpu_vrig_paper.gin shape: {rays} rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, elastic "
+                          "loss (reduce 'weight', w=0.001) on the coarse samples, 16384 background points per GPU (w=1), stratified"),
+    'fullhd': dict(rays=512, cfg=CfgFullHD, reg=True, alpha=8.0, elastic_w=0.01,
+                   metric='train rays/sec (512 samples/ray, SE3 warp + elastic + background regularisers)',
+                   workload="gpu_fullhd.gin shape: {rays} rays/GPU (4096 global on 8) x (256+256) samples, F_p=10, SE3 warp F_w=8, "
+                            "appearance + warp ids, elastic loss (reduce 'weight', w=0.01) on the coarse samples, 16384 background "
+                            'points per GPU (w=1), stratified'),
+}
+TRAIN_MODES['train_bf16'] = dict(TRAIN_MODES['train'], force_bf16=True)
+BF16_NOTE = (' [opt-in bf16 mode: bfloat16 NeRF-MLP operands and activation / dY stash; fp32 master weights, posenc, SE3 warp '
+             'field and its regularisers, compositing, loss, all-reduce, Adam]')
+
+
 def synthetic_batch(n, seed, device):
   g = torch.Generator(device='cpu').manual_seed(seed)
   o = torch.rand(n, 3, generator=g) - 0.5
@@ -215,51 +263,57 @@ def cpu_baseline(seconds_budget=20.0):
                     f'oracle, median of {len(times)} steps, {best_threads} threads (best of a probe up to {ncpu} on 128 rays)'}
 
 
-def side_mode(args, world, rank, dev):
-  """Secondary workloads (never the default bench line): eval forward and the vrig training shape."""
-  from nerfies_amd import evaluation, models, training
+def kernel_table(prof, nsteps):
+  return {e['name']: {'ms': e['ms'] / max(e['launches'], 1), 'launches_per_step': e['launches'] / nsteps,
+                      'tflops': (e['flops_per_launch'] / (e['ms'] / max(e['launches'], 1) * 1e-3) / 1e12)
+                      if e['flops_per_launch'] > 0 and e['ms'] > 0 else None} for e in prof}
+
+
+def roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg):
+  """Roofline entry of the dominant kernel (largest accumulated time among the kernels that carry algorithmic flops)."""
+  mf = [e for e in prof if e['flops_per_launch'] > 0]
+  dom = max(mf, key=lambda e: e['ms'])
+  dom_ms = dom['ms'] / dom['launches']
+  achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
+  traffic, traffic_src = hbm_traffic(dom['name'], mode_key)
+  # the NeRF-MLP kernels run on bf16 MFMA in the bf16 modes; the SE3 field and the fp32 wgrad kernel never do
+  on_bf16 = bf16 and dom['name'].startswith('mlp_')
+  peak_tf = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
+  r = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': achieved / peak_tf,
+       'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']}
+  if dom['name'] == 'wgrad_bf16':
+    # HBM-bound: the kernel's algorithmic traffic is both bf16 stashes read once -- per MLP row X = posenc 64 + h1..h8 8x256 +
+    # bottleneck 256 + rgb hidden 128 features, dY = dpre0..7 8x256 + d bottleneck 256 + d rgb hidden 128 + d raw 4, 2 B each
+    rows = rays_per_gpu * (2 * cfg.num_coarse_samples + cfg.num_fine_samples)
+    alg_bytes = rows * 2 * ((64 + 8 * 256 + 256 + 128) + (8 * 256 + 256 + 128 + 4))
+    gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
+    r = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
+         'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'bytes_per_launch': alg_bytes}
+  return r, peak_tf
+
+
+def rccl_version():
+  try:
+    v = torch.cuda.nccl.version()
+    return '.'.join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+  except Exception as e:   # noqa: BLE001
+    return f'unavailable ({type(e).__name__})'
+
+
+def eval_mode(args, world, rank, dev, bf16):
+  """BASELINE configs[4]: the video-render forward, 8192-ray chunks x (128+128), hipGraph replay."""
+  from nerfies_amd import evaluation, models
+  n = 8192
+  model, fp = models.construct_nerf(0, CfgEval, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
+  rays = {k: v for k, v in synthetic_batch(n, 100 + rank, dev).items() if k != 'rgb'}
+  fn = evaluation.GraphedChunkRenderer(model, bf16=bf16)
+  step = lambda: fn(0, 1, fp, rays, {})
+  prof_step = lambda: model.apply({'params': fp}, rays, {}, bf16=bf16)   # HIP events cannot be recorded inside a graph replay
 
   def barrier():
     if world > 1:
       dist.barrier()
     torch.cuda.synchronize()
-
-  if args.mode == 'eval':
-    class C(Cfg):
-      num_coarse_samples, num_fine_samples, use_stratified_sampling = 128, 128, False
-    n = 8192
-    model, fp = models.construct_nerf(0, C, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
-    rays = {k: v for k, v in synthetic_batch(n, 100 + rank, dev).items() if k != 'rgb'}
-    bf16 = bool(os.environ.get('BENCH_BF16'))   # opt-in bfloat16-operand inference mode (never the default line)
-    fn = evaluation.GraphedChunkRenderer(model, bf16=bf16)
-    step = lambda: fn(0, 1, fp, rays, {})
-    prof_step = lambda: model.apply({'params': fp}, rays, {}, bf16=bf16)   # HIP events cannot be recorded inside a graph replay
-    per_step, name, flops = n, 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [bf16 MLP operands]' if bf16 else ''), None
-    workload = 'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, warp off, deterministic, forward only'
-  else:
-    class C(Cfg):
-      num_coarse_samples, num_fine_samples = 128, 128
-      use_warp, num_warp_freqs, num_warp_features, use_camera_metadata = True, 6, 8, True
-      warp_field_type = 'se3'
-    n = 768
-    model, fp = models.construct_nerf(0, C, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
-    state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=6.0)
-    sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0, elastic_loss_weight=0.001)
-    batch = synthetic_batch(n, 100 + rank, dev)
-    g = torch.Generator().manual_seed(rank)
-    batch['metadata'] = {'warp': torch.randint(0, 4, (n, 1), generator=g).to(dev), 'camera': torch.randint(0, 2, (n, 1), generator=g).to(dev)}
-    batch['background_points'] = ((torch.rand(16384 // max(world, 1), 3, generator=g) - 0.5) * 0.8).to(dev)
-    box = {'state': state, 'key': 1 + rank}
-
-    vbf16 = bool(os.environ.get('BENCH_BF16'))   # opt-in: the NeRF MLPs in the bf16 training mode (the warp field stays fp32)
-
-    def step():
-      box['state'], _, box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, use_elastic_loss=True,
-                                                        elastic_reduce_method='weight', use_background_loss=True, bf16=vbf16)
-    prof_step = step
-    per_step, name = n, 'train rays/sec (256 samples/ray, SE3 warp + elastic + background regularisers)' + (' [bf16 NeRF MLPs]' if vbf16 else '')
-    workload = ('gpu_vrig_paper.gin shape: 768 rays/GPU x (128+128) samples, SE3 warp F_w=6 + camera code, elastic loss '
-                "(reduce 'weight', w=0.001) on the coarse samples, background points 16384/world (w=1), stratified")
   if args.burn_in_s > 0:
     burn_in(step, args.burn_in_s, world, dev)
   for _ in range(args.warmup):
@@ -281,27 +335,18 @@ def side_mode(args, world, rank, dev):
   prof = model.profile_read()
   model.profile_enable(False)
   if rank == 0:
-    kernels = {e['name']: {'ms': e['ms'] / max(e['launches'], 1), 'launches_per_step': e['launches'] / 5,
-                           'tflops': (e['flops_per_launch'] / (e['ms'] / max(e['launches'], 1) * 1e-3) / 1e12)
-                           if e['flops_per_launch'] > 0 and e['ms'] > 0 else None} for e in prof}
-    mf = [e for e in prof if e['flops_per_launch'] > 0]
-    dom = max(mf, key=lambda e: e['ms'])
-    dom_ms = dom['ms'] / dom['launches']
-    achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
+    roofline, peak = roofline_of(prof, bf16, 'eval_bf16' if bf16 else 'eval', n, CfgEval)
     step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / 5
     ms = 1e3 * elapsed / args.steps
-    # dense bf16 MFMA peak (MI355X_MICROARCH.md) for the opt-in bf16-operand mode, fp32 MFMA peak otherwise
-    peak = PEAK_BF16_MFMA_TFLOPS if (args.mode == 'eval' and os.environ.get('BENCH_BF16')) else PEAK_FP32_MFMA_TFLOPS
     print(json.dumps({
-        'metric': name, 'value': world * per_step * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps,
-        'warmup': args.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16' if (args.mode == 'eval' and os.environ.get('BENCH_BF16')) else ('bf16 NeRF MLPs + f32 warp field' if os.environ.get('BENCH_BF16') else 'f32'),
-        'data': 'synthetic', 'config': {'workload': workload, 'rays_per_gpu': per_step, 'parallelism': f'ray-shard dp{world}'},
-        'roofline': {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                     'frac': achieved / peak, 'traffic': None, 'kernel_ms': dom_ms},
-        'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernels}))
-  if world > 1:
-    dist.destroy_process_group()
+        'metric': 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [bf16 MLP operands]' if bf16 else ''),
+        'value': world * n * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32',
+        'data': 'synthetic',
+        'config': {'workload': 'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, warp off, deterministic, forward only',
+                   'rays_per_gpu': n, 'parallelism': f'ray-shard dp{world}'},
+        'roofline': roofline, 'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernel_table(prof, 5),
+        'csrc_sha16': kernel_source_sha()}))
 
 
 def main():
@@ -312,52 +357,93 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--burn-in-s', type=float, default=3.0,
                   help='seconds of untimed steps of the same workload before the warm-up + timed steps (steady-state clocks)')
-  ap.add_argument('--mode', default='train', choices=['train', 'train_bf16', 'eval', 'vrig'],
+  ap.add_argument('--mode', default='train', choices=['train', 'train_bf16', 'eval', 'vrig', 'fullhd'],
                   help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
                        '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
-                       'SE3 warp F_w=6 + camera code + elastic + background regularisers); train_bf16: the headline workload with '
-                       'bfloat16 MLP operands and stash (opt-in mode, never the default line; BASELINE configs[3] precision)')
+                       'SE3 warp F_w=6 + camera code + elastic + background regularisers); fullhd: configs[3] shape (512 rays/GPU x '
+                       '(256+256), F_p=10, SE3 warp F_w=8, appearance ids, elastic + background; --bf16 = the precision BASELINE '
+                       'names for it); train_bf16: the headline workload with bfloat16 MLP operands and stash (opt-in mode, '
+                       'never the default line)')
+  ap.add_argument('--bf16', action='store_true', help='vrig / fullhd / eval: NeRF MLPs in the bf16 mode (same as BENCH_BF16=1)')
+  ap.add_argument('--rays-per-gpu', type=int, default=0,
+                  help='rays per GPU of the training modes (default: the mode\'s own, 1024 for the headline); 128 = one GPU\'s share '
+                       'of a 1024-ray global batch on 8 GPUs (the north star\'s strong-scaling point)')
+  ap.add_argument('--graph', action='store_true', help='replay the whole train step (loss+grad, all-reduce, Adam) from one hipGraph')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
   rank = int(os.environ.get('RANK', '0'))
   local_rank = int(os.environ.get('LOCAL_RANK', '0'))
   # Debug hooks for exercising the N>1 code path on a ONE-GPU box (never set by the driver): BENCH_DIST_BACKEND=gloo
-  # swaps RCCL for gloo, BENCH_SAME_DEVICE=1 puts every rank on cuda:0 (RCCL refuses two ranks on one device).
+  # swaps RCCL for gloo, BENCH_SAME_DEVICE=1 puts every rank on cuda:0 (RCCL refuses two ranks on one device),
+  # BENCH_FORCE_DIST=1 creates the RCCL communicator even with ONE rank, so that the step's fused [grad | stats] all-reduce
+  # really goes through librccl on the one GPU a box has.
   backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+  force_dist = bool(os.environ.get('BENCH_FORCE_DIST')) and world == 1
   if os.environ.get('BENCH_SAME_DEVICE'):
     local_rank = 0
-  if world > 1:
+  if world > 1 or force_dist:
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
     torch.cuda.set_device(local_rank)
+    kw = {'rank': rank, 'world_size': world} if force_dist else {}
     if backend == 'nccl':
-      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), **kw)
     else:
-      dist.init_process_group(backend)
+      dist.init_process_group(backend, **kw)
   elif args.gpus > 1:
     raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
   dev = torch.device('cuda', local_rank if world > 1 else 0)
   torch.cuda.set_device(dev)
+  dist_on = world > 1 or force_dist
+
+  bf16 = args.bf16 or bool(os.environ.get('BENCH_BF16'))
+  if args.mode == 'eval':
+    eval_mode(args, world, rank, dev, bf16)
+    if dist_on:
+      dist.destroy_process_group()
+    return
 
   from nerfies_amd import models, training
-  if args.mode not in ('train', 'train_bf16'):
-    return side_mode(args, world, rank, dev)
-  bf16 = args.mode == 'train_bf16'
-  model, fp = models.construct_nerf(0, Cfg, RAYS_PER_GPU, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
-  state = training.TrainState(optimizer=training.Optimizer(fp))
-  sp = training.ScalarParams(learning_rate=1e-3)
-  batch = synthetic_batch(RAYS_PER_GPU, seed=100 + rank, device=dev)   # each rank: its own ray shard
+  M = TRAIN_MODES[args.mode]
+  bf16 = bf16 or bool(M.get('force_bf16'))
+  cfg = M['cfg']
+  rays_per_gpu = args.rays_per_gpu or M['rays']
+  model, fp = models.construct_nerf(0, cfg, rays_per_gpu, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=M['alpha'])
+  batch = synthetic_batch(rays_per_gpu, seed=100 + rank, device=dev)   # each rank: its own ray shard
+  kw = {}
+  if M['reg']:
+    sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0, elastic_loss_weight=M['elastic_w'])
+    g = torch.Generator().manual_seed(rank)
+    md = {'warp': torch.randint(0, 4, (rays_per_gpu, 1), generator=g).to(dev)}
+    if getattr(cfg, 'use_camera_metadata', False):
+      md['camera'] = torch.randint(0, 2, (rays_per_gpu, 1), generator=g).to(dev)
+    if getattr(cfg, 'use_appearance_metadata', False):
+      md['appearance'] = torch.randint(0, 4, (rays_per_gpu, 1), generator=g).to(dev)
+    batch['metadata'] = md
+    # train.py:186-197: min(len(points), n_dev * 16384) points per step, sharded -> 16384 per device
+    batch['background_points'] = ((torch.rand(16384, 3, generator=g) - 0.5) * 0.8).to(dev)
+    kw = dict(use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
+  else:
+    sp = training.ScalarParams(learning_rate=1e-3)
   key = 12345 + rank
 
   def barrier():
-    if world > 1:
+    if dist_on:
       dist.barrier()
     torch.cuda.synchronize()
 
   box = {'state': state, 'key': key, 'stats': None}
+  if args.graph:
+    gstep = training.GraphedTrainStep(model, state, batch, sp, bf16=bf16, **kw)
 
-  def step():
-    box['state'], box['stats'], box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, bf16=bf16)
+    def step():
+      box['stats'] = gstep(box['key'])
+      box['key'] += 1
+  else:
+    def step():
+      box['state'], box['stats'], box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, bf16=bf16, **kw)
 
   # untimed burn-in at the same workload (>= --burn-in-s seconds) so the short timed window below sits at steady-state
   # clocks and power; the sampler keeps running through the timed region
@@ -382,7 +468,7 @@ def main():
 
   # ---- the gradient all-reduce on its own (outside the timed region): the fused [grad | stats] buffer, 20 calls ----
   allreduce_us = None
-  if world > 1:
+  if dist_on:
     buf = torch.zeros_like(state.optimizer._gs)
     for _ in range(5):
       dist.all_reduce(buf)
@@ -395,62 +481,53 @@ def main():
     torch.cuda.synchronize()
     allreduce_us = e0.elapsed_time(e1) * 1e3 / 20
 
-  # ---- per-kernel timing of the SAME step with HIP events on the launch stream ----
+  # ---- per-kernel timing of the SAME step with HIP events on the launch stream (eager: events cannot be recorded inside a
+  #      graph replay) ----
   model.profile_enable(True)
   prof_steps = max(5, min(args.steps, 20))
   for _ in range(prof_steps):
-    state, stats, key = training.train_step(model, key, state, batch, sp, bf16=bf16)
+    state, stats, key = training.train_step(model, key, state, batch, sp, bf16=bf16, **kw)
   torch.cuda.synchronize()
   prof = model.profile_read()
   model.profile_enable(False)
 
   if rank == 0:
     ms_per_step = 1e3 * elapsed / args.steps
-    value = world * RAYS_PER_GPU * args.steps / elapsed
+    value = world * rays_per_gpu * args.steps / elapsed
     step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / prof_steps
-    kernels = {e['name']: {'ms': e['ms'] / max(e['launches'], 1), 'launches_per_step': e['launches'] / prof_steps,
-                           'tflops': (e['flops_per_launch'] / (e['ms'] / max(e['launches'], 1) * 1e-3) / 1e12)
-                           if e['flops_per_launch'] > 0 and e['ms'] > 0 else None} for e in prof}
-    mf = [e for e in prof if e['flops_per_launch'] > 0]
-    dom = max(mf, key=lambda e: e['ms'])
-    dom_ms = dom['ms'] / dom['launches']
-    achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
-    traffic, traffic_src = hbm_traffic(dom['name'])
-    peak_tf = PEAK_BF16_MFMA_TFLOPS if bf16 else PEAK_FP32_MFMA_TFLOPS
-    roofline = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s',
-                'frac': achieved / peak_tf, 'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms,
-                'flops_per_launch': dom['flops_per_launch']}
-    if dom['name'] == 'wgrad_bf16':
-      # HBM-bound: the kernel's algorithmic traffic is both bf16 stashes read once -- per MLP row X = posenc 64 + h1..h8 8x256 +
-      # bottleneck 256 + rgb hidden 128 features, dY = dpre0..7 8x256 + d bottleneck 256 + d rgb hidden 128 + d raw 4, 2 B each
-      rows = RAYS_PER_GPU * (N_COARSE + (N_COARSE + N_FINE))
-      alg_bytes = rows * 2 * ((64 + 8 * 256 + 256 + 128) + (8 * 256 + 256 + 128 + 4))
-      gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
-      roofline = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
-                  'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'bytes_per_launch': alg_bytes}
+    mode_key = args.mode + ('_bf16' if bf16 and not M.get('force_bf16') else '')
+    roofline, peak_tf = roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg)
+    kernels = kernel_table(prof, prof_steps)
+    ksum_ms = sum(v['ms'] * v['launches_per_step'] for v in kernels.values())
+    mixed = bf16 and getattr(cfg, 'use_warp', False)
+    # the step's flops are priced against the bf16 peak only when every MFMA kernel of it runs in bf16 (warp off)
+    step_peak = PEAK_BF16_MFMA_TFLOPS if (bf16 and not mixed) else PEAK_FP32_MFMA_TFLOPS
     out = {
-        'metric': 'train rays/sec (192 samples/ray)', 'value': value, 'unit': 'rays/s', 'n_gpus': world,
+        'metric': M['metric'], 'value': value, 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32', 'data': 'synthetic',
-        'config': {'workload': 'gpu_quarterhd.gin shape: 1024 rays/GPU x (64+128) samples, F_p=8, warp off, '
-                               'stratified, fwd+MSE+bwd+grad all-reduce+Adam' +
-                               (' [opt-in bf16 mode: bfloat16 MLP operands and activation / dY stash; fp32 master weights, '
-                                'posenc, compositing, loss, all-reduce, Adam]' if bf16 else ''), 'rays_per_gpu': RAYS_PER_GPU,
-                   'global_batch': world * RAYS_PER_GPU, 'parallelism': f'ray-shard dp{world}'},
+        'scaling': 'weak', 'vs_baseline': None,
+        'dtype': ('bf16 NeRF MLPs + f32 warp field' if mixed else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': M['workload'].format(rays=rays_per_gpu) + (BF16_NOTE if bf16 else '') +
+                               (' [whole step replayed from one hipGraph]' if args.graph else ''),
+                   'rays_per_gpu': rays_per_gpu, 'global_batch': world * rays_per_gpu, 'parallelism': f'ray-shard dp{world}'},
         'roofline': roofline,
         'step_tflops': step_flops / (ms_per_step * 1e-3) / 1e12,
-        ('step_frac_of_bf16_mfma_peak' if bf16 else 'step_frac_of_fp32_mfma_peak'): step_flops / (ms_per_step * 1e-3) / 1e12 / (peak_tf * world),
-        'kernels': kernels, 'final_loss_fine': loss,
+        ('step_frac_of_bf16_mfma_peak' if step_peak == PEAK_BF16_MFMA_TFLOPS else 'step_frac_of_fp32_mfma_peak'):
+            None if mixed else step_flops / (ms_per_step * 1e-3) / 1e12 / (step_peak * world),
+        'kernels': kernels, 'sum_of_kernels_ms': ksum_ms, 'step_over_sum_of_kernels': ms_per_step / ksum_ms if ksum_ms else None,
+        'final_loss_fine': loss,
         'steady_state': {'burn_in_steps': burn_steps, 'burn_in_s': args.burn_in_s, 'timed_window_s': elapsed,
                          'during_timed_window': clocks},
-        'rccl_ranks': dist.get_world_size() if world > 1 else 1, 'dist_backend': backend if world > 1 else None,
+        'graph_replay': bool(args.graph),
+        'rccl_ranks': dist.get_world_size() if dist_on else 1, 'dist_backend': backend if dist_on else None,
+        'rccl_version': rccl_version() if dist_on and backend == 'nccl' else None,
         'grad_allreduce_us': allreduce_us, 'grad_allreduce_bytes': 4 * state.optimizer._gs.numel(),
         'csrc_sha16': kernel_source_sha(),
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and args.mode == 'train' and not args.no_cpu_baseline and not force_dist:
       out['cpu_baseline'] = cpu_baseline()
     print(json.dumps(out))
-  if world > 1:
+  if dist_on:
     dist.destroy_process_group()
 
 

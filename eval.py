@@ -62,6 +62,11 @@ def process_iterator(tag, item_ids, iterator, rng, state, step, render_fn, write
           # models.py:121-131) -- the same convention training.train_step's background ids follow
           md[name] = torch.full(batch['origins'][..., :1].shape, int(ids[g.randint(len(ids))]), dtype=torch.int32,
                                 device=batch['origins'].device)
+      if getattr(datasource, 'use_time', False):
+        # eval.py:189-194: timestamp ~ U[0, 1) from the step's key, then jnp.full(shape, timestamp, dtype=uint32) -- the
+        # reference's integer cast truncates it to 0; kept (drop-in behaviour), as a float32 tensor the TimeEncoder takes
+        timestamp = float(np.uint32(g.uniform(0.0, 1.0)))
+        md['time'] = torch.full(batch['origins'][..., :1].shape, timestamp, dtype=torch.float32, device=batch['origins'].device)
       batch['metadata'] = md
     stats = process_batch(batch=batch, rng=rng, state=state, tag=tag, item_id=item_id, step=step, writer=writer,
                           render_fn=render_fn, save_dir=save_dir, datasource=datasource)

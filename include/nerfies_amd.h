@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 200 /* 0.2.0: alpha condition, pre-encoded metadata, warp Jacobian output, noise_std, warp_reg loss,
+#define NRF_VERSION 300 /* 0.3.0: device-resident per-step scalars (a whole train step replays from one hipGraph), background ids /
+                           noise drawn by the library, `points` output without the warp field.
+                           0.2.0: alpha condition, pre-encoded metadata, warp Jacobian output, noise_std, warp_reg loss,
                            elastic loss types, time metadata encoder, stats[16], bf16 training */
 
 enum {
@@ -122,10 +124,35 @@ typedef struct nrf_rays {
   const float* time;             /* (B,) metadata['time'] in [-1,1] (datasets/core.py:272-274); NRF_META_TIME only */
 } nrf_rays;
 
+/* The scalars that change from one optimisation step to the next (train.py:280-285 recomputes them from the schedules; the
+ * rng key advances), in DEVICE memory.  A launch sequence captured into a hipGraph bakes every by-value argument in; with
+ * nrf_step_scalars.dynamic set, the kernels read these values from the device instead, so the caller rewrites this struct
+ * (one 64-byte host-to-device copy ahead of the replay) and replays the SAME graph for every step.  adam_c1 / adam_c2 are
+ * the bias corrections 1 - beta^(step+1), formed in double on the host exactly as nrf_adam_step forms them. */
+typedef struct nrf_dynamic_scalars {
+  float warp_alpha;           /* replaces nrf_step_scalars.warp_alpha */
+  float time_alpha;           /* replaces nrf_step_scalars.time_alpha */
+  float elastic_loss_weight;  /* replaces nrf_elastic.loss_weight */
+  float learning_rate;        /* nrf_adam_step_dynamic */
+  float adam_c1;              /* nrf_adam_step_dynamic: 1 - beta1^(step+1) */
+  float adam_c2;              /* nrf_adam_step_dynamic: 1 - beta2^(step+1) */
+  float grad_scale;           /* nrf_adam_step_dynamic: 1 / world_size */
+  float reserved0;
+  uint64_t rng_seed;          /* replaces nrf_rand.seed (sampling streams, noise, the background draw) */
+  uint64_t rng_offset;        /* replaces nrf_rand.offset */
+  uint64_t reserved1[2];
+} nrf_dynamic_scalars;        /* 64 bytes */
+
+/* Writes *host_values into the device struct with a one-thread kernel on `stream` (the values travel as kernel arguments:
+ * no host buffer has to outlive the call, nothing synchronises).  Call it ahead of every graph replay. */
+int nrf_dynamic_scalars_write(nrf_dynamic_scalars* device_dst, const nrf_dynamic_scalars* host_values, void* stream);
+
 /* warp_extra + the per-step scalars of training.ScalarParams (training.py:35-43). */
 typedef struct nrf_step_scalars {
   float warp_alpha; /* warp_extra['alpha'] */
   float time_alpha; /* warp_extra['time_alpha']: annealing of the TimeEncoder's posenc (NRF_META_TIME) */
+  const nrf_dynamic_scalars* dynamic; /* DEVICE pointer or NULL: when set, it overrides warp_alpha / time_alpha above,
+                                         nrf_rand.seed / offset and nrf_elastic.loss_weight (graph-replayable step) */
 } nrf_step_scalars;
 
 /* Stand-in for the flax RNG streams 'coarse' / 'fine' (models.py:333,355).
@@ -151,8 +178,8 @@ typedef struct nrf_level_out {
   float* acc;       /* (B,)  */
   float* weights;   /* (B,S) */
   float* z_vals;    /* (B,S)  (extra: the sample depths of this level) */
-  float* points;        /* (B,S,3) sample points before the warp (return_points, models.py:250-251) */
-  float* warped_points; /* (B,S,3) after SE3Field (models.py:266-267); both need use_warp */
+  float* points;        /* (B,S,3) sample points before the warp (return_points, models.py:247-248: with or without the warp) */
+  float* warped_points; /* (B,S,3) after SE3Field (models.py:266-267); needs the warp field */
   float* warp_jacobian; /* (B,S,3,3) jax.jacfwd(SE3Field.warp) per sample, row-major d x'_i / d x_j (warping.py:385-387,
                            models.py:264-265); needs NRF_FLAG_WARP_JACOBIAN in flags and in nrf_workspace_bytes */
 } nrf_level_out;
@@ -217,11 +244,16 @@ int nrf_train_step_loss_grad(nrf_handle h, const float* params, const nrf_rays* 
  * (utils.py:264-331) and ADDS its parameter gradient to grad_params. */
 typedef struct nrf_background {
   int32_t num_points;
-  const float* points;      /* (N,3) noised points */
-  const int32_t* warp_ids;  /* (N,) */
+  const float* points;      /* (N,3) points: already noised when warp_ids is given, raw when the library draws */
+  const int32_t* warp_ids;  /* (N,) or NULL: the library draws id = id_choices[floor(U * num_choices)] (random.choice over
+                               model.warp_ids, training.py:121-123) and adds noise_std * N(0,1) to the points (:124-126) with
+                               its Philox streams 4..7 of (nrf_rand.seed, offset) -- nothing left for the host to launch */
   float loss_weight;        /* scalar_params.background_loss_weight */
   float loss_alpha;         /* -2 (training.py:119) */
   float loss_scale;         /* 0.001 */
+  const int32_t* id_choices;/* (num_choices,) model.warp_ids; used when warp_ids == NULL */
+  int32_t num_choices;
+  float noise_std;          /* scalar_params.background_noise_std; used when warp_ids == NULL */
 } nrf_background;
 
 /* Elastic regulariser of training.compute_elastic_loss (training.py:71-114, 177-197) on the COARSE samples
@@ -279,6 +311,10 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
 int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t n,
                   double lr, double beta1, double beta2, double eps, int64_t step,
                   double grad_scale, void* stream);
+/* The same update with lr, the bias corrections and grad_scale read from DEVICE memory (nrf_dynamic_scalars): the launch
+ * can sit in a captured graph and still follow the learning-rate schedule and the step count. */
+int nrf_adam_step_dynamic(float* params, float* m, float* v, const float* grad, int64_t n, double beta1, double beta2,
+                          double eps, const nrf_dynamic_scalars* dynamic, void* stream);
 
 /* ---- measurement: per-kernel wall time from HIP events recorded on the launch stream ----
  * (the reference only has utils.TimeTracker host timers, utils.py:418-465, around an

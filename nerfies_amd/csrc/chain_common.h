@@ -21,8 +21,15 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // buffer_store_dwordx4, and on gfx950 that store then picked up the NEW register contents for
 // some lanes (observed: SE3 dgrad stash corrupted in exactly the component overwritten by the
 // following v_pk_add_f32).  With soffset = 0 the compiler keeps the required wait state.
+// The base is wave-uniform by construction, but hipcc selects 64-bit address arithmetic (layer * stride + tile * size) onto
+// the VALU; the descriptor then sits in VGPRs and EVERY buffer_store is wrapped in a waterfall loop (v_readfirstlane x4,
+// compare, s_and_saveexec, store, loop: 16 of them per layer epilogue of the training forward in rounds 1-2, 40 in the merged
+// dgrad kernel of round 3).  Two readfirstlanes put it back into SGPRs.
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+  const uint64_t a = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, 0x00020000);
 }
 // Cache policy of the stash / dY stores (aux immediate of the buffer store: 1 = sc0, 2 = nt, 16 = sc1).  The stash is
 // written once and next read by another kernel after > 1 GB of other traffic, so it is stored non-temporal: the lines

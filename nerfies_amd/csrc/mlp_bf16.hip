@@ -418,7 +418,8 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
         o.z = 1.f / (1.f + expf(-acc1[g][0][2]));
         float araw = alpha_raw[g];
         if (A.noise_std > 0.f)   // model_utils.noise_regularize (model_utils.py:266-282)
-          araw += A.noise_std * (A.noise ? A.noise[row[g]] : philox_normal(A.noise_seed, A.noise_offset, A.noise_stream, (uint32_t)row[g]));
+          araw += A.noise_std * (A.noise ? A.noise[row[g]]
+                                         : philox_normal(A.dyn ? A.dyn->rng_seed : A.noise_seed, A.dyn ? A.dyn->rng_offset : A.noise_offset, A.noise_stream, (uint32_t)row[g]));
         o.w = bf_sigma(araw, A.sigma_act);
         A.out4[row[g]] = o;
       }

@@ -255,7 +255,8 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
         o.x = 1.f / (1.f + expf(-t[0])); o.y = 1.f / (1.f + expf(-t[1])); o.z = 1.f / (1.f + expf(-t[2]));
         if (A.noise_std > 0.f) {   // model_utils.noise_regularize (model_utils.py:266-282)
           const int row = tile * TILE_ROWS + p;
-          const float nz = A.noise ? A.noise[min(row, A.rows - 1)] : philox_normal(A.noise_seed, A.noise_offset, A.noise_stream, (uint32_t)row);
+          const float nz = A.noise ? A.noise[min(row, A.rows - 1)]
+                                   : philox_normal(A.dyn ? A.dyn->rng_seed : A.noise_seed, A.dyn ? A.dyn->rng_offset : A.noise_offset, A.noise_stream, (uint32_t)row);
           sigma_raw = __fadd_rn(sigma_raw, __fmul_rn(nz, A.noise_std));
         }
         o.w = sigma_activation(sigma_raw, A.sigma_act);

@@ -49,6 +49,7 @@ struct LevelWs {   // float offsets from the workspace base, per level (0 = coar
 struct WsPlan {
   int B = -1;
   uint32_t flags = 0;
+  uint64_t serial = 0;   // identity of this layout: a stash written under one plan must not be differentiated under another
   int S[4], rows[4], ntiles[4];
   size_t tables;        // byte region at the start: PackDesc[], WgradGroup[], ReduceDesc[]
   size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b, emb_off_b;
@@ -67,6 +68,7 @@ struct WsPlan {
   size_t cond, mse, zero_rgb, slabs;
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
   size_t bg_loss;       // [64] background-loss accumulator
+  size_t bg_points = 0, bg_ids = 0;   // [bgN][3] noised points / [bgN] ids drawn by the library
   size_t el_sums;       // [64] elastic-loss / residual accumulators
   size_t el_coef;       // [B][N_c] one-hot sample selector of elastic_reduce_method 'median'
   size_t wr_sums = 0;   // [64] warp_reg loss / residual accumulators (coarse: 0, 1; fine: 2, 3)
@@ -158,6 +160,7 @@ struct nrf_handle_s {
   int uploaded_bgN = 0;
   int uploaded_elastic = 0;
   void* stashed_ws = nullptr;
+  uint64_t stashed_plan = 0;   // WsPlan::serial of the stashed forward
   int stashed_B = -1;
   bool stashed_warp = false;
   std::vector<PackDesc> wp_pack;   // pack table of nrf_warp_points (kept alive for the async upload)
@@ -337,7 +340,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
   const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) && h->warp;   // tangent pass in an inference plan
   const bool wstash = train || jac;                                // the warp kernels keep their input / sign-bit stash
+  static uint64_t next_serial = 1;
   p = WsPlan();
+  p.serial = next_serial++;
   p.B = B;
   p.flags = flags;
   p.bgN = bgN;
@@ -468,15 +473,19 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     const char* e = getenv(name);
     return e ? atof(e) : dflt;
   };
-  // measured with scripts/wgrad_calib.py (per-segment wall clocks, least squares), relative to a 256x256 tile
-  const double c_vec256 = env_cost("NRF_COST_VEC256", 0.157), c_vec128 = env_cost("NRF_COST_VEC128", 0.121),
-               c_pe = env_cost("NRF_COST_PE", 0.335), c_rgbh = env_cost("NRF_COST_RGBH", 0.571),
-               c_pe128 = env_cost("NRF_COST_PE128", 0.201),   // SE3 trunk input rows: 64 x 128 (scripts/wgrad_calib_vrig.py)
+  // measured with scripts/wgrad_calib.py / wgrad_calib_vrig.py (per-segment wall clocks, least squares), relative to a
+  // 256x256 tile; round 3 (asm LDS-DMA + 160 KiB ring: the narrow groups are no longer latency-bound): 8x8 = 14.8 us
+  const double c_vec256 = env_cost("NRF_COST_VEC256", 0.105), c_vec128 = env_cost("NRF_COST_VEC128", 0.094),
+               c_vec128x2 = env_cost("NRF_COST_VEC128X2", 0.150),   // SE3 heads: two vectors against one pass over h6
+               c_pe = env_cost("NRF_COST_PE", 0.287),               // 2 x 8 blocks: posenc rows of the NeRF trunk
+               c_rgbh = env_cost("NRF_COST_RGBH", 0.533),           // 8 x 4
+               c_44 = env_cost("NRF_COST_44", 0.285),               // 4 x 4: SE3 trunk layers
+               c_pe128 = env_cost("NRF_COST_PE128", 0.156),         // 2 x 4: SE3 trunk input rows
                c_seg = env_cost("NRF_COST_SEG", 0.5);   // fixed cost of opening a segment (pipeline fill + slab flush), in tiles
   auto tile_cost = [&](const GroupSpec& sp) -> double {
-    if (sp.Nb == 0) return sp.Kb == 8 ? c_vec256 : c_vec128;   // vector columns only (VALU + HBM stream)
-    const double mm = (double)sp.Kb * sp.Nb / 64.0;
-    return mm < 0.2 ? c_pe128 : mm < 0.3 ? c_pe : (mm < 0.6 ? c_rgbh : 1.0);
+    if (sp.Nb == 0) return sp.Kb == 8 ? c_vec256 : sp.vecoff2 ? c_vec128x2 : c_vec128;   // vector columns only (VALU + HBM stream)
+    if (sp.Nb == 8) return sp.Kb >= 5 ? 1.0 : c_pe;
+    return sp.Kb >= 5 ? c_rgbh : sp.Kb >= 3 ? c_44 : c_pe128;
   };
   std::vector<int> nsplit(specs.size(), 0);
   if (!specs.empty()) {
@@ -549,20 +558,6 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     p.bwgrad_nwg = nwg;
   }
   p.ntasks = (int)p.segs.size();
-  const int npack = 64;
-  const int nreduce_max = 192;
-  // tables region (bytes -> floats)
-  p.pack_off_b = 0;
-  p.groups_off_b = align_up(npack * sizeof(PackDesc), 256);
-  p.reduce_off_b = p.groups_off_b + align_up(specs.size() * sizeof(WgradGroup) + 256, 256);
-  p.segs_off_b = p.reduce_off_b + align_up(nreduce_max * sizeof(ReduceDesc), 256);
-  p.segbegin_off_b = p.segs_off_b + align_up(p.segs.size() * sizeof(WgradSegment) + 256, 256);
-  p.emb_off_b = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
-  p.bgroups_off_b = p.emb_off_b + align_up((h->emb.size() + 1) * sizeof(EmbedDesc), 256);
-  p.bsegs_off_b = p.bgroups_off_b + align_up(bspecs.size() * sizeof(WgradGroup) + 256, 256);
-  p.bsegbegin_off_b = p.bsegs_off_b + align_up(p.bsegs.size() * sizeof(WgradSegment) + 256, 256);
-  const size_t table_bytes = p.bsegbegin_off_b + align_up((p.bseg_begin.size() + 1) * sizeof(int), 256);
-  p.tables = take(table_bytes / 4);
   if (h->embed) {
     p.iparams = take((size_t)h->nparams);
     if (train) p.igrad = take((size_t)h->nparams);
@@ -687,6 +682,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   if (h->warp && bgN > 0) {
     alloc_warp(p.L[BG], p.ntiles[BG]);
     p.bg_loss = take(64);
+    p.bg_points = take((size_t)bgN * 3);   // the library's own draw (nrf_background.warp_ids == NULL): noised points, ids
+    p.bg_ids = take((size_t)bgN);
   }
   if (h->time_enc) {
     p.t_codes = take((size_t)B * h->G);
@@ -874,6 +871,19 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   p.reduce.insert(p.reduce.end(), reduce2.begin(), reduce2.end());
   p.reduce.insert(p.reduce.end(), reduce3.begin(), reduce3.end());
   p.reduce.insert(p.reduce.end(), reduce4.begin(), reduce4.end());
+  // ---- descriptor tables (bytes), sized from what was actually built (round 2 reserved 64 pack / 192 reduce
+  //      descriptors without a check) ----
+  p.pack_off_b = 0;
+  p.groups_off_b = align_up((p.pack.size() + 1) * sizeof(PackDesc), 256);
+  p.reduce_off_b = p.groups_off_b + align_up(specs.size() * sizeof(WgradGroup) + 256, 256);
+  p.segs_off_b = p.reduce_off_b + align_up((p.reduce.size() + 1) * sizeof(ReduceDesc), 256);
+  p.segbegin_off_b = p.segs_off_b + align_up(p.segs.size() * sizeof(WgradSegment) + 256, 256);
+  p.emb_off_b = p.segbegin_off_b + align_up((p.seg_begin.size() + 1) * sizeof(int), 256);
+  p.bgroups_off_b = p.emb_off_b + align_up((h->emb.size() + 1) * sizeof(EmbedDesc), 256);
+  p.bsegs_off_b = p.bgroups_off_b + align_up(bspecs.size() * sizeof(WgradGroup) + 256, 256);
+  p.bsegbegin_off_b = p.bsegs_off_b + align_up(p.bsegs.size() * sizeof(WgradSegment) + 256, 256);
+  const size_t table_bytes = p.bsegbegin_off_b + align_up((p.bseg_begin.size() + 1) * sizeof(int), 256);
+  p.tables = take(table_bytes / 4);
   p.total_floats = o;
 }
 
@@ -966,7 +976,8 @@ BfStash bf_stash(const WsPlan& p, int lv, float* ws) {
   return b;
 }
 
-ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train, const nrf_rand* rnd) {
+ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train, const nrf_rand* rnd,
+                      const nrf_dynamic_scalars* dyn = nullptr) {
   const WsPlan& p = h->plan;
   const LevelWs& L = p.L[lv];
   ChainFwdArgs a;
@@ -983,6 +994,7 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
     a.noise_std = h->d.noise_std;
     a.noise = rnd ? (lv == 0 ? rnd->noise_coarse : rnd->noise_fine) : nullptr;
     a.noise_seed = rnd ? rnd->seed : 0; a.noise_offset = rnd ? rnd->offset : 0; a.noise_stream = 2u + (unsigned)lv;
+    a.dyn = dyn;
   }
   if (train && (p.flags & NRF_FLAG_BF16)) {
     a.bst = bf_stash(p, lv, ws);
@@ -1021,7 +1033,8 @@ double wgrad_flops_row(nrf_handle h) {
   return 2.0 * (2 * P * 256 + 7 * 65536.0 + 65536.0 + (256 + R) * 128 + 256 + 128 * 3);
 }
 
-WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float alpha, float* ws, bool train) {
+WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, const nrf_step_scalars* sc, float* ws, bool train) {
+  const float alpha = sc->warp_alpha;
   const WsPlan& p = h->plan;
   const LevelWs& L = p.L[lv];
   WarpFwdArgs a;
@@ -1035,7 +1048,7 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
   a.embed_table = rays->warp_codes ? rays->warp_codes : h->time_enc ? ws + p.t_codes : params + h->wpo.embed;
   a.points_out = ws + L.wpoints; a.points_raw = ws + L.points_raw;
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
-  a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = alpha;
+  a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = alpha; a.dyn = sc->dynamic;
   a.tile_counter = tile_counter_or_null(ws + p.counters, CT_WARP_FWD + lv);
   if (train) {   // train: here "keep the stash" (training plan, or an inference plan that returns the Jacobian)
     a.st_win = ws + L.w_st_win; a.st_h = ws + L.w_st_h; a.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
@@ -1045,11 +1058,11 @@ WarpFwdArgs warp_fwd_args(nrf_handle h, int lv, const float* params, const nrf_r
 }
 
 // forward-mode pass of the warp Jacobian of level lv (warping.py:385-387): 3 tangent tiles per primal tile
-void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float alpha, float* ws, int gmul, hipStream_t stream) {
+void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_rays* rays, const nrf_step_scalars* sc, float* ws, int gmul, hipStream_t stream) {
   const WsPlan& p = h->plan;
   const LevelWs& L = p.L[lv];
   const LevelWs& T = p.L[TG];
-  WarpFwdArgs ta = warp_fwd_args(h, lv, params, rays, alpha, ws, true);
+  WarpFwdArgs ta = warp_fwd_args(h, lv, params, rays, sc, ws, true);
   ta.nt_prim = p.ntiles[lv]; ta.prim_win = ws + L.w_st_win; ta.prim_bits = reinterpret_cast<const uint32_t*>(ws + L.w_bits);
   ta.ntiles = 3 * p.ntiles[lv]; ta.rows = ta.ntiles * TILE_ROWS;
   ta.st_win = ws + T.w_st_win; ta.st_h = ws + T.w_st_h; ta.st_wv = reinterpret_cast<float4*>(ws + T.w_st_wv);
@@ -1061,7 +1074,8 @@ void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_ray
   h->prof.end(stream);
 }
 
-WarpFwdArgs bg_fwd_args(nrf_handle h, const float* params, const nrf_background* bg, float alpha, float* ws);
+WarpFwdArgs bg_fwd_args(nrf_handle h, const float* params, const nrf_background* bg, const nrf_step_scalars* sc, float* ws);
+void draw_background(nrf_handle h, const nrf_background* bg, const nrf_rand* rnd, const nrf_step_scalars* sc, float* ws, hipStream_t stream);
 
 int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, const nrf_step_scalars* scalars, const nrf_rand* rnd,
                  const nrf_outputs* out, uint32_t flags, float* ws, size_t ws_bytes, hipStream_t stream, int bgN = 0,
@@ -1119,14 +1133,16 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
     ra.cond = ws + p.cond;
     launch_ray_prep(ra, stream);
   }
+  const nrf_dynamic_scalars* dyn = scalars ? scalars->dynamic : nullptr;
   launch_sample_coarse(rnd ? rnd->t_rand : nullptr, B, p.S[0], d.near_plane, d.far_plane, d.use_stratified_sampling,
-                       d.use_linear_disparity, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0, ws + p.L[0].z, stream);
+                       d.use_linear_disparity, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0, dyn, ws + p.L[0].z, stream);
+  if (train && bg && p.bgN > 0 && warp_on) draw_background(h, bg, rnd, scalars, ws, stream);
   pf.end(stream);
   if (warp_on && h->time_enc && !rays->warp_codes) {   // modules.TimeEncoder once per ray (warping.py:311-313, models.py:252-254)
     TimeEncArgs ta;
     memset(&ta, 0, sizeof(ta));
     ta.params = params; ta.po = h->tpo; ta.time = rays->time; ta.B = B; ta.F = h->Ft; ta.Tin = h->Tin; ta.G = h->G;
-    ta.alpha = scalars->time_alpha; ta.codes = ws + p.t_codes;
+    ta.alpha = scalars->time_alpha; ta.dyn = dyn; ta.codes = ws + p.t_codes;
     if (train) { ta.st_in = ws + p.t_in; ta.st_h = ws + p.t_h; }
     launch_time_encoder_fwd(ta, stream);
   }
@@ -1135,29 +1151,29 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
     if (lv == 1) {
       pf.begin("sample_pdf", 0, stream);
       launch_sample_fine(ws + p.L[0].z, ws + p.L[0].weights, B, d.num_coarse_samples, d.num_fine_samples,
-                         d.use_stratified_sampling, rnd ? rnd->u : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0,
+                         d.use_stratified_sampling, rnd ? rnd->u : nullptr, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0, dyn,
                          ws + L.z, stream);
       pf.end(stream);
     }
-    ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train, rnd);
+    ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train, rnd, dyn);
     const int gmul = getenv("NRF_GRID_MUL") ? atoi(getenv("NRF_GRID_MUL")) : 2;
     const int grid = p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus;   // two workgroups per CU
     if (warp_on) {
       // the background-point batch of the fused train step rides in the coarse launch (its 256 tiles under-fill the chip)
       const bool with_bg = lv == 0 && train && bg && p.bgN > 0;
       WarpFwdArgs bga;
-      if (with_bg) bga = bg_fwd_args(h, params, bg, scalars->warp_alpha, ws);
+      if (with_bg) bga = bg_fwd_args(h, params, bg, scalars, ws);
       const int wnt = p.ntiles[lv] + (with_bg ? p.ntiles[BG] : 0);
       const int wgrid = wnt < gmul * h->num_cus ? wnt : gmul * h->num_cus;
       pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * (p.rows[lv] + (with_bg ? p.bgN : 0)), stream);
-      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars->warp_alpha, ws, train || jac), with_bg ? &bga : nullptr,
+      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars, ws, train || jac), with_bg ? &bga : nullptr,
                       train || jac, wgrid, stream);
       pf.end(stream);
       a.points = ws + L.wpoints;
       // forward-mode Jacobian of the warp: on the coarse samples for the elastic regulariser (models.py:345), per level
       // as an output (return_warp_jacobian, models.py:345-346, 367-368)
       float* jout = !out ? nullptr : lv == 0 ? out->coarse.warp_jacobian : out->fine.warp_jacobian;
-      if ((lv == 0 && train && p.elastic) || (jac && jout)) launch_tangent_fwd(h, lv, params, rays, scalars->warp_alpha, ws, gmul, stream);
+      if ((lv == 0 && train && p.elastic) || (jac && jout)) launch_tangent_fwd(h, lv, params, rays, scalars, ws, gmul, stream);
       if (jac && jout) {
         JacobianArgs ja;
         ja.prim_win = ws + L.w_st_win; ja.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
@@ -1189,8 +1205,10 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       CK(copy_out(lo.acc, ws + L.acc, B, stream));
       CK(copy_out(lo.weights, ws + L.weights, (size_t)p.rows[lv], stream));
       CK(copy_out(lo.z_vals, ws + L.z, (size_t)p.rows[lv], stream));
-      if (lo.points || lo.warped_points) {
-        if (!warp_on) return fail(NRF_E_UNSUPPORTED, "points / warped_points outputs need the warp field");
+      if (lo.warped_points && !warp_on) return fail(NRF_E_UNSUPPORTED, "the warped_points output needs the warp field (models.py:266-267)");
+      if (lo.points && !warp_on)   // models.py:247-248: `points` is returned whether or not the model warps
+        launch_sample_points(rays->origins, rays->directions, ws + L.z, B, p.S[lv], lo.points, stream);
+      else if (lo.points || lo.warped_points) {
         CK(copy_out(lo.points, ws + L.points_raw, (size_t)p.rows[lv] * 3, stream));
         CK(copy_out(lo.warped_points, ws + L.wpoints, (size_t)p.rows[lv] * 3, stream));
       }
@@ -1198,6 +1216,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   }
   CK(check_launch("nrf_forward"));
   h->stashed_ws = train ? (void*)ws : nullptr;
+  h->stashed_plan = train ? p.serial : 0;
   h->stashed_B = train ? B : -1;
   h->stashed_warp = warp_on;
   return NRF_OK;
@@ -1205,19 +1224,33 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
 
 // SE3 field on the (already noised) background points, one warp id per point (training.compute_background_loss,
 // training.py:117-135): forward arguments of the BG level
-WarpFwdArgs bg_fwd_args(nrf_handle h, const float* params, const nrf_background* bg, float alpha, float* ws) {
+// the points / ids the background level runs on: the caller's (already noised, ids given) or the library's own draw
+const float* bg_points_of(const WsPlan& p, const nrf_background* bg, const float* ws) { return bg->warp_ids ? bg->points : ws + p.bg_points; }
+const int32_t* bg_ids_of(const WsPlan& p, const nrf_background* bg, const float* ws) {
+  return bg->warp_ids ? bg->warp_ids : reinterpret_cast<const int32_t*>(ws + p.bg_ids);
+}
+
+WarpFwdArgs bg_fwd_args(nrf_handle h, const float* params, const nrf_background* bg, const nrf_step_scalars* sc, float* ws) {
   const WsPlan& p = h->plan;
   const LevelWs& L = p.L[BG];
   WarpFwdArgs fa;
   memset(&fa, 0, sizeof(fa));
   fa.params = params; fa.po = h->wpo; fa.wpk = ws + p.warp_wpk; fa.pk = h->wpk;
-  fa.points_in = bg->points; fa.point_ids = bg->warp_ids; fa.points_out = ws + L.wpoints;
+  fa.points_in = bg_points_of(p, bg, ws); fa.point_ids = bg_ids_of(p, bg, ws); fa.points_out = ws + L.wpoints;
   fa.embed_table = params + h->wpo.embed;
   fa.S = 1; fa.B = p.bgN; fa.rows = p.bgN; fa.ntiles = p.ntiles[BG];
-  fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = alpha;
+  fa.F = h->Fw; fa.G = h->G; fa.Win = h->Win; fa.PKw = h->PKw; fa.alpha = sc->warp_alpha; fa.dyn = sc->dynamic;
   fa.st_win = ws + L.w_st_win; fa.st_h = ws + L.w_st_h; fa.st_wv = reinterpret_cast<float4*>(ws + L.w_st_wv);
   fa.bits = reinterpret_cast<uint32_t*>(ws + L.w_bits);
   return fa;
+}
+
+// nrf_background.warp_ids == NULL: training.py:121-126 on the device (ids from id_choices, noise added), into the workspace
+void draw_background(nrf_handle h, const nrf_background* bg, const nrf_rand* rnd, const nrf_step_scalars* sc, float* ws, hipStream_t stream) {
+  const WsPlan& p = h->plan;
+  if (bg->warp_ids) return;
+  launch_background_draw(bg->points, p.bgN, bg->id_choices, bg->num_choices, bg->noise_std, rnd ? rnd->seed : 0, rnd ? rnd->offset : 0,
+                         sc ? sc->dynamic : nullptr, ws + p.bg_points, reinterpret_cast<int32_t*>(ws + p.bg_ids), stream);
 }
 
 // d_rgb[lv] != nullptr: upstream gradient mode; else MSE-loss mode against `target`.
@@ -1305,6 +1338,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     h->prof.begin("mlp_dgrad", dgrad_flops_row(h, warp_on) * mlp_rows, stream);
     launch_chain_bwd(ca[0], h->nlevels > 1 ? &ca[1] : nullptr, nt_all < G2 ? nt_all : G2, stream);
     h->prof.end(stream);
+    (void)nt_all;
   }
   if (el_on) {   // training.compute_elastic_loss on the coarse samples
     const LevelWs& L = p.L[0];
@@ -1322,6 +1356,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     ea.sums = ws + p.el_sums;
     ea.rows = p.rows[0]; ea.rows_pad = p.ntiles[0] * TILE_ROWS; ea.PKS = (h->PKw + 31) / 32 * 32;
     ea.eps = el->eps; ea.alpha = el->loss_alpha; ea.scale = el->loss_scale; ea.gscale = el->loss_weight / (float)B;
+    ea.inv_rays = 1.0f / (float)B; ea.dyn = scalars ? scalars->dynamic : nullptr;
     ea.loss_type = el->loss_type;
     h->prof.begin("elastic", 0, stream);
     launch_elastic(ea, stream);
@@ -1339,11 +1374,12 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     const LevelWs& L = p.L[BG];
     if (!bg_forward_done) {   // nrf_forward + nrf_backward path: the fused train step ran it inside the coarse warp launch
       const int grid = p.ntiles[BG] < G2 ? p.ntiles[BG] : G2;
+      draw_background(h, bg, nullptr, scalars, ws, stream);
       h->prof.begin("warp_fwd_bg", warp_fwd_flops_row(h) * p.bgN, stream);
-      launch_warp_fwd(bg_fwd_args(h, params, bg, scalars->warp_alpha, ws), nullptr, true, grid, stream);
+      launch_warp_fwd(bg_fwd_args(h, params, bg, scalars, ws), nullptr, true, grid, stream);
       h->prof.end(stream);
     }
-    launch_background_loss(bg->points, ws + L.wpoints, p.bgN, p.ntiles[BG] * TILE_ROWS, bg->loss_alpha, bg->loss_scale,
+    launch_background_loss(bg_points_of(p, bg, ws), ws + L.wpoints, p.bgN, p.ntiles[BG] * TILE_ROWS, bg->loss_alpha, bg->loss_scale,
                            bg->loss_weight, ws + L.d_points, ws + p.bg_loss, stream);
   }
   if (warp_on) {
@@ -1376,7 +1412,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       WarpBwdArgs& w = wa[nlev++];
       common(w, BG);
       w.B = p.bgN; w.S = 1;
-      w.point_ids = bg->warp_ids;
+      w.point_ids = bg_ids_of(p, bg, ws);
       w.grad_embed = grad + h->wpo.embed;
     }
     h->prof.begin("warp_dgrad", warp_dgrad_flops_row(h) * rows_all, stream);
@@ -1454,7 +1490,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       sa.el_weight = el->loss_weight;
     }
     if (wr_on) { sa.wr_sums = ws + p.wr_sums; sa.wr_weight = wr->loss_weight; }
-    sa.stats = stats;
+    sa.stats = stats; sa.dyn = scalars ? scalars->dynamic : nullptr;
     launch_finish_stats(sa, stream);
   }
   h->prof.end(stream);
@@ -1565,6 +1601,9 @@ int nrf_backward(nrf_handle h, const float* params, const nrf_rays* rays, const 
   if (!h || !params || !rays || !grad_params || !workspace) return fail(NRF_E_NULL, "null argument");
   if (h->stashed_ws != workspace || h->stashed_B != rays->num_rays)
     return fail(NRF_E_STATE, "nrf_backward needs a preceding nrf_forward(NRF_FLAG_TRAIN) on this workspace");
+  if (h->stashed_plan != h->plan.serial)   // another call re-planned the handle (other num_rays / flags) since the stashed forward
+    return fail(NRF_E_STATE, "nrf_backward: the workspace layout changed since the stashed nrf_forward (an intervening call with "
+                             "another num_rays / flags); run nrf_forward(NRF_FLAG_TRAIN) again");
   if (workspace_bytes < h->plan.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small");
   float* ws = (float*)workspace;
   hipStream_t st = (hipStream_t)stream;
@@ -1606,7 +1645,9 @@ int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_ray
   if (bg && bg->num_points > 0) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the background regulariser needs the warp field");
     if (h->time_enc) return fail(NRF_E_UNSUPPORTED, "the background regulariser draws warp IDS (training.py:121-123): not defined for the time encoder");
-    if (!bg->points || !bg->warp_ids) return fail(NRF_E_NULL, "background points / warp_ids is null");
+    if (!bg->points) return fail(NRF_E_NULL, "background points is null");
+    if (!bg->warp_ids && (!bg->id_choices || bg->num_choices <= 0))
+      return fail(NRF_E_NULL, "background: give warp_ids (points already noised) or id_choices (the library draws ids and noise)");
     if (!scalars) return fail(NRF_E_NULL, "nrf_step_scalars required");
     bgN = bg->num_points;
   }
@@ -1707,7 +1748,7 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   a.points_in = points; a.point_ids = warp_ids; a.points_out = ws + q.out_f;
   a.embed_table = params + wo.embed;
   a.S = 1; a.B = num_points; a.rows = num_points; a.ntiles = q.ntiles;
-  a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha;
+  a.F = h->Fw; a.G = h->G; a.Win = h->Win; a.PKw = h->PKw; a.alpha = scalars->warp_alpha; a.dyn = scalars->dynamic;
   const int grid = q.ntiles < 2 * h->num_cus ? q.ntiles : 2 * h->num_cus;
   e = hipMemsetAsync(ws + q.ctr_f, 0, 16 * sizeof(int), st);
   if (e != hipSuccess) return fail_hip(e, "zero tile counter");
@@ -1755,6 +1796,7 @@ int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* 
       {"w_bits", L.w_bits}, {"bits_trunk", L.bits_trunk}, {"bits_rgbh", L.bits_rgbh},
       {"b_pe", L.b_pe}, {"b_h", L.b_h}, {"b_bn", L.b_bn}, {"b_rgbh", L.b_rgbh}, {"b_bits", L.b_bits}, {"b_dy", L.b_dy},
       {"b_dbn", L.b_dbn}, {"b_drgbh", L.b_drgbh}, {"b_dsmall", L.b_dsmall},
+      {"bg_points", h->plan.bg_points}, {"bg_ids", h->plan.bg_ids},
       {"timeline", h->plan.timeline + (size_t)(level & 1) * 2 * (256 + 512 + 4 * 2048)}};
   for (const auto& t : tab)
     if (!strcmp(t.n, name)) { *float_offset = (int64_t)t.v; return NRF_OK; }
@@ -1790,6 +1832,20 @@ int nrf_adam_step(float* params, float* m, float* v, const float* grad, int64_t 
   return check_launch("nrf_adam_step");
 }
 
+int nrf_dynamic_scalars_write(nrf_dynamic_scalars* device_dst, const nrf_dynamic_scalars* host_values, void* stream) {
+  if (!device_dst || !host_values) return fail(NRF_E_NULL, "null argument");
+  launch_dynamic_write(device_dst, *host_values, (hipStream_t)stream);
+  return check_launch("nrf_dynamic_scalars_write");
+}
+
+int nrf_adam_step_dynamic(float* params, float* m, float* v, const float* grad, int64_t n, double beta1, double beta2, double eps,
+                          const nrf_dynamic_scalars* dynamic, void* stream) {
+  if (!params || !m || !v || !grad || !dynamic) return fail(NRF_E_NULL, "null argument");
+  if (n <= 0) return fail(NRF_E_SHAPE, "n must be positive");
+  launch_adam_dynamic(params, m, v, grad, n, beta1, beta2, eps, dynamic, (hipStream_t)stream);
+  return check_launch("nrf_adam_step_dynamic");
+}
+
 int nrf_sample_along_rays(const float* origins, const float* directions, int32_t num_rays, int32_t num_samples,
                           float near_plane, float far_plane, int32_t stratified, int32_t linear_disparity,
                           const float* t_rand, uint64_t seed, uint64_t offset, float* z_vals, void* stream) {
@@ -1797,7 +1853,7 @@ int nrf_sample_along_rays(const float* origins, const float* directions, int32_t
   if (!z_vals) return fail(NRF_E_NULL, "z_vals is null");
   if (num_rays <= 0 || num_samples < 2) return fail(NRF_E_SHAPE, "bad shape");
   launch_sample_coarse(t_rand, num_rays, num_samples, near_plane, far_plane, stratified, linear_disparity, seed, offset,
-                       z_vals, (hipStream_t)stream);
+                       nullptr, z_vals, (hipStream_t)stream);
   return check_launch("nrf_sample_along_rays");
 }
 
@@ -1818,7 +1874,7 @@ int nrf_sample_pdf(const float* z_coarse, const float* weights_coarse, int32_t n
   if (!z_coarse || !weights_coarse || !z_out) return fail(NRF_E_NULL, "null argument");
   if (num_rays <= 0 || num_coarse < 3 || num_coarse > 256 || num_fine < 1 || num_coarse + num_fine > 512)
     return fail(NRF_E_SHAPE, "need 3 <= num_coarse <= 256 and num_coarse + num_fine <= 512");
-  launch_sample_fine(z_coarse, weights_coarse, num_rays, num_coarse, num_fine, stratified, u, seed, offset, z_out,
+  launch_sample_fine(z_coarse, weights_coarse, num_rays, num_coarse, num_fine, stratified, u, seed, offset, nullptr, z_out,
                      (hipStream_t)stream);
   return check_launch("nrf_sample_pdf");
 }

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/nerfies_amd.h"
+
 namespace nrf {
 
 constexpr int TILE_ROWS = 64;    // rows (ray samples) per workgroup tile; two workgroups per CU
@@ -76,6 +78,7 @@ struct TimeEncArgs {
   const float* time;       // [B] time stamps (metadata['time'])
   int B, F, Tin, G;        // rays, posenc freqs, 1 + 2F, code width
   float alpha;             // warp_extra['time_alpha']
+  const nrf_dynamic_scalars* dyn;   // device-resident step scalars (overrides alpha) or nullptr
   float* codes;            // [B][G] out
   const float* d_codes;    // [B][G] (backward)
   float* st_in;            // [B][TIME_MAX_IN] encoder input (training stash) or nullptr
@@ -159,6 +162,7 @@ struct ChainFwdArgs {
   float noise_std;
   unsigned long long noise_seed, noise_offset;
   unsigned noise_stream;
+  const nrf_dynamic_scalars* dyn;   // device-resident step scalars (overrides the noise seed / offset) or nullptr
   // activation stash (training only)
   float* st_pe;              // [ntiles][PK][128]
   float* st_h;               // [8][ntiles][256*128]  h1..h8, fragment-native
@@ -211,6 +215,7 @@ struct WarpFwdArgs {
   int S, B, rows, ntiles;
   int F, G, Win, PKw;        // warp freqs, code width, 3+6F+G, Win rounded up to a multiple of 8
   float alpha;               // warp_extra['alpha']
+  const nrf_dynamic_scalars* dyn;   // device-resident step scalars (overrides alpha) or nullptr
   float* st_win;             // [ntiles][PKw][128] trunk input (training stash)
   float* st_h;               // [6][ntiles][128*128] h1..h6, fragment-native
   float4* st_wv;             // [ntiles*128][2] raw head outputs (w, v)
@@ -261,6 +266,8 @@ struct ElasticArgs {
   int rows, rows_pad, PKS;
   float eps, alpha, scale;
   float gscale;              // elastic_loss_weight / num_rays
+  float inv_rays;            // 1 / num_rays
+  const nrf_dynamic_scalars* dyn;   // device-resident step scalars: gscale = dyn->elastic_loss_weight * inv_rays
   int res_selected;          // 'median': the residual statistic only counts the selected sample of each ray
   int loss_type;             // NRF_ELASTIC_LOG_SVALS ...
 };
@@ -361,8 +368,9 @@ struct RayPrepArgs {
 };
 void launch_ray_prep(const RayPrepArgs& a, hipStream_t stream);
 void launch_sample_coarse(const float* t_rand, int B, int N, float near_p, float far_p,
-                          int stratified, int lindisp, uint64_t seed, uint64_t offset,
+                          int stratified, int lindisp, uint64_t seed, uint64_t offset, const nrf_dynamic_scalars* dyn,
                           float* z, hipStream_t stream);
+void launch_sample_points(const float* origins, const float* dirs, const float* z, int B, int S, float* out, hipStream_t stream);
 void launch_composite_fwd(const float4* out4, const float* z, const float* dirs, int B, int S,
                           int white_bkgd, int sample_at_inf, float* rgb, float* depth,
                           float* med_depth, float* acc, float* weights, hipStream_t stream);
@@ -377,8 +385,11 @@ void launch_alpha_cond_grad(const float* params, const float* cond, const float*
 void launch_warp_reg(const float* weights, const float* points, const float* warped, int B, int S, float alpha, float scale,
                      float gscale, float* d_points, float* sums, hipStream_t stream);
 void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int Nf, int stratified,
-                        const float* u, uint64_t seed, uint64_t offset, float* z_out,
+                        const float* u, uint64_t seed, uint64_t offset, const nrf_dynamic_scalars* dyn, float* z_out,
                         hipStream_t stream);
+// training.compute_background_loss's draws (training.py:121-126) on the device: id = choices[floor(U n)], x += std N(0,1)
+void launch_background_draw(const float* points, int N, const int32_t* choices, int nchoices, float noise_std, uint64_t seed,
+                            uint64_t offset, const nrf_dynamic_scalars* dyn, float* out_points, int32_t* out_ids, hipStream_t stream);
 void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst /*[R][128]*/,
                        hipStream_t stream);
 void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
@@ -390,6 +401,7 @@ struct StatsArgs {
   const float* el_sums; int el_rows, el_jac_rows; float el_weight;
   const float* wr_sums; float wr_weight;   // [4]: loss coarse, residual coarse, loss fine, residual fine
   float* stats;
+  const nrf_dynamic_scalars* dyn;          // device-resident step scalars (overrides el_weight) or nullptr
 };
 void launch_finish_stats(const StatsArgs& a, hipStream_t stream);
 void launch_background_loss(const float* points, const float* warped, int N, int rows_pad, float alpha, float scale,
@@ -404,6 +416,9 @@ struct ZeroArgs {
 void launch_zero_ranges(const ZeroArgs& a, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,
                  double b2, double eps, int64_t step, double gscale, hipStream_t stream);
+void launch_dynamic_write(nrf_dynamic_scalars* dst, const nrf_dynamic_scalars& v, hipStream_t stream);
+void launch_adam_dynamic(float* p, float* m, float* v, const float* g, int64_t n, double b1, double b2, double eps,
+                         const nrf_dynamic_scalars* dyn, hipStream_t stream);
 
 // Narrower models run on the 256-wide / 128-wide kernels by embedding: the caller's parameter leaves are copied into
 // a zero-filled internal image with the kernels' widths (zero weights and biases for the extra units: relu(0) = 0 and

@@ -9,6 +9,7 @@
 //   training._compute_loss_and_stats MSE/psnr   training.py:172,225 ; utils.py:94-103
 //   flax.optim.Adam.apply_gradient        training.py:268-269
 #include "nrf_internal.h"
+#include "general_loss.h"
 #include "philox.h"
 
 namespace nrf {
@@ -90,9 +91,10 @@ __device__ __forceinline__ float coarse_z(int s, int N, float near_p, float far_
 
 __global__ void sample_coarse_kernel(const float* __restrict__ t_rand, int B, int N, float near_p, float far_p,
                                      int stratified, int lindisp, uint64_t seed, uint64_t offset,
-                                     float* __restrict__ z) {
+                                     const nrf_dynamic_scalars* __restrict__ dyn, float* __restrict__ z) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= B * N) return;
+  if (dyn) { seed = dyn->rng_seed; offset = dyn->rng_offset; }   // graph-replayable step: the key lives on the device
   const int s = idx % N;
   const float zc = coarse_z(s, N, near_p, far_p, lindisp);
   if (!stratified) { z[idx] = zc; return; }
@@ -105,11 +107,29 @@ __global__ void sample_coarse_kernel(const float* __restrict__ t_rand, int B, in
   z[idx] = lower + (upper - lower) * t;
 }
 
+// points = origins + z_vals * directions (model_utils.py:72-73, :213-215) as an OUTPUT: with the warp field the warp kernel
+// writes them; without it the MLP kernel forms them in its prologue and never stores them, so return_points
+// (models.py:247-248 returns `points` whether or not the model warps) gets its own small kernel.
+__global__ void sample_points_kernel(const float* __restrict__ origins, const float* __restrict__ dirs, const float* __restrict__ z,
+                                     int rows, int S, float* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int ray = r / S;
+  const float zi = z[r];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out[3 * (size_t)r + c] = __fadd_rn(origins[3 * ray + c], __fmul_rn(zi, dirs[3 * ray + c]));
+}
+
+void launch_sample_points(const float* origins, const float* dirs, const float* z, int B, int S, float* out, hipStream_t stream) {
+  const int rows = B * S;
+  hipLaunchKernelGGL(sample_points_kernel, dim3((rows + 255) / 256), dim3(256), 0, stream, origins, dirs, z, rows, S, out);
+}
+
 void launch_sample_coarse(const float* t_rand, int B, int N, float near_p, float far_p, int stratified, int lindisp,
-                          uint64_t seed, uint64_t offset, float* z, hipStream_t stream) {
+                          uint64_t seed, uint64_t offset, const nrf_dynamic_scalars* dyn, float* z, hipStream_t stream) {
   const int total = B * N;
   hipLaunchKernelGGL(sample_coarse_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, t_rand, B, N, near_p,
-                     far_p, stratified, lindisp, seed, offset, z);
+                     far_p, stratified, lindisp, seed, offset, dyn, z);
 }
 
 // ------------------------------------------------------------------ compositing
@@ -287,8 +307,10 @@ constexpr int SF_MAXT = 512;   // max coarse + fine samples
 
 __global__ __launch_bounds__(256) void sample_fine_kernel(
     const float* __restrict__ z_c, const float* __restrict__ w_c, int B, int Nc, int Nf, int stratified,
-    const float* __restrict__ u_in, uint64_t seed, uint64_t offset, float* __restrict__ z_out) {
+    const float* __restrict__ u_in, uint64_t seed, uint64_t offset, const nrf_dynamic_scalars* __restrict__ dyn,
+    float* __restrict__ z_out) {
   __shared__ float s_bins[4][SF_MAXC];
+  if (dyn) { seed = dyn->rng_seed; offset = dyn->rng_offset; }
   __shared__ float s_cdf[4][SF_MAXC];
   __shared__ float s_all[4][SF_MAXT];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -342,9 +364,9 @@ __global__ __launch_bounds__(256) void sample_fine_kernel(
 }
 
 void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int Nf, int stratified, const float* u,
-                        uint64_t seed, uint64_t offset, float* z_out, hipStream_t stream) {
+                        uint64_t seed, uint64_t offset, const nrf_dynamic_scalars* dyn, float* z_out, hipStream_t stream) {
   hipLaunchKernelGGL(sample_fine_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, z_c, w_c, B, Nc, Nf, stratified, u,
-                     seed, offset, z_out);
+                     seed, offset, dyn, z_out);
 }
 
 // ------------------------------------------------------------------ small gradient pieces
@@ -449,7 +471,8 @@ __global__ void finish_stats_kernel(const StatsArgs A) {
     stats[0] = mc; stats[1] = mf;
     stats[2] = -10.f * logf(mc) / logf(10.f);   // utils.compute_psnr (utils.py:94-103)
     stats[3] = -10.f * logf(mf) / logf(10.f);
-    stats[4] = mc + mf + A.bg_weight * bgl + A.el_weight * ell + A.wr_weight * (wrc + wrf);   // training.py:261 (+ :197, :212, :257-258)
+    const float el_weight = A.dyn ? A.dyn->elastic_loss_weight : A.el_weight;
+    stats[4] = mc + mf + A.bg_weight * bgl + el_weight * ell + A.wr_weight * (wrc + wrf);   // training.py:261 (+ :197, :212, :257-258)
     stats[5] = bgl;                               // stats['background_loss'] (training.py:259)
     stats[6] = ell;                               // stats['loss/elastic']
     stats[7] = A.el_sums ? A.el_sums[1] / (float)A.el_rows : 0.f;   // stats['residual/elastic'] (training.py:196)
@@ -494,11 +517,8 @@ __global__ __launch_bounds__(256) void warp_reg_kernel(const float* __restrict__
     float r[3], q = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { r[c] = warped[3 * row + c] - pts[3 * row + c]; q += r[c] * r[c]; }
-    const float beta = fmaxf(1.1920929e-7f, fabsf(alpha - 2.f));
-    const float a_safe = (alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(alpha));
-    const float u = q / (scale * scale * beta) + 1.f;
-    const float rho = scale * (beta / a_safe) * (powf(u, 0.5f * alpha) - 1.f);
-    const float drho = (0.5f / scale) * powf(u, 0.5f * alpha - 1.f);
+    float rho, drho;
+    general_loss_sq(q, alpha, scale, rho, drho);
 #pragma unroll
     for (int c = 0; c < 3; ++c) d_points[3 * row + c] += gscale * drho * 2.f * r[c];
     atomicAdd(sums, rho);
@@ -537,9 +557,8 @@ void launch_median_coef(const float* weights, int B, int S, float* coef, hipStre
 }
 
 // ------------------------------------------------------------------ background regulariser
-// loss_i = general_loss_with_squared_residual(|x'_i - x_i|^2, alpha, scale) (utils.py:264-331, finite alpha not in
-// {0,2}):  rho(q) = scale * (beta/alpha) * ((q/(scale^2 beta) + 1)^(alpha/2) - 1),  beta = |alpha - 2|;
-// d rho/d x' = rho'(q) * 2 (x' - x),  rho'(q) = (1/(2 scale)) (q/(scale^2 beta) + 1)^(alpha/2 - 1).
+// loss_i = general_loss_with_squared_residual(|x'_i - x_i|^2, alpha, scale) (utils.py:264-331, every branch:
+// general_loss.h);  d rho/d x' = rho'(q) * 2 (x' - x).
 // d_points = weight/N * d rho/d x' (0 on the tile padding rows);  loss_sum += sum_i rho_i.
 __global__ __launch_bounds__(256) void background_loss_kernel(const float* __restrict__ pts, const float* __restrict__ warped,
                                                               int N, int rows_pad, float alpha, float scale, float gscale,
@@ -549,14 +568,11 @@ __global__ __launch_bounds__(256) void background_loss_kernel(const float* __res
   if (i < rows_pad) {
     float g[3] = {0.f, 0.f, 0.f};
     if (i < N) {
-      const float beta = fmaxf(1.1920929e-7f, fabsf(alpha - 2.f));
-      const float a_safe = (alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(alpha));
       float r[3], q = 0.f;
 #pragma unroll
       for (int c = 0; c < 3; ++c) { r[c] = warped[3 * i + c] - pts[3 * i + c]; q += r[c] * r[c]; }
-      const float u = q / (scale * scale * beta) + 1.f;
-      rho = scale * (beta / a_safe) * (powf(u, 0.5f * alpha) - 1.f);
-      const float drho = (0.5f / scale) * powf(u, 0.5f * alpha - 1.f);
+      float drho;
+      general_loss_sq(q, alpha, scale, rho, drho);
 #pragma unroll
       for (int c = 0; c < 3; ++c) g[c] = gscale * drho * 2.f * r[c];
     }
@@ -572,6 +588,27 @@ void launch_background_loss(const float* points, const float* warped, int N, int
                      alpha, scale, weight / (float)N, d_points, loss_sum);
 }
 
+// training.compute_background_loss's two draws (training.py:121-126), one thread per point: warp id = choices[floor(U n)]
+// (random.choice over model.warp_ids; Philox stream 4), x += noise_std * N(0, 1) per coordinate (stream 5, element 3 i + c).
+__global__ __launch_bounds__(256) void background_draw_kernel(const float* __restrict__ pts, int N, const int32_t* __restrict__ choices,
+                                                              int nchoices, float noise_std, uint64_t seed, uint64_t offset,
+                                                              const nrf_dynamic_scalars* __restrict__ dyn, float* __restrict__ out_pts,
+                                                              int32_t* __restrict__ out_ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  if (dyn) { seed = dyn->rng_seed; offset = dyn->rng_offset; }
+  const int k = min((int)(philox_uniform(seed, offset, 4u, (uint32_t)i) * (float)nchoices), nchoices - 1);
+  out_ids[i] = choices[k];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) out_pts[3 * i + c] = pts[3 * i + c] + noise_std * philox_normal(seed, offset, 5u, (uint32_t)(3 * i + c));
+}
+
+void launch_background_draw(const float* points, int N, const int32_t* choices, int nchoices, float noise_std, uint64_t seed,
+                            uint64_t offset, const nrf_dynamic_scalars* dyn, float* out_points, int32_t* out_ids, hipStream_t stream) {
+  hipLaunchKernelGGL(background_draw_kernel, dim3((N + 255) / 256), dim3(256), 0, stream, points, N, choices, nchoices, noise_std, seed,
+                     offset, dyn, out_points, out_ids);
+}
+
 // ------------------------------------------------------------------ Adam
 __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
                             const float* __restrict__ g, int64_t n, float lr, float b1, float omb1, float b2,
@@ -583,6 +620,35 @@ __global__ void adam_kernel(float* __restrict__ p, float* __restrict__ m, float*
     m[i] = mi; v[i] = vi;
     p[i] = p[i] - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
   }
+}
+
+__global__ void dynamic_write_kernel(nrf_dynamic_scalars* __restrict__ dst, const nrf_dynamic_scalars v) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *dst = v;
+}
+void launch_dynamic_write(nrf_dynamic_scalars* dst, const nrf_dynamic_scalars& v, hipStream_t stream) {
+  hipLaunchKernelGGL(dynamic_write_kernel, dim3(1), dim3(64), 0, stream, dst, v);
+}
+
+// the same update with lr / bias corrections / grad scale read from the device-resident step scalars (graph-replayable)
+__global__ void adam_dynamic_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
+                                    const float* __restrict__ g, int64_t n, float b1, float omb1, float b2, float omb2, float eps,
+                                    const nrf_dynamic_scalars* __restrict__ dyn) {
+  const float lr = dyn->learning_rate, c1 = dyn->adam_c1, c2 = dyn->adam_c2, gscale = dyn->grad_scale;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float gi = g[i] * gscale;
+    const float mi = b1 * m[i] + omb1 * gi;
+    const float vi = b2 * v[i] + omb2 * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] = p[i] - lr * (mi / c1) / (sqrtf(vi / c2) + eps);
+  }
+}
+
+void launch_adam_dynamic(float* p, float* m, float* v, const float* g, int64_t n, double b1, double b2, double eps,
+                         const nrf_dynamic_scalars* dyn, hipStream_t stream) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(adam_dynamic_kernel, dim3(blocks), dim3(256), 0, stream, p, m, v, g, n, (float)b1, (float)(1.0 - b1), (float)b2,
+                     (float)(1.0 - b2), (float)eps, dyn);
 }
 
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1, double b2, double eps,

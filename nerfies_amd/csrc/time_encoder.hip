@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void time_encoder_fwd_kernel(const TimeEncArgs
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (ray >= A.B) return;
   const float* __restrict__ prm = A.params;
-  const float tin = lane < A.Tin ? time_feature(A.time[ray], lane, A.F, A.alpha) : 0.f;   // lane k holds input feature k
+  const float tin = lane < A.Tin ? time_feature(A.time[ray], lane, A.F, A.dyn ? A.dyn->time_alpha : A.alpha) : 0.f;   // lane k holds input feature k
   if (A.st_in && lane < TIME_MAX_IN) A.st_in[(size_t)ray * TIME_MAX_IN + lane] = tin;
   float h = 0.f;
   for (int l = 0; l < TIME_DEPTH; ++l) {

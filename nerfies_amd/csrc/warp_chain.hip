@@ -14,6 +14,7 @@
 // the VALU in the epilogue, one row per thread.
 #include "../../include/nerfies_amd.h"
 #include "chain_common.h"
+#include "general_loss.h"
 
 namespace nrf {
 
@@ -198,9 +199,10 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
       }
       const float half_pi = 1.57079632679489661923f;
       const float pi = 3.14159265358979323846f;
+      const float warp_alpha = A.dyn ? A.dyn->warp_alpha : A.alpha;   // device-resident in a graph-replayed step
       for (int f = part; f < A.F; f += 4) {
         // cosine_easing_window (modules.py:274-294): 0.5 (1 + cos(pi clip(alpha - band, 0, 1) + pi))
-        const float cl = fminf(fmaxf(A.alpha - (float)f, 0.f), 1.f);
+        const float cl = fminf(fmaxf(warp_alpha - (float)f, 0.f), 1.f);
         const float wdw = 0.5f * (1.f + cosf(__fadd_rn(__fmul_rn(pi, cl), pi)));
         const float fr = (float)(1 << f);
 #pragma unroll
@@ -726,15 +728,12 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) Gd[i][k] = M[i][k] + E[i][0] * M[0][k] + E[i][1] * M[1][k] + E[i][2] * M[2][k];   // J M, J = I + E
       }
-      const float beta = fmaxf(1.1920929e-7f, fabsf(A.alpha - 2.f));
-      const float a_safe = (A.alpha >= 0.f ? 1.f : -1.f) * fmaxf(1.1920929e-7f, fabsf(A.alpha));
-      const float u = sq / (A.scale * A.scale * beta) + 1.f;
-      const float rho = A.scale * (beta / a_safe) * (powf(u, 0.5f * A.alpha) - 1.f);
-      const float drho = (0.5f / A.scale) * powf(u, 0.5f * A.alpha - 1.f);
+      float rho, drho;
+      general_loss_sq(sq, A.alpha, A.scale, rho, drho);   // utils.py:264-331, every branch
       const float coef = A.coef[row];
       rho_c = coef * rho;
       res = (A.res_selected && coef == 0.f) ? 0.f : sqrtf(sq);
-      const float gs = coef * A.gscale * drho;
+      const float gs = coef * (A.dyn ? A.dyn->elastic_loss_weight * A.inv_rays : A.gscale) * drho;
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));

@@ -83,8 +83,9 @@ class DataSource:
   def __init__(self, train_ids, val_ids, use_appearance_id=False, use_camera_id=False, use_warp_id=False,
                use_depth=False, use_relative_depth=False, use_time=False, random_seed=0, train_stride=1, val_stride=1,
                preload=True, **_):
-    if use_depth or use_relative_depth or use_time:
-      raise NotImplementedError('depth / time inputs are not on the built path (no shipped preset uses them)')
+    if use_depth or use_relative_depth:
+      raise NotImplementedError('depth inputs are not on the built path (no shipped preset uses them)')
+    self.use_time = bool(use_time)   # metadata['time'] for the TimeEncoder (core.py:217, 602-603)
     self._train_ids, self._val_ids = list(train_ids), list(val_ids)
     self.train_stride, self.val_stride = train_stride, val_stride
     self.use_appearance_id, self.use_camera_id, self.use_warp_id = use_appearance_id, use_camera_id, use_warp_id
@@ -96,7 +97,7 @@ class DataSource:
   all_ids = property(lambda self: sorted(list(self.train_ids) + list(self.val_ids)))
   train_ids = property(lambda self: self._train_ids[::self.train_stride])
   val_ids = property(lambda self: self._val_ids[::self.val_stride])
-  has_metadata = property(lambda self: self.use_appearance_id or self.use_warp_id or self.use_camera_id)
+  has_metadata = property(lambda self: self.use_appearance_id or self.use_warp_id or self.use_camera_id or self.use_time)
 
   def _ids(self, kind, enabled, getter):
     """Sorted set of the raw ids seen in the TRAINING items; model embeddings are indexed by position in it."""
@@ -109,6 +110,11 @@ class DataSource:
   appearance_ids = property(lambda self: self._ids('appearance', self.use_appearance_id, self.get_appearance_id))
   camera_ids = property(lambda self: self._ids('camera', self.use_camera_id, self.get_camera_id))
   warp_ids = property(lambda self: self._ids('warp', self.use_warp_id, self.get_warp_id))
+  time_ids = property(lambda self: self._ids('time', self.use_time, self.get_time_id))   # core.py:298-303
+
+  def get_time(self, item_id) -> float:
+    """Time stamp in [-1, 1] (core.py:272-274): time_id / max(time_ids) * 2 - 1."""
+    return (self.get_time_id(item_id) / max(self.time_ids)) * 2.0 - 1.0
 
   def item_metadata(self, item_id) -> Dict[str, int]:
     """Embedding-table rows of an item (core.py:593-600)."""
@@ -119,6 +125,8 @@ class DataSource:
       md['camera'] = self.camera_ids.index(self.get_camera_id(item_id))
     if self.use_warp_id:
       md['warp'] = self.warp_ids.index(self.get_warp_id(item_id))
+    if self.use_time:   # a float, not a table row (core.py:602-603)
+      md['time'] = float(self.get_time(item_id))
     return md
 
   def get_item(self, item_id, scale_factor=1.0) -> Dict[str, Any]:

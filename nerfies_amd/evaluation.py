@@ -19,7 +19,8 @@ class GraphedChunkRenderer:
 
   model_fn-compatible: `renderer(key_0, key_1, params, rays_dict, warp_extra)`; rays are copied into
   static buffers, the graph is replayed and copies of the static outputs are returned.
-  One graph per (chunk size, parameter buffer, warp_alpha, metadata keys) is kept, so a frame whose last chunk is
+  One graph per (chunk size, parameter buffer, warp_alpha, time_alpha, metadata keys) is kept -- the two step scalars are
+  by-value kernel arguments baked into the captured launches -- so a frame whose last chunk is
   shorter replays two graphs instead of re-capturing twice per frame; render_image additionally edge-pads the tail to
   the full chunk when the renderer asks for it (`wants_fixed_chunks`), so that one graph serves the whole frame."""
   wants_fixed_chunks = True
@@ -51,8 +52,9 @@ class GraphedChunkRenderer:
   def __call__(self, key_0, key_1, params, rays, warp_extra):
     del key_0, key_1               # eval is deterministic (eval.py:239 forces use_stratified_sampling off)
     n = rays['origins'].shape[0]
-    alpha = float((warp_extra or {}).get('alpha', 0.0))
-    key = (n, params.flat.data_ptr(), alpha, tuple(sorted((rays.get('metadata') or {}).keys())))
+    # every scalar of lib.StepScalars is part of the key: a replay would otherwise render with the captured value
+    scalars = tuple(float((warp_extra or {}).get(k, 0.0)) for k in ('alpha', 'time_alpha'))
+    key = (n, params.flat.data_ptr(), scalars, tuple(sorted((rays.get('metadata') or {}).keys())))
     slot = self._slots.get(key)
     if slot is None:
       # every chunk size has its own workspace (descriptor tables included), so graphs of different sizes coexist
@@ -83,7 +85,8 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
   h, w = rays_dict['origins'].shape[:2]
   flat = _tree_map(lambda x: x.reshape(h * w, -1), rays_dict)
   num_rays = h * w
-  world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+  dist_on = dist.is_available() and dist.is_initialized()   # a one-rank communicator still runs the gather (RCCL on the GPU)
+  world = dist.get_world_size() if dist_on else 1
   rank = dist.get_rank() if world > 1 else 0
   del device_count
   ret_maps = []
@@ -104,7 +107,7 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
     out = model_fn(rng, rng + 1, state.optimizer.target, mine, state.warp_extra)
     ret_key = default_ret_key or ('fine' if 'fine' in out else 'coarse')
     ret = out[ret_key]
-    if world > 1:   # ONE all_gather per chunk: every output key packed side by side into a (per, sum of widths) buffer
+    if dist_on:   # ONE all_gather per chunk: every output key packed side by side into a (per, sum of widths) buffer
       keys = list(ret.keys())
       cols = [ret[k].reshape(per, -1).to(torch.float32) for k in keys]
       packed = torch.cat(cols, 1).contiguous()
@@ -124,9 +127,10 @@ def rays_from_camera(camera, metadata: Optional[Dict[str, int]] = None, device='
   ('warp', 'appearance', 'camera') broadcast to [H, W, 1] int32."""
   rays = camera.to_rays(device)
   h, w = rays['origins'].shape[:2]
-  if metadata:
-    rays['metadata'] = {k: torch.full((h, w, 1), int(v), dtype=torch.int32, device=rays['origins'].device)
-                       for k, v in metadata.items()}
+  if metadata:   # ids are int32 table rows; 'time' is the float stamp of the TimeEncoder (core.py:508-509, 602-603)
+    dev = rays['origins'].device
+    rays['metadata'] = {k: (torch.full((h, w, 1), float(v), dtype=torch.float32, device=dev) if k == 'time' else
+                            torch.full((h, w, 1), int(v), dtype=torch.int32, device=dev)) for k, v in metadata.items()}
   return rays
 
 

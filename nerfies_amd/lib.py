@@ -52,8 +52,15 @@ class Rays(C.Structure):
               ('time', C.c_void_p)]
 
 
+class DynamicScalars(C.Structure):
+  """nrf_dynamic_scalars: the per-step scalars in DEVICE memory (64 bytes) of a graph-replayed train step."""
+  _fields_ = [('warp_alpha', C.c_float), ('time_alpha', C.c_float), ('elastic_loss_weight', C.c_float), ('learning_rate', C.c_float),
+              ('adam_c1', C.c_float), ('adam_c2', C.c_float), ('grad_scale', C.c_float), ('reserved0', C.c_float),
+              ('rng_seed', C.c_uint64), ('rng_offset', C.c_uint64), ('reserved1', C.c_uint64 * 2)]
+
+
 class StepScalars(C.Structure):
-  _fields_ = [('warp_alpha', C.c_float), ('time_alpha', C.c_float)]
+  _fields_ = [('warp_alpha', C.c_float), ('time_alpha', C.c_float), ('dynamic', C.c_void_p)]
 
 
 class Rand(C.Structure):
@@ -73,7 +80,8 @@ class Outputs(C.Structure):
 
 class Background(C.Structure):
   _fields_ = [('num_points', C.c_int32), ('points', C.c_void_p), ('warp_ids', C.c_void_p), ('loss_weight', C.c_float),
-              ('loss_alpha', C.c_float), ('loss_scale', C.c_float)]
+              ('loss_alpha', C.c_float), ('loss_scale', C.c_float), ('id_choices', C.c_void_p), ('num_choices', C.c_int32),
+              ('noise_std', C.c_float)]
 
 
 class Elastic(C.Structure):
@@ -104,6 +112,7 @@ EXPORTS = [
     'nrf_debug_wgrad_segments', 'nrf_debug_ws_offset', 'nrf_train_step_loss_grad_ex', 'nrf_workspace_bytes_ex',
     'nrf_warp_points_workspace_bytes', 'nrf_warp_points',
     'nrf_camera_pixels_to_rays', 'nrf_camera_pixels_to_points', 'nrf_camera_project',
+    'nrf_dynamic_scalars_write', 'nrf_adam_step_dynamic',
 ]
 
 _lib = None
@@ -138,6 +147,8 @@ def load_library(path=None):
       'nrf_train_step_loss_grad': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand), vp, vp, vp,
                                    C.c_size_t, vp],
       'nrf_adam_step': [vp, vp, vp, vp, i64, f64, f64, f64, f64, i64, f64, vp],
+      'nrf_adam_step_dynamic': [vp, vp, vp, vp, i64, f64, f64, f64, vp, vp],
+      'nrf_dynamic_scalars_write': [vp, C.POINTER(DynamicScalars), vp],
       'nrf_sample_along_rays': [vp, vp, i32, i32, f32, f32, i32, i32, vp, u64, u64, vp, vp],
       'nrf_volumetric_rendering': [vp, vp, vp, i32, i32, i32, i32, C.POINTER(LevelOut), vp],
       'nrf_sample_pdf': [vp, vp, i32, i32, i32, i32, vp, u64, u64, vp, vp],

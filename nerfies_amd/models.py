@@ -34,6 +34,21 @@ def _ids(t, device):
   return t.to(torch.int32).contiguous()
 
 
+def _scalars(warp_extra, dynamic: Optional[torch.Tensor] = None) -> 'L.StepScalars':
+  """nrf_step_scalars of warp_extra; `dynamic`: the device buffer of a training.DynamicScalars (graph-replayable step)."""
+  we = warp_extra or {}
+  return L.StepScalars(float(we.get('alpha', 0.0)), float(we.get('time_alpha', 0.0)), None if dynamic is None else dynamic.data_ptr())
+
+
+def rng_seed_of(coarse_key: int, fine_key: int) -> int:
+  """The Philox seed NerfModel._rand_struct derives from integer 'coarse' / 'fine' keys (what a device-resident
+  nrf_dynamic_scalars.rng_seed must hold to reproduce the eager call)."""
+  seed = 0
+  for k in (coarse_key, fine_key):
+    seed = (seed * 0x9E3779B97F4A7C15 + int(k)) & 0xFFFFFFFFFFFFFFFF
+  return seed
+
+
 def _act_name(a):
   if isinstance(a, str):
     return a
@@ -287,8 +302,6 @@ class NerfModel:
         jac_levels.add('fine')
     if train and metadata_encoded:
       raise L.NrfError('metadata_encoded=True is an inference input (the reference never trains with it)')
-    if return_points and not warp_on:
-      raise L.NrfError('return_points is only built together with the warp field')
     device = torch.as_tensor(rays_dict['origins']).device
     if device.type != 'cuda':
       raise L.NrfError('rays must live on the GPU: the hot path has no CPU fallback')
@@ -312,18 +325,19 @@ class NerfModel:
           d['weights'] = torch.empty(B, s, device=device)
         if return_z_vals:   # extra (not in the reference dict): the sample depths of this level
           d['z_vals'] = torch.empty(B, s, device=device)
-        if return_points:   # models.py:250-251, 266-267
+        if return_points:   # models.py:247-248 (always), 266-267 (only behind the warp field)
           d['points'] = torch.empty(B, s, 3, device=device)
-          d['warped_points'] = torch.empty(B, s, 3, device=device)
+          if warp_on:
+            d['warped_points'] = torch.empty(B, s, 3, device=device)
         if name in jac_levels:   # models.py:264-265
           d['warp_jacobian'] = torch.empty(B, s, 3, 3, device=device)
       for k, t in d.items():
         setattr(lo, k, _ptr(t))
       ret[name] = d
-    scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
+    scal = _scalars(warp_extra)
     ws = self.workspace(B, train, device, jacobian=bool(jac_levels), bf16=bf16)
     if train:
-      self._train_ws = ws   # the stash `backward` differentiates (fp32 or bf16 layout)
+      self._train_ws = (B, ws)   # the stash `backward` differentiates (fp32 or bf16 layout), and the batch size it is for
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0) | \
         (L.NRF_FLAG_BF16 if bf16 else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jac_levels else 0)
@@ -340,9 +354,12 @@ class NerfModel:
     grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
     dc = None if d_rgb_coarse is None else _f32(d_rgb_coarse, device)
     df = None if d_rgb_fine is None else _f32(d_rgb_fine, device)
-    ws = getattr(self, '_train_ws', None)
-    if ws is None:
-      ws = self.workspace(rays.num_rays, True, device)
+    stash = getattr(self, '_train_ws', None)
+    if stash is None:
+      raise L.NrfError('backward() needs a preceding apply(..., train=True)')
+    if stash[0] != rays.num_rays:
+      raise L.NrfError(f'backward(): the stashed forward was run on {stash[0]} rays, not {rays.num_rays}')
+    ws = stash[1]   # the library also refuses a stash whose workspace plan was replaced by another call (NRF_E_STATE)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     L.check(self.lib.nrf_backward(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(dc), _ptr(df), _ptr(grad), _ptr(ws),
                                   ws.numel() * 4, stream), self.lib)
@@ -350,10 +367,14 @@ class NerfModel:
     return grad
 
   def loss_and_grad(self, fp: P.FlatParams, batch, warp_extra=None, rngs=None, grad_out=None, stats_out=None,
-                    background=None, elastic=None, warp_reg=None, bf16=False):
+                    background=None, elastic=None, warp_reg=None, bf16=False, dynamic=None):
     """forward + MSE_coarse + MSE_fine [+ background regulariser] + backward in one library call
     (training.py:168-265).  `background` = dict(points (N,3) already noised, warp_ids (N,), weight, alpha=-2,
     scale=1e-3) adds weight * mean(general_loss(|warp(x) - x|^2)) (training.py:117-135, 248-259).
+    Instead of 'warp_ids' the dict may carry `id_choices` (the model's warp ids) and `noise_std`: the library then draws the id
+    per point and adds the noise itself (training.py:121-126), `points` being the raw points.  `dynamic`: the device buffer
+    of a training.DynamicScalars -- warp_alpha / time_alpha / the rng key / the elastic weight are read from it on the device
+    (a captured launch sequence stays valid when they change).
     `elastic` = dict(weight, reduce_method='weight', eps=1e-6, alpha=-2, scale=0.03) adds the elastic regulariser
     on the coarse samples (training.py:71-114, 177-197); `loss_type` in lib.ELASTIC_TYPE.  `warp_reg` = dict(weight,
     alpha=-2, scale=1e-3): training.py:199-212 on both levels.  `bf16`: bfloat16 MLP operands (NRF_FLAG_BF16).
@@ -365,15 +386,21 @@ class NerfModel:
     target = _f32(batch['rgb'], device)[..., :3].contiguous()
     grad = grad_out if grad_out is not None else torch.empty_like(fp.flat)
     stats = stats_out if stats_out is not None else torch.empty(L.NRF_NUM_STATS, device=device)
-    scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
+    scal = _scalars(warp_extra, dynamic)
     bg, nbg, keep3 = None, 0, []
     if background is not None:
       pts = _f32(background['points'], device).reshape(-1, 3)
-      ids = _ids(background['warp_ids'], device).reshape(-1)
       nbg = pts.shape[0]
-      keep3 = [pts, ids]
-      bg = L.Background(nbg, _ptr(pts), _ptr(ids), float(background.get('weight', 1.0)), float(background.get('alpha', -2.0)),
-                        float(background.get('scale', 0.001)))
+      if background.get('warp_ids') is not None:   # the caller drew ids and noise (parity runs)
+        ids = _ids(background['warp_ids'], device).reshape(-1)
+        keep3 = [pts, ids]
+        bg = L.Background(nbg, _ptr(pts), _ptr(ids), float(background.get('weight', 1.0)), float(background.get('alpha', -2.0)),
+                          float(background.get('scale', 0.001)), None, 0, 0.0)
+      else:                                        # the library draws them (training.py:121-126)
+        choices = _ids(background['id_choices'], device).reshape(-1)
+        keep3 = [pts, choices]
+        bg = L.Background(nbg, _ptr(pts), None, float(background.get('weight', 1.0)), float(background.get('alpha', -2.0)),
+                          float(background.get('scale', 0.001)), _ptr(choices), choices.numel(), float(background.get('noise_std', 0.001)))
     el = None
     if elastic is not None:
       method = elastic.get('reduce_method', 'weight')
@@ -410,7 +437,7 @@ class NerfModel:
     L.check(self.lib.nrf_warp_points_workspace_bytes(self.handle, n, C.byref(nbytes)), self.lib)
     ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
     out = torch.empty(n, 3, device=device)
-    scal = L.StepScalars(float((warp_extra or {}).get('alpha', 0.0)), float((warp_extra or {}).get('time_alpha', 0.0)))
+    scal = _scalars(warp_extra)
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     L.check(self.lib.nrf_warp_points(self.handle, _ptr(fp.flat), _ptr(pts), _ptr(ids), n, C.byref(scal), _ptr(out), _ptr(ws),
                                      ws.numel() * 4, stream), self.lib)

@@ -407,15 +407,23 @@ def sample_pdf(bins, weights, origins, directions, z_vals, num_samples,
 # utils.py
 # ----------------------------------------------------------------------------
 def general_loss_with_squared_residual(squared_x, alpha, scale):
-  """utils.py:264-331, restricted to finite alpha not in {0, 2} (every call
-  site passes alpha=-2: training.py:112-113, :133-134)."""
-  assert alpha not in (0.0, 2.0) and math.isfinite(alpha)
+  """utils.py:264-331: every branch (alpha = -inf, 0, 2, +inf and the generic one; the presets' call sites pass
+  alpha=-2: training.py:112-113, :133-134; warp_reg_loss_alpha is a user-settable ScalarParam, training.py:38)."""
   eps = float(np.finfo(np.float32).eps)
   squared_scaled_x = squared_x / (scale ** 2)
-  beta_safe = max(eps, abs(alpha - 2.))
-  alpha_safe = (1.0 if alpha >= 0 else -1.0) * max(eps, abs(alpha))
-  loss = (beta_safe / alpha_safe) * (
-      torch.pow(squared_scaled_x / beta_safe + 1., 0.5 * alpha) - 1.)
+  if alpha == -math.inf:
+    loss = -torch.expm1(-0.5 * squared_scaled_x)                                   # utils.py:309
+  elif alpha == 0:
+    loss = torch.log1p(torch.clamp(0.5 * squared_scaled_x, max=3e37))              # :307, log1p_safe
+  elif alpha == 2:
+    loss = 0.5 * squared_scaled_x                                                  # :305
+  elif alpha == math.inf:
+    loss = torch.expm1(torch.clamp(0.5 * squared_scaled_x, max=87.5))              # :311, expm1_safe
+  else:
+    beta_safe = max(eps, abs(alpha - 2.))
+    alpha_safe = (1.0 if alpha >= 0 else -1.0) * max(eps, abs(alpha))
+    loss = (beta_safe / alpha_safe) * (
+        torch.pow(squared_scaled_x / beta_safe + 1., 0.5 * alpha) - 1.)
   return scale * loss
 
 

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
   config.addinivalue_line('markers', 'gpu: needs a real MI355X (run via gpurun)')
+  config.addinivalue_line('markers', 'slow: tens of seconds on the GPU (long convergence / full-shape oracle runs); deselect with -m "gpu and not slow"')
 
 
 def pytest_collection_modifyitems(config, items):

@@ -435,7 +435,25 @@ def elastic_types_and_noise():
   save('elastic_types_noise', **out)
 
 
+# ---------------------------------------------------------------------------------------------
+# round 3: every branch of utils.general_loss_with_squared_residual (utils.py:304-329)
+# ---------------------------------------------------------------------------------------------
+def general_loss_branches():
+  sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
+  out = dict(sq=sq)
+  for name, alpha in (('neginf', -np.inf), ('m2', -2.0), ('zero', 0.0), ('one', 1.0), ('two', 2.0), ('posinf', np.inf)):
+    for cname, scale in (('c03', 0.03), ('c1', 1.0)):
+      with np.errstate(over='ignore', invalid='ignore'):
+        out[f'{name}_{cname}'] = ref_utils.general_loss_with_squared_residual(sq, alpha=np.float64(alpha), scale=scale)
+  save('general_loss_branches', **out)
+
+
 if __name__ == '__main__':
+  if len(sys.argv) > 1:   # only the named generators (fixtures of earlier rounds stay byte-identical either way)
+    for name in sys.argv[1:]:
+      globals()[name]()
+    sys.exit(0)
+  general_loss_branches()
   rigid_body()
   model_utils()
   encoders_and_mlps()

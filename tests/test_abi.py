@@ -64,6 +64,60 @@ def test_struct_sizes_match_header():
   assert '#define NRF_FLAG_WARP_JACOBIAN %du' % L.NRF_FLAG_WARP_JACOBIAN in src
 
 
+def test_ctypes_mirrors_match_the_compiled_header(tmp_path):
+  """Every POD struct of include/nerfies_amd.h, compiled by the C compiler, against its ctypes mirror in nerfies_amd/lib.py:
+  same size, same offset for every field (a stale mirror -- INTEGRATION.md's stub of round 2 lacked four nrf_rays fields and
+  sized stats at 8 floats -- reads garbage pointers or overruns a buffer)."""
+  import shutil
+  import subprocess
+  from nerfies_amd import lib as L
+  cc = shutil.which('gcc') or shutil.which('cc')
+  if cc is None:
+    pytest.skip('no C compiler')
+  pairs = [('nrf_model_desc', L.ModelDesc), ('nrf_tensor_info', L.TensorInfo), ('nrf_rays', L.Rays), ('nrf_dynamic_scalars', L.DynamicScalars),
+           ('nrf_step_scalars', L.StepScalars), ('nrf_rand', L.Rand), ('nrf_level_out', L.LevelOut), ('nrf_outputs', L.Outputs),
+           ('nrf_background', L.Background), ('nrf_elastic', L.Elastic), ('nrf_warp_reg', L.WarpReg), ('nrf_camera', L.CameraDesc),
+           ('nrf_profile_entry', L.ProfileEntry)]
+  lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', 'int main(void) {']
+  for cname, ct in pairs:
+    lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+    for fname, _ in ct._fields_:
+      lines.append(f'  printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+  lines += ['  printf("NRF_NUM_STATS %d\\n", NRF_NUM_STATS);', '  printf("NRF_VERSION %d\\n", NRF_VERSION);', '  return 0;', '}']
+  src = tmp_path / 'abi.c'
+  src.write_text('\n'.join(lines))
+  exe = tmp_path / 'abi'
+  subprocess.run([cc, '-std=c99', '-Wall', '-Werror', str(src), '-o', str(exe)], check=True)
+  got = {}
+  for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines():
+    *k, v = line.split()
+    got[' '.join(k)] = int(v)
+  for cname, ct in pairs:
+    assert got[f'{cname} size'] == C.sizeof(ct), (cname, got[f'{cname} size'], C.sizeof(ct))
+    for fname, _ in ct._fields_:
+      assert got[f'{cname} {fname}'] == getattr(ct, fname).offset, (cname, fname)
+  assert got['NRF_NUM_STATS'] == L.NRF_NUM_STATS
+  assert C.sizeof(L.DynamicScalars) == 64
+
+
+def test_integration_stub_matches_the_binding():
+  """INTEGRATION.md's reference-side stub: its struct mirrors are executed and compared with nerfies_amd/lib.py field by
+  field, and the stats buffer it allocates has NRF_NUM_STATS floats."""
+  from nerfies_amd import lib as L
+  md = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+  block = re.search(r'```python\n# nerfies/hip_backend.py.*?```', md, flags=re.S).group(0)
+  code = block[len('```python\n'):-3]
+  code = code[:code.index("_lib = C.CDLL")]          # the struct mirrors and constants; loading the .so is lib.py's job
+  ns = {}
+  exec(code, ns)
+  assert ns['NRF_NUM_STATS'] == L.NRF_NUM_STATS and ns['NRF_FLAG_BF16'] == L.NRF_FLAG_BF16
+  for name, ct in (('ModelDesc', L.ModelDesc), ('TensorInfo', L.TensorInfo), ('Rays', L.Rays), ('StepScalars', L.StepScalars), ('Rand', L.Rand)):
+    mine = ns[name]
+    assert [(n, C.sizeof(t)) for n, t in mine._fields_] == [(n, C.sizeof(t)) for n, t in ct._fields_], name
+    assert C.sizeof(mine) == C.sizeof(ct)
+  assert 'jnp.empty(NRF_NUM_STATS)' in md and 'jnp.empty(8)' not in md
+
+
 def _desc(**kw):
   from nerfies_amd import lib as L
   d = L.ModelDesc(num_coarse_samples=64, num_fine_samples=128, use_viewdirs=1, near_plane=0.02, far_plane=0.8,

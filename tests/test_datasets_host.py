@@ -32,6 +32,25 @@ def test_scene_ids_metadata(scene):
     datasets.from_config({'type': 'dynamic_scene', 'data_dir': d}, image_scale=2)
 
 
+def test_use_time_gives_the_time_encoder_its_stamp(scene):
+  """core.py:269-274, 298-303, 602-603: metadata['time'] = time_id / max(time_ids) * 2 - 1, time_id falling back to warp_id
+  (nerfies.py:188-192); train.py:172 / eval.py:290 switch it on with warp_metadata_encoder_type == 'time'."""
+  d, ids = scene
+  ds = datasets.NerfiesDataSource(d, image_scale=2, use_warp_id=True, use_time=True)
+  assert ds.use_time and ds.has_metadata and ds.time_ids == (0, 1, 2, 3)
+  assert [ds.get_time(i) for i in ids[:4]] == [-1.0, -1.0 + 2 / 3, -1.0 + 4 / 3, 1.0]
+  md = ds.item_metadata(ids[1])
+  assert md['warp'] == 1 and md['time'] == pytest.approx(-1.0 + 2 / 3) and isinstance(md['time'], float)
+  assert datasets.NerfiesDataSource(d, image_scale=2, use_warp_id=True).time_ids == ()
+  import types
+  import train as train_driver
+  flags = types.SimpleNamespace(data_dir=d)
+  exp = types.SimpleNamespace(datasource_spec=None, datasource_type='nerfies', image_scale=2, random_seed=0, datasource_kwargs={})
+  for enc, want in (('time', True), ('glo', False)):
+    mc = types.SimpleNamespace(use_appearance_metadata=False, use_camera_metadata=False, use_warp=True, warp_metadata_encoder_type=enc)
+    assert train_driver.make_datasource(flags, exp, mc).use_time is want
+
+
 def test_camera_is_rescaled_and_normalised(scene):
   d, ids = scene
   raw = json.load(open(os.path.join(d, 'camera', ids[1] + '.json')))

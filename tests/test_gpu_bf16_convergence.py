@@ -1,0 +1,115 @@
+"""dPSNR gates of the bf16 training mode on the configurations it is FOR (SURVEY 8d "precision modes": the reference has no
+reduced-precision switch, so parity of the mode is a held-out-PSNR / loss-curve statement against the fp32 path):
+
+  * with the SE3 warp field ON (BASELINE configs[3], gpu_fullhd.gin, trains with the warp, warp_alpha annealing and the elastic
+    regulariser): 300 Adam steps of a small deforming scene, warp_alpha advancing every step; TWO-sided against the spread two
+    fp32 runs have among themselves (they differ only in their sampling keys);
+  * (slow) 2000 Adam steps at the BASELINE config-A shape itself, 1024 rays x (64+128), lr 1e-3 -> 1e-4 -- the record
+    profiles/r02_bf16_convergence.json, promoted to a test.
+Two training runs that differ only in rounding diverge chaotically, so every gate is relative to the fp32 runs' own spread."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _scene_rgb(o, d, shift=None):
+  """a smooth view-dependent target the network can fit; `shift` (N,3) deforms it per frame (what the warp field learns)"""
+  x = o if shift is None else o + shift
+  return torch.sigmoid(torch.stack([2.0 * torch.sin(3.0 * x[:, 0] + 2.0 * d[:, 1]), 2.0 * torch.cos(2.0 * x[:, 1] - 3.0 * d[:, 2]),
+                                    1.5 * torch.sin(4.0 * x[:, 2] + d[:, 0])], -1))
+
+
+def _psnr(a, b):
+  return float(-10.0 * np.log10(((a - b) ** 2).mean().item()))
+
+
+def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread():
+  from nerfies_amd import models, training
+  B, K, NB, NID = 256, 300, 32, 4
+
+  class Cfg:
+    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 32, 32, 6
+    sigma_activation, use_stratified_sampling, use_viewdirs = 'softplus', True, True
+    use_warp, warp_field_type, num_warp_freqs, num_warp_features = True, 'se3', 4, 8
+  g = torch.Generator().manual_seed(0)
+  n_train, n_test = NB * B, 2048
+  o = (torch.rand(n_train + n_test, 3, generator=g) - 0.5).to(DEV)
+  d = torch.nn.functional.normalize(torch.randn(n_train + n_test, 3, generator=g), dim=-1).to(DEV)
+  ids = torch.randint(0, NID, (n_train + n_test, 1), generator=g).to(DEV)
+  frame_shift = (0.04 * torch.randn(NID, 3, generator=g)).to(DEV)
+  rgb = _scene_rgb(o, d, frame_shift[ids[:, 0]])
+  ecfg = type('E', (Cfg,), {'use_stratified_sampling': False})
+  em, _ = models.construct_nerf(7, ecfg, n_test, [0], [0], list(range(NID)), 0.05, 1.0, device=DEV)
+  test = {'origins': o[n_train:], 'directions': d[n_train:], 'metadata': {'warp': ids[n_train:]}}
+  runs = {}
+  for mode, key0 in (('f32', 1), ('f32b', 1001), ('bf16', 1)):
+    model, fp = models.construct_nerf(7, Cfg, B, [0], [0], list(range(NID)), 0.05, 1.0, device=DEV)
+    state = training.TrainState(optimizer=training.Optimizer(fp))
+    sp = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=1e-3)
+    key, losses = key0, []
+    for k in range(K):
+      state = state.replace(warp_alpha=4.0 * min(1.0, k / (0.8 * K)))   # linear schedule 0 -> F_w (warp_defaults.gin)
+      i0 = (k % NB) * B
+      batch = {'origins': o[i0:i0 + B], 'directions': d[i0:i0 + B], 'rgb': rgb[i0:i0 + B], 'metadata': {'warp': ids[i0:i0 + B]}}
+      state, stats, key = training.train_step(model, key, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight',
+                                              bf16=(mode == 'bf16'))
+      losses.append(stats['fine']['loss/rgb'])
+    losses = torch.stack(losses).cpu().numpy()
+    assert np.isfinite(losses).all()
+    psnr = {tag: _psnr(em.apply({'params': fp}, test, {'alpha': 4.0}, **kw)['fine']['rgb'], rgb[n_train:])
+            for tag, kw in (('f32', {}), ('bf16', dict(bf16=True)))}   # the same weights rendered by both inference modes
+    runs[mode] = (psnr, losses)
+  (pa, la), (pb, lb), (p16, l16) = runs['f32'], runs['f32b'], runs['bf16']
+  lo, hi = min(pa['f32'], pb['f32']), max(pa['f32'], pb['f32'])
+  print(f'[bf16 training, warp on] held-out PSNR: fp32 runs {pa["f32"]:.3f} / {pb["f32"]:.3f} dB, bf16-trained {p16["f32"]:.3f} dB; bf16 '
+        f'rendering of the same weights {pa["bf16"] - pa["f32"]:+.3f} / {p16["bf16"] - p16["f32"]:+.3f} dB; mean loss of the last 100 '
+        f'steps {la[-100:].mean():.5f} / {lb[-100:].mean():.5f} / {l16[-100:].mean():.5f}')
+  assert lo > 18.0                                                   # the scene is learnt at all
+  assert lo - 0.1 - (hi - lo) <= p16['f32'] <= hi + 0.1 + (hi - lo)   # two-sided, relative to the fp32 spread
+  m32 = (la[-100:].mean(), lb[-100:].mean())
+  assert 0.95 * min(m32) - abs(m32[0] - m32[1]) <= l16[-100:].mean() <= 1.05 * max(m32) + abs(m32[0] - m32[1])
+  for psnr, _ in runs.values():                                      # inference-mode gate with the warp on
+    assert abs(psnr['bf16'] - psnr['f32']) <= 0.1
+
+
+@pytest.mark.slow
+def test_bf16_convergence_at_the_config_a_shape():
+  """profiles/r02_bf16_convergence.json as a test (measured there: fp32 38.452 / 38.409 dB, bf16 38.418 dB; loss-curve gap over
+  the second half 12.5 % bf16-vs-fp32 against 10.6 % fp32-vs-fp32)."""
+  from nerfies_amd import models, training
+  B, K, NB = 1024, 2000, 128
+
+  class Cfg:
+    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 64, 128, 8
+    sigma_activation, use_stratified_sampling, use_viewdirs = 'softplus', True, True
+  g = torch.Generator().manual_seed(0)
+  o = (torch.rand(NB * B + 8192, 3, generator=g) - 0.5).to(DEV)
+  d = torch.nn.functional.normalize(torch.randn(NB * B + 8192, 3, generator=g), dim=-1).to(DEV)
+  rgb = _scene_rgb(o, d)
+  em, _ = models.construct_nerf(7, type('E', (Cfg,), {'use_stratified_sampling': False}), 8192, [0], [0], [0], 0.05, 1.0, device=DEV)
+  test = {'origins': o[NB * B:], 'directions': d[NB * B:], 'metadata': {}}
+  res = {}
+  for mode, key0 in (('f32', 1), ('f32b', 1001), ('bf16', 1)):
+    model, fp = models.construct_nerf(7, Cfg, B, [0], [0], [0], 0.05, 1.0, device=DEV)
+    state = training.TrainState(optimizer=training.Optimizer(fp))
+    key, curve = key0, []
+    for k in range(K):
+      sp = training.ScalarParams(learning_rate=1e-3 * (0.1 ** (k / K)))
+      i0 = (k % NB) * B
+      batch = {'origins': o[i0:i0 + B], 'directions': d[i0:i0 + B], 'rgb': rgb[i0:i0 + B], 'metadata': {}}
+      state, stats, key = training.train_step(model, key, state, batch, sp, bf16=(mode == 'bf16'))
+      if (k + 1) % 20 == 0:
+        curve.append(stats['fine']['loss/rgb'])
+    res[mode] = (_psnr(em.apply({'params': fp}, test, {})['fine']['rgb'], rgb[NB * B:]), torch.stack(curve).cpu().numpy())
+  (pa, ca), (pb, cb), (p16, c16) = res['f32'], res['f32b'], res['bf16']
+  tail = slice(len(ca) // 2, None)
+  gap32 = np.abs(ca[tail] - cb[tail]).max() / ca[tail].mean()
+  gap16 = np.abs(c16[tail] - ca[tail]).max() / ca[tail].mean()
+  print(f'[bf16 convergence, config A shape, {K} steps] held-out PSNR fp32 {pa:.3f} / {pb:.3f} dB, bf16 {p16:.3f} dB ({p16 - pa:+.3f}); '
+        f'loss-curve gap over the second half: bf16 vs fp32 {100 * gap16:.1f} %, fp32 vs fp32 {100 * gap32:.1f} %')
+  assert min(pa, pb) > 30.0
+  assert min(pa, pb) - 0.1 <= p16 <= max(pa, pb) + 0.1 + abs(pa - pb)
+  assert gap16 <= 2.0 * gap32 + 0.05

@@ -88,13 +88,13 @@ CASES = [(37, {}), (401, {}), (50, dict(num_nerf_point_freqs=10, use_camera_meta
 WARP_ALPHA = 4.0
 
 
-@pytest.mark.parametrize('B,kw', CASES)
-def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
+def check_forward_and_stash(setup):
   """Step 1a: loss, rendered outputs and every stashed activation against the float64 oracle with the same roundings.
   float32 vs float64 accumulation moves a pre-activation by ~1e-7 relative, which flips the bfloat16 rounding of about
   one element in 3000 by one ulp (0.4 %), and later layers inherit those: per layer the relative L2 distance stays below
   5e-3, the largest deviation below 2 % of the layer's scale, at least 95 % of the elements within one ulp."""
-  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, **kw)
+  spec, p, b, t_rand, u, model, fp, rngs = setup
+  B = b['origins'].shape[0]
   gb = H.gpu_batch(b)
   grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=True)
   torch.cuda.synchronize()
@@ -105,19 +105,20 @@ def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
   acts = {}
 
   def record(name, layer, pre):
-    acts[(name, layer)] = H.bf16_round(torch.relu(pre.detach()))
+    acts[(name, layer)] = H.bf16_round(torch.relu(pre.detach())).float()   # exact in float32, half the host memory
     return torch.relu(pre)
-  with H.host_threads(64), O.dense_hook(bf16_dense_for(spec)), O.relu_hook(record):
-    loss, ostats, _, ret = O.loss_and_grad(p, spec, b, warp_alpha=WARP_ALPHA, t_rand=t_rand, u=u, fixed_fine_z=z_fine)
+  with H.host_threads(64), torch.no_grad(), O.dense_hook(bf16_dense_for(spec)), O.relu_hook(record):   # forward only: no graph
+    loss, ostats, ret = O.loss_fn(p, spec, b, warp_alpha=WARP_ALPHA, t_rand=t_rand, u=u, fixed_fine_z=z_fine)
   assert abs(stats[4].item() - loss.item()) < 5e-5, (stats[4].item(), loss.item())
   tw, rw = spec.nerf_trunk_width, spec.nerf_rgb_branch_width
   for lv, name in enumerate(('coarse', 'fine') if fine else ('coarse',)):
     rows = B * S[lv]
-    hs = H.bf16_stash(model, ws, 'b_h', lv, 8, 8, rows)
-    rg = H.bf16_stash(model, ws, 'b_rgbh', lv, 1, 4, rows)[0]
+    hs = H.bf16_stash(model, ws, 'b_h', lv, 8, 8, rows, as_float32=True)
+    rg = H.bf16_stash(model, ws, 'b_rgbh', lv, 1, 4, rows, as_float32=True)[0]
     def close(got, want, what):
       # one-ulp bf16 ties (float32 vs float64 accumulation, v_sin_f32 vs sin in the posenc) propagate: a unit near its kink
       # may differ by a multiple of its own value, never by more than a few bf16 ulps of the layer's scale
+      got, want = got.double(), want.double()
       err = (got - want).abs()
       assert err.max().item() <= 2e-2 * want.abs().max().item(), (what, err.max().item(), want.abs().max().item())
       assert (err.norm() / want.norm()).item() <= 5e-3, (what, (err.norm() / want.norm()).item())
@@ -133,7 +134,11 @@ def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
 
 
 @pytest.mark.parametrize('B,kw', CASES)
-def test_bf16_backward_matches_float64_given_the_stash(B, kw):
+def test_bf16_forward_and_stash_match_the_rounded_oracle(B, kw):
+  check_forward_and_stash(_setup(B, **kw))
+
+
+def check_backward_given_the_stash(setup):
   """Step 1b: the dgrad chain and the transposing wgrad kernel against a float64 evaluation of the SAME quantities from
   the kernels' own forward stash (bfloat16 activations X, bfloat16 d raw, bfloat16 weights, every dpre rounded to
   bfloat16 before use): all weight / bias gradient leaves to 5e-3 of the leaf's max-abs (measured 5e-5 .. 2e-3: a dpre within
@@ -141,7 +146,8 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
   the rounded oracle is not used for the gradients: the one-ulp rounding ties of step 1a, harmless in the rendered
   colour, are amplified by the cancellation inside d sigma = T (c_i - C_behind) to percents of the density gradient.)"""
   from nerfies_amd import params as P
-  spec, p, b, t_rand, u, model, fp, rngs = _setup(B, **kw)
+  spec, p, b, t_rand, u, model, fp, rngs = setup
+  B = b['origins'].shape[0]
   grad, stats = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=True)
   torch.cuda.synchronize()
   ws = model.workspace(B, True, DEV, bf16=True)
@@ -203,6 +209,12 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
       worst = max(worst, (f'{name}/d_points', err), key=lambda t: t[1])
       assert err < 5e-3, (name, 'd_points', err)
   print(f'[bf16 backward given the stash, B={B}] worst leaf {worst[0]}: {worst[1]:.2e}')
+  return grad
+
+
+@pytest.mark.parametrize('B,kw', CASES)
+def test_bf16_backward_matches_float64_given_the_stash(B, kw):
+  check_backward_given_the_stash(_setup(B, **kw))
 
 
 @pytest.mark.parametrize('kw,cos_floor', [({}, 0.99), (dict(use_warp=True, num_warp_freqs=6), 0.97)])

@@ -48,13 +48,21 @@ def _run(rank, world):
   gb = {k: (v[sl] if torch.is_tensor(v) else {kk: vv[sl] for kk, vv in v.items()}) for k, v in gb.items()}
   state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=4.0)
   sp = training.ScalarParams(learning_rate=LR, elastic_loss_weight=0.01)
+  # step 0, before Adam: the all-reduced mean of the shard gradients (lax.pmean, training.py:266) IS the full-batch gradient
+  import torch.distributed as dist
+  grad0, _ = model.loss_and_grad(fp, gb, warp_extra=state.warp_extra, rngs={'coarse': uni[0][0][sl].to(H.DEV), 'fine': uni[0][1][sl].to(H.DEV)},
+                                 elastic={'weight': 0.01, 'reduce_method': 'weight'})
+  grad0 = grad0.clone()
+  if world > 1:
+    dist.all_reduce(grad0)
+    grad0 /= world
   hist = []
   for k, (t_rand, u) in enumerate(uni):
     state, stats, _ = training.train_step(model, k, state, gb, sp, use_elastic_loss=True, elastic_reduce_method='weight',
                                           rngs={'coarse': t_rand[sl].to(H.DEV), 'fine': u[sl].to(H.DEV)})
     hist.append([stats['coarse']['loss/rgb'].item(), stats['fine']['loss/rgb'].item(), stats['coarse']['loss/elastic'].item()])
   torch.cuda.synchronize()
-  return fp.flat.cpu(), np.array(hist)
+  return fp.flat.cpu(), np.array(hist), grad0.cpu()
 
 
 def _worker(rank, port, tmp):
@@ -62,12 +70,12 @@ def _worker(rank, port, tmp):
   os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
   torch.cuda.set_device(0)
   dist.init_process_group('gloo', rank=rank, world_size=WORLD)
-  flat, hist = _run(rank, WORLD)
+  flat, hist, grad0 = _run(rank, WORLD)
   both = [torch.empty_like(flat) for _ in range(WORLD)]
   dist.all_gather(both, flat)
   assert torch.equal(both[0], both[1])   # replicas stay bit-identical: same all-reduced gradient, same Adam
   if rank == 0:
-    torch.save({'flat': flat, 'hist': hist}, tmp)
+    torch.save({'flat': flat, 'hist': hist, 'grad0': grad0}, tmp)
   dist.barrier()
   dist.destroy_process_group()
 
@@ -78,9 +86,20 @@ def test_two_rank_train_step_equals_full_batch(tmp_path):
   tmp = str(tmp_path / 'out.pt')
   mp.spawn(_worker, args=(_free_port(), tmp), nprocs=WORLD, join=True)
   got = torch.load(tmp, weights_only=False)
-  want, hist = _run(0, 1)
+  want, hist, grad_full = _run(0, 1)
   spec, p, _, _ = _inputs()
   model, fp0 = H.gpu_model(spec, p, B)
+  # the first-step gradient through the collective, leaf by leaf, against the full-batch gradient: only the float32
+  # summation order differs (tiles over other row sets, atomics)
+  worst = 0.0
+  for name, off, shape in model.layout.entries:
+    n = int(np.prod(shape))
+    a, b = got['grad0'][off:off + n], grad_full[off:off + n]
+    scale = b.abs().max().item()
+    if scale > 0:
+      worst = max(worst, (a - b).abs().max().item() / scale)
+  print(f'[2 ranks vs 1] step-0 all-reduced gradient: worst leaf {worst:.2e} of its max-abs entry')
+  assert worst < 1e-5
   init = fp0.flat.cpu()
   travel = (want - init).norm().item()
   diff = (got['flat'] - want).norm().item()

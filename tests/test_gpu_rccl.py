@@ -1,0 +1,87 @@
+"""RCCL on the one GPU a box has: a world-size-1 `nccl` process group loads librccl and pushes the step's fused
+[grad | stats] all-reduce (training.py:266-267), render_image's packed all_gather_into_tensor (eval.py:339) and bench.py's
+all-reduce timing through it, on the library's stream.  Results must equal the run without torch.distributed bit for bit
+(a one-rank sum / gather is the identity), so the first multi-GPU run only adds ranks to a path that has already executed.
+Runs in a child process: a process group cannot be re-initialised inside the pytest process."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r'''
+import json, os, sys
+sys.path.insert(0, os.environ['NRF_ROOT']); sys.path.insert(0, os.path.join(os.environ['NRF_ROOT'], 'tests'))
+import torch, torch.distributed as dist
+import helpers as H
+from oracle import nerfies_oracle as O
+from nerfies_amd import training, evaluation
+use_dist = sys.argv[1] == '1'
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+if use_dist:
+  os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = sys.argv[2]
+  dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+spec = O.ModelSpec(num_coarse_samples=32, num_fine_samples=32, num_nerf_point_freqs=6, use_stratified_sampling=True, use_warp=True,
+                   num_warp_freqs=4, use_camera_metadata=True)
+oparams = O.init_params(spec, seed=3, trained_like=True, dtype=torch.float32)
+B = 96
+batch = H.gpu_batch(O.synthetic_batch(B, seed=4, dtype=torch.float32))
+batch['background_points'] = (torch.rand(512, 3, generator=torch.Generator().manual_seed(1)) - 0.5).to(dev)
+model, fp = H.gpu_model(spec, oparams, B)
+state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=2.5)
+sp = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, background_loss_weight=1.0)
+key, losses = 7, []
+for _ in range(3):
+  state, stats, key = training.train_step(model, key, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight',
+                                          use_background_loss=True)
+  losses.append([float(stats['coarse']['loss/total']), float(stats['fine']['loss/total']), float(stats['background_loss'])])
+# render_image: 5 x 7 = 35 rays in chunks of 16 (ragged tail), through the packed gather
+rays = {k: v[:35].reshape(5, 7, -1) for k, v in batch.items() if k in ('origins', 'directions')}
+rays['metadata'] = {k: v[:35].reshape(5, 7, 1) for k, v in batch['metadata'].items()}
+fn = lambda k0, k1, params, r, extra: model.apply({'params': params}, r, extra)
+img = evaluation.render_image(state, rays, fn, chunk=16)
+out = {'params_sum': float(fp.flat.double().sum()), 'params_abs': float(fp.flat.double().abs().sum()),
+       'params_bits': int(fp.flat.view(torch.int32).to(torch.int64).sum().item()), 'losses': losses,
+       'rgb_bits': int(img['rgb'].contiguous().view(torch.int32).to(torch.int64).sum().item()), 'rgb_shape': list(img['rgb'].shape),
+       'rccl': None}
+if use_dist:
+  v = torch.cuda.nccl.version()
+  out['rccl'] = list(v) if isinstance(v, (tuple, list)) else v
+  out['backend'] = dist.get_backend()
+  dist.destroy_process_group()
+print('RESULT ' + json.dumps(out))
+'''
+
+
+def _run(use_dist, port):
+  env = dict(os.environ, NRF_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  r = subprocess.run([sys.executable, '-c', CHILD, '1' if use_dist else '0', str(port)], env=env, capture_output=True, text=True,
+                     timeout=600)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  line = [l for l in r.stdout.splitlines() if l.startswith('RESULT ')][-1]
+  return json.loads(line[7:])
+
+
+def test_train_step_and_render_through_a_one_rank_rccl_communicator():
+  plain = _run(False, 0)
+  rccl = _run(True, 29517)
+  assert rccl['backend'] == 'nccl' and rccl['rccl'], rccl
+  for k in ('params_bits', 'rgb_bits', 'losses', 'rgb_shape', 'params_sum'):
+    assert plain[k] == rccl[k], (k, plain[k], rccl[k])   # bit-identical: a one-rank all-reduce / gather is the identity
+
+
+def test_bench_line_through_rccl(tmp_path):
+  """bench.py BENCH_FORCE_DIST=1: the headline step, the burn-in agreement and the grad_allreduce_us measurement on a one-rank
+  RCCL communicator; the line reports the RCCL version."""
+  env = dict(os.environ, BENCH_FORCE_DIST='1', MASTER_PORT='29519', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--burn-in-s', '0',
+                      '--no-cpu-baseline', '--rays-per-gpu', '128'], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+  assert d['dist_backend'] == 'nccl' and d['rccl_ranks'] == 1 and d['rccl_version'] and d['grad_allreduce_us'] > 0
+  assert d['config']['rays_per_gpu'] == 128 and d['value'] > 0

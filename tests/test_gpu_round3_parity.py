@@ -1,0 +1,248 @@
+"""Round-3 parity extensions at the configurations the reference actually trains / renders:
+
+  * BASELINE configs[3] (gpu_fullhd.gin: 512 rays/GPU x (256+256), F_p = 10, SE3 warp F_w = 8, appearance + warp ids) in the
+    bf16 precision BASELINE names for it, at its FULL per-GPU shape: forward / stash against the rounded float64 oracle, the
+    backward given the stash, and the float32 warp-field leaves against the pinned float64 VJP fed with the kernels' own
+    bfloat16-path d_points;
+  * a 20-step Adam trajectory with the warp, the elastic and the background regularisers on and warp_alpha advancing every step
+    (the configs that take 250 k - 1 M steps in the reference all train like that) against the float64 oracle;
+  * BASELINE configs[4] (eval / video: 8192-ray chunk x (128+128), deterministic) through GraphedChunkRenderer against the
+    float64 oracle (fp32 <= 1e-4) and its bf16 mode by dPSNR (<= 0.1 dB)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+from oracle import nerfies_oracle as O  # noqa: E402
+import helpers as H  # noqa: E402
+import test_gpu_bf16_train as T  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+# ---------------------------------------------------------------------------------------------
+# config D, bf16, full per-GPU shape
+# ---------------------------------------------------------------------------------------------
+def check_warp_leaves_given_d_points(setup, grad):
+  """The SE3 field stays float32 in the bf16 mode: its leaves get their gradient only through d loss / d warped point, which
+  the bf16 dgrad chain emits in float32 (`d_points`).  Float64 VJP of the warp field (hidden ReLUs pinned to the HIP path's own
+  sign bits, tests/test_gpu_pinned.py) with exactly those d_points as the upstream gradient: every warp leaf within
+  helpers.grad_tol (4e-3 at F_p = 10) of its max-abs entry."""
+  from nerfies_amd import params as P
+  spec, p, b, t_rand, u, model, fp, rngs = setup
+  B = b['origins'].shape[0]
+  ws = model.workspace(B, True, DEV, bf16=True)
+  torch.cuda.synchronize()
+  S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
+  leaves = [(path, t.float().double().requires_grad_(True)) for path, t in O.tree_leaves_with_path(p['warp_field'])]
+  it = iter([t for _, t in leaves])
+  pw = O.tree_map(lambda _: next(it), p['warp_field'])
+  o32, d32 = b['origins'].float(), b['directions'].float()
+  total, hooks = 0.0, []
+  for lv, name in enumerate(('coarse', 'fine')):
+    rows, nt = B * S[lv], (B * S[lv] + 63) // 64
+    z = torch.from_numpy(H._ws_words(model, ws, 'z', lv, rows).view('float32').reshape(B, S[lv]).copy())
+    pts = (o32[:, None, :] + z[..., None] * d32[:, None, :]).double()          # fadd(o, fmul(z, d)) as the kernel forms it
+    dp = torch.from_numpy(H._ws_words(model, ws, 'd_points', lv, nt * 64 * 3).view('float32').reshape(nt * 64, 3)[:rows].copy())
+    m = H._decode_bits(H._ws_words(model, ws, 'w_bits', lv, nt * 4 * 64 * 6), 6, nt, 1, rows)
+    hook = H.PinnedRelu({f'{name}/warp': [m[l] for l in range(6)]})
+    wmeta = b['metadata']['warp'][:, None, :].expand(B, S[lv], 1)
+    with O.relu_hook(hook):
+      out = O.se3_field(pw, pts, wmeta, T.WARP_ALPHA, spec.num_warp_freqs, name=f'{name}/warp')
+    total = total + (out['warped_points'] * dp.double().reshape(B, S[lv], 3)).sum()
+    hooks.append(hook)
+  grads = torch.autograd.grad(total, [t for _, t in leaves])
+  got = P.tree_from_flat(grad.cpu(), model.layout)['warp_field']
+  tol, worst = H.grad_tol(spec), ('', 0.0)
+  for (path, _), g in zip(leaves, grads):
+    scale = g.abs().max().item()
+    assert scale > 0, path
+    err = (H.leaf(got, path).double() - g).abs().max().item() / scale
+    worst = max(worst, (path, err), key=lambda t: t[1])
+    assert err < tol, (path, err, scale)
+  flips, tot = sum(h.flips for h in hooks), sum(h.total for h in hooks)
+  print(f'[warp leaves given the bf16 d_points, B={B}] worst leaf warp_field/{worst[0]}: {worst[1]:.2e} (tol {tol:.0e}); ReLU ties {flips}/{tot}')
+  assert flips <= H.FLIP_FRACTION * tot
+
+
+def test_config_d_full_shard_in_bf16():
+  """configs[3] per-GPU shard in the bf16 mode: 512 rays x (256+256), F_p = 10, SE3 warp F_w = 8 G = 8, appearance + warp ids
+  (/root/reference/configs/gpu_fullhd.gin:24-40 + warp_defaults.gin)."""
+  kw = dict(num_coarse_samples=256, num_fine_samples=256, num_nerf_point_freqs=10, use_warp=True, num_warp_freqs=8,
+            num_warp_features=8, use_appearance_metadata=True)
+  with H.host_threads(64):
+    setup = T._setup(512, seed=13, **kw)
+    T.check_forward_and_stash(setup)
+    grad = T.check_backward_given_the_stash(setup)
+    check_warp_leaves_given_d_points(setup, grad)
+
+
+def test_warp_leaves_given_d_points_small():
+  """The same warp-leaf check at a size that runs in seconds (and with the camera code in the rgb condition)."""
+  setup = T._setup(45, use_warp=True, num_warp_freqs=6, use_camera_metadata=True, num_coarse_samples=48, num_fine_samples=48)
+  spec, p, b, t_rand, u, model, fp, rngs = setup
+  grad, _ = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': T.WARP_ALPHA}, rngs=rngs, bf16=True)
+  check_warp_leaves_given_d_points(setup, grad)
+
+
+# ---------------------------------------------------------------------------------------------
+# trajectory with the warp + elastic + background terms, warp_alpha advancing
+# ---------------------------------------------------------------------------------------------
+def _oracle_trajectory(spec, p0, batch, steps, lr, dtype, el_w, bg_w):
+  cast = lambda t: t.to(dtype) if torch.is_tensor(t) and t.is_floating_point() else t
+  b = {k: (O.tree_map(cast, v) if isinstance(v, dict) else cast(v)) for k, v in batch.items()}
+  leaves = [(path, t.to(dtype).clone()) for path, t in O.tree_leaves_with_path(p0)]
+  m = [torch.zeros_like(t) for _, t in leaves]
+  v = [torch.zeros_like(t) for _, t in leaves]
+  losses = []
+  for k, st in enumerate(steps):
+    it = iter([t for _, t in leaves])
+    cur = O.tree_map(lambda _: next(it), p0)
+    loss, _, grads, _ = O.loss_and_grad(cur, spec, b, warp_alpha=st['alpha'], t_rand=st['t_rand'].to(dtype), u=st['u'].to(dtype),
+                                        use_elastic_loss=True, elastic_loss_weight=el_w, elastic_reduce_method='weight',
+                                        use_background_loss=True, background_loss_weight=bg_w,
+                                        background={'points': st['bg_points'].to(dtype), 'warp_ids': st['bg_ids'], 'noise': st['bg_noise'].to(dtype)})
+    losses.append(loss.item())
+    for j, (_, gt) in enumerate(O.tree_leaves_with_path(grads)):
+      pnew, m[j], v[j] = O.adam_update(leaves[j][1], m[j], v[j], gt, k, lr)
+      leaves[j] = (leaves[j][0], pnew)
+  return np.array(losses), dict(leaves)
+
+
+def test_training_trajectory_with_warp_elastic_and_background():
+  """20 Adam steps (training.py:138-271) with everything gpu_vrig_paper / gpu_fullhd train with: SE3 warp, warp_alpha annealing
+  (linear, one schedule step per Adam step), elastic loss ('weight') on the coarse samples, background loss on freshly drawn
+  points -- against the float64 oracle from the same init with the same uniforms, ids and noise.  Criteria as
+  tests/test_gpu_pinned.py::test_training_trajectory_matches_oracle (what a float32 path can have): loss curve within 3e-5,
+  every leaf within 2e-3 relative L2 of the float64 run and no further from it than 4x the float32 oracle's own distance."""
+  from nerfies_amd import params as P, training
+  B, K, lr, NBG, el_w, bg_w = 24, 20, 1e-4, 64, 0.01, 1.0
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=6, use_stratified_sampling=True, use_warp=True,
+                     num_warp_freqs=4, num_warp_features=8, use_camera_metadata=True)
+  p64 = O.init_params(spec, seed=41, trained_like=True, dtype=torch.float64)
+  b64 = O.synthetic_batch(B, seed=42, dtype=torch.float64)
+  g = torch.Generator().manual_seed(43)
+  steps = []
+  for k in range(K):
+    steps.append({'alpha': 4.0 * k / (K - 1), 't_rand': torch.rand(B, spec.num_coarse_samples, generator=g).double(),
+                  'u': torch.rand(B, spec.num_fine_samples, generator=g).double(),
+                  'bg_points': (torch.rand(NBG, 3, generator=g).double() - 0.5) * 0.8, 'bg_ids': torch.randint(0, 4, (NBG, 1), generator=g),
+                  'bg_noise': 1e-3 * torch.randn(NBG, 3, generator=g).double()})
+  model, fp = H.gpu_model(spec, p64, B)
+  gb = H.gpu_batch(b64)
+  opt = training.Optimizer(fp)
+  gpu_loss = []
+  for k, st in enumerate(steps):   # training.train_step with the background ids / noise supplied instead of drawn
+    grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': st['alpha']},
+                                      rngs={'coarse': st['t_rand'].float().to(DEV), 'fine': st['u'].float().to(DEV)},
+                                      grad_out=opt.grad, stats_out=opt.stats, elastic={'weight': el_w, 'reduce_method': 'weight'},
+                                      background={'points': (st['bg_points'] + st['bg_noise']).float().to(DEV), 'warp_ids': st['bg_ids'].to(DEV),
+                                                  'weight': bg_w})
+    gpu_loss.append(stats[4].item())
+    opt.apply_gradient(grad, learning_rate=lr)
+  with H.host_threads(32):
+    l64, w64 = _oracle_trajectory(spec, p64, b64, steps, lr, torch.float64, el_w, bg_w)
+    l32, w32 = _oracle_trajectory(spec, p64, b64, steps, lr, torch.float32, el_w, bg_w)
+  dev_gpu, dev_f32 = np.abs(np.array(gpu_loss) - l64).max(), np.abs(l32 - l64).max()
+  got = P.tree_from_flat(fp.flat.cpu(), model.layout)
+  worst = (0.0, 0.0, '')
+  rows = []
+  for path, want in w64.items():
+    have = H.leaf(got, path).double()
+    nrm = max(want.norm().item(), 1e-30)
+    l2_gpu, l2_f32 = (have - want).norm().item() / nrm, (w32[path].double() - want).norm().item() / nrm
+    rows.append((path, l2_gpu, l2_f32))
+    worst = max(worst, (l2_gpu, l2_f32, path))
+  print(f'[trajectory warp+elastic+bg] {K} steps, alpha 0 -> 4: loss max dev gpu {dev_gpu:.1e} (float32 oracle {dev_f32:.1e}); worst leaf '
+        f'{worst[2]} rel-L2 gpu {worst[0]:.1e} (float32 oracle {worst[1]:.1e})')
+  assert dev_gpu < 3e-5 + 3 * dev_f32
+  assert l64[-1] < l64[0]
+  for path, l2_gpu, l2_f32 in rows:
+    assert l2_gpu < 2e-3, (path, l2_gpu)
+    assert l2_gpu < 4 * l2_f32 + 2e-5, (path, l2_gpu, l2_f32)
+
+
+# ---------------------------------------------------------------------------------------------
+# config E: the eval / video chunk
+# ---------------------------------------------------------------------------------------------
+def test_config_e_chunk_through_the_graphed_renderer():
+  """8192 rays x (128+128), deterministic sampling (eval.py:239), one hipGraph replay per chunk.  The float64 oracle renders a
+  strided subset of the chunk's rays (rays are independent units: every 8th ray of the GPU's full-chunk result must equal the
+  oracle's render of that ray), fp32 <= 1e-4 on rgb / depth / acc; the bf16 mode by dPSNR against a noisy target <= 0.1 dB."""
+  from nerfies_amd import evaluation
+  n, stride = 8192, 8
+  spec = O.ModelSpec(num_coarse_samples=128, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=False)
+  p64 = O.init_params(spec, seed=51, trained_like=True, dtype=torch.float64)
+  b64 = O.synthetic_batch(n, seed=52, dtype=torch.float64)
+  model, fp = H.gpu_model(spec, p64, n)
+  gb = H.gpu_batch(b64)
+  rays = {'origins': gb['origins'], 'directions': gb['directions']}
+  fn32, fn16 = evaluation.GraphedChunkRenderer(model), evaluation.GraphedChunkRenderer(model, bf16=True)
+  out = fn32(0, 1, fp, rays, {})
+  again = fn32(0, 1, fp, rays, {})                        # second call = graph REPLAY
+  assert fn32.captures == 1 and torch.equal(out['fine']['rgb'], again['fine']['rgb'])
+  sub = {k: (v[::stride] if torch.is_tensor(v) else {kk: vv[::stride] for kk, vv in v.items()}) for k, v in b64.items()}
+  with H.host_threads(64), torch.no_grad():
+    ref = O.nerf_model_apply(p64, spec, sub)
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc'):
+      err = (again[lv][k][::stride].cpu().double() - ref[lv][k]).abs().max().item()
+      assert err < 1e-4, (lv, k, err)
+  lo = fn16(0, 1, fp, rays, {})
+  g = torch.Generator().manual_seed(3)
+  target = (again['fine']['rgb'].cpu() + 0.05 * torch.randn(n, 3, generator=g)).clamp(0, 1)
+  ps = lambda x: -10.0 * np.log10(((x.cpu() - target) ** 2).mean().item())
+  d = ps(lo['fine']['rgb']) - ps(again['fine']['rgb'])
+  print(f'[config E chunk] fp32 vs float64 oracle on every {stride}th ray <= 1e-4; bf16 rendering: dPSNR {d:+.4f} dB '
+        f'(max |d rgb| {(lo["fine"]["rgb"] - again["fine"]["rgb"]).abs().max().item():.1e})')
+  assert abs(d) <= 0.1
+
+
+# ---------------------------------------------------------------------------------------------
+# contract leftovers of round 2
+# ---------------------------------------------------------------------------------------------
+def test_return_points_without_the_warp_field():
+  """models.py:247-248: `points` is in the output dict whenever return_points is set -- with use_warp False (a warp-less model,
+  or use_warp=False at the call) there is no 'warped_points' key, but the sample points are still returned."""
+  for kw, call_kw in ((dict(), {}), (dict(use_warp=True, num_warp_freqs=4), dict(use_warp=False))):
+    spec = O.ModelSpec(num_coarse_samples=12, num_fine_samples=9, num_nerf_point_freqs=4, use_stratified_sampling=True, **kw)
+    p = O.init_params(spec, seed=2, trained_like=True, dtype=torch.float64)
+    b = O.synthetic_batch(33, seed=3, dtype=torch.float64)
+    g = torch.Generator().manual_seed(4)
+    t_rand, u = torch.rand(33, 12, generator=g).double(), torch.rand(33, 9, generator=g).double()
+    model, fp = H.gpu_model(spec, p, 33)
+    out = model.apply({'params': fp}, H.gpu_batch(b), {'alpha': 2.0}, return_points=True,
+                      rngs={'coarse': t_rand.float().to(DEV), 'fine': u.float().to(DEV)}, **call_kw)
+    ref = O.nerf_model_apply(p, spec, b, 2.0, use_warp=call_kw.get('use_warp', True), return_points=True, t_rand=t_rand, u=u)
+    for lv in ('coarse', 'fine'):
+      assert 'warped_points' not in out[lv] and 'warped_points' not in ref[lv]
+      assert out[lv]['points'].shape == ref[lv]['points'].shape
+      np.testing.assert_allclose(out[lv]['points'].cpu().numpy(), ref[lv]['points'].numpy(), atol=2e-6)
+
+
+def test_graphed_renderer_keys_on_time_alpha():
+  """GraphedChunkRenderer: warp_extra['time_alpha'] is a by-value kernel argument of the captured TimeEncoder launch; a replay
+  after the schedule moved it must re-capture (the key held `alpha` only and replayed the stale window)."""
+  from nerfies_amd import evaluation
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                     num_warp_freqs=4, warp_metadata_encoder_type='time')
+  p = O.init_params(spec, seed=5, trained_like=True, dtype=torch.float64)
+  b = O.synthetic_batch(40, seed=6, dtype=torch.float64)
+  model, fp = H.gpu_model(spec, p, 40)
+  gb = H.gpu_batch(b)
+  rays = {'origins': gb['origins'], 'directions': gb['directions'], 'metadata': {'time': gb['metadata']['time']}}
+  fn = evaluation.GraphedChunkRenderer(model)
+  a = fn(0, 1, fp, rays, {'alpha': 2.0, 'time_alpha': 0.25})
+  c = fn(0, 1, fp, rays, {'alpha': 2.0, 'time_alpha': 1.0})
+  assert fn.captures == 2
+  direct = model.apply({'params': fp}, rays, {'alpha': 2.0, 'time_alpha': 1.0})
+  np.testing.assert_allclose(c['fine']['rgb'].cpu().numpy(), direct['fine']['rgb'].cpu().numpy(), atol=1e-6)
+  assert (a['fine']['rgb'] - c['fine']['rgb']).abs().max().item() > 1e-5   # the window does change the render
+  again = fn(0, 1, fp, rays, {'alpha': 2.0, 'time_alpha': 0.25})              # ... and the first graph is still there
+  assert fn.captures == 2 and torch.equal(again['fine']['rgb'], a['fine']['rgb'])

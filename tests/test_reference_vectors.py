@@ -148,6 +148,18 @@ def test_losses_psnr_elastic():
   close(el, r['el_loss'], 1e-10); close(res, r['el_residual'], 1e-10)
 
 
+def test_general_loss_every_branch():
+  """utils.general_loss_with_squared_residual (utils.py:304-329): alpha = -inf, 0, 2, +inf and generic alphas, against the
+  reference's own function (tests/golden/make_reference_vectors.py general_loss_branches)."""
+  import math
+  r = ref('general_loss_branches')
+  sq = T(r['sq'])
+  for name, alpha in (('neginf', -math.inf), ('m2', -2.0), ('zero', 0.0), ('one', 1.0), ('two', 2.0), ('posinf', math.inf)):
+    for cname, scale in (('c03', 0.03), ('c1', 1.0)):
+      got = O.general_loss_with_squared_residual(sq, alpha, scale).numpy()
+      np.testing.assert_allclose(got, r[f'{name}_{cname}'], rtol=1e-12, atol=1e-300)
+
+
 def test_background_loss():
   """training.compute_background_loss (training.py:117-135): the reference run on the oracle's warp parameters with the
   ids and the noise it draws supplied to it."""

@@ -47,6 +47,7 @@ def make_datasource(flags, exp_config, model_config):
   return datasets.from_config(
       spec, image_scale=exp_config.image_scale, use_appearance_id=model_config.use_appearance_metadata,
       use_camera_id=model_config.use_camera_metadata, use_warp_id=model_config.use_warp,
+      use_time=model_config.warp_metadata_encoder_type == 'time',   # train.py:172, eval.py:290
       random_seed=exp_config.random_seed, **exp_config.datasource_kwargs)
 
 

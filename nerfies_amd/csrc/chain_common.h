@@ -128,8 +128,7 @@ __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* 
   float2 a0[4], a1[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) a0[s] = *reinterpret_cast<const float2*>(ap + off[s]);
-#pragma unroll 2
-  for (int q = 0; q < nquads; ++q) {
+  auto quad = [&]() {
     WQuad<NCB> bn;   // weights run up to one quad past the end of the layer (the pack buffer is padded)
 #pragma unroll
     for (int t = 0; t < NB; ++t) bn.b[t] = bp[(NB + t) * 64];
@@ -152,7 +151,16 @@ __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* 
     bc = bn;
     ap += QUAD_FLOATS;
     bp += NB * 64;
-  }
+  };
+  // The first quad is peeled out of the loop.  Inside the loop hipcc waits for the weights of the CURRENT quad with a
+  // count that assumes only the loop's own loads are in flight (vmcnt(7)); entering a layer, the 16 stash stores of the
+  // previous layer's epilogue are still unacknowledged, and that generic wait -- redundant in the first trip, whose weights
+  // were prefetched ahead of the stores -- drained them: every layer of the training kernels exposed the store
+  // acknowledgement latency.  Peeled, the first quad (32 / 16 MFMAs) runs behind an exact count and the stores retire
+  // under it.
+  if (nquads > 0) quad();
+#pragma unroll 2
+  for (int q = 1; q < nquads; ++q) quad();
 }
 
 // Tile hand-out.  counter == nullptr (default): static round-robin split.  Otherwise workgroups pull 64-row
@@ -195,6 +203,28 @@ __device__ __forceinline__ void bias_acc(f32x16 (&acc)[2][NCB], const float* __r
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = bv;
   }
+}
+
+// The same in two steps: the bias of the NEXT layer is fetched before this layer's epilogue issues its stash stores.  A
+// load issued behind the stores can only be waited for together with them (vmcnt counts both, in order): with the bias load
+// at the top of the next layer every layer of the TRAINING forward exposed the acknowledgement latency of its 16 stash
+// stores, which the stash-less inference forward never saw (137 vs 123 TF for the same kernel in round 2).
+template <int NCB> struct BiasRegs { float b[NCB]; };
+template <int NCB>
+__device__ __forceinline__ BiasRegs<NCB> bias_load(const float* __restrict__ bias, int ncol0, int lane) {
+  BiasRegs<NCB> r;
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) r.b[cb] = bias[ncol0 + 32 * cb + (lane & 31)];
+  return r;
+}
+template <int NCB>
+__device__ __forceinline__ void bias_set(f32x16 (&acc)[2][NCB], const BiasRegs<NCB>& r) {
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[rb][cb][q] = r.b[cb];
 }
 
 template <int NCB>

@@ -39,8 +39,13 @@ __device__ __forceinline__ float sigma_activation(float x, int kind) {
   return relu(x);
 }
 
+// The arguments are read through a run-time index into the kernarg segment (always 0: gridDim.x < 2^24): hipcc then fetches
+// each field with a scalar load where it is used instead of keeping the whole 700-byte struct in SGPRs for the lifetime of the
+// kernel (round 2: 116 spilled SGPRs, parked in VGPR lanes of a kernel that is out of VGPRs).
+struct ChainFwdArgs1 { ChainFwdArgs a[1]; };
 template <bool STASH>
-__global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs A) {
+__global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs1 P) {
+  const ChainFwdArgs& A = P.a[blockIdx.x >> 24];
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* act = smem;                 // [256][64] swizzled
   float* pe = smem + ACT_FLOATS;     // [PK][64]; reused as scratch after the skip layer
@@ -54,14 +59,19 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
   const int PK = A.PK;
   const int PKS = (PK + 31) / 32 * 32;   // features per posenc stash tile (whole 32-feature blocks)
   const int nq_pe = PK / 16;
+  // in-kernel timeline (scripts/exp_timeline.py): compiled in only with -DNRF_TIMELINE_BUILD -- its counters and clock values
+  // are live across the whole kernel, in a kernel that is out of registers
+#ifdef NRF_TIMELINE_BUILD
   int stamp_i = 0;
   auto STAMP = [&]() {
     if (A.timeline && blockIdx.x == 0 && lane == 0 && stamp_i < 64) A.timeline[wave * 64 + stamp_i] = clock64();
     ++stamp_i;
   };
-
   unsigned long long wg_t0 = 0, wg_w0 = 0;
   if (A.timeline && tid == 0) { wg_t0 = clock64(); wg_w0 = wall_clock64(); }
+#else
+  auto STAMP = [&]() {};
+#endif
   int* tslot = reinterpret_cast<int*>(pe);   // free between tiles
   const TileIter ti = tile_iter(A.ntiles, A.k_old);
   for (int tile = A.tile_counter ? next_tile(A.tile_counter, tslot) : ti.first; tile < (A.tile_counter ? A.ntiles : ti.end);
@@ -115,9 +125,10 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     // ---- trunk: 8 x Dense(256)+ReLU, skip concat [h, posenc] at layer 4 (modules.py:41-50) ----
     const float4* wL0 = wpk4 + (A.pk.fwd_L[0] / 4) + wave * (PK / 4) * 64;
     WQuad<2> wnext = prefetch_quad<2>(wL0, lane);
+    BiasRegs<2> bnext = bias_load<2>(prm + A.po.trunk_b[0], wave * 64, lane);
 #pragma unroll 1
     for (int l = 0; l < TRUNK_DEPTH; ++l) {
-      bias_acc<2>(acc, prm + A.po.trunk_b[l], wave * 64, lane);
+      bias_set<2>(acc, bnext);
       if (l == 0) {
         mfma_k_loop<2, false>(acc, pe, nq_pe, wL0, lane, wnext);
       } else {
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
       }
       // the next layer's first weights go out before this layer's stash stores
       wnext = prefetch_quad<2>(wpk4 + ((l + 1 < TRUNK_DEPTH ? A.pk.fwd_L[l + 1] : A.pk.fwd_bn) / 4) + wave * 64 * 64, lane);
+      bnext = bias_load<2>(prm + (l + 1 < TRUNK_DEPTH ? A.po.trunk_b[l + 1] : A.po.bn_b), wave * 64, lane);   // ... and its bias (chain_common.h)
       __builtin_amdgcn_sched_barrier(0);
       STAMP();   // k loop of layer l issued
       fwd_epilogue<2, EPI_RELU, STASH>(
@@ -170,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
 
     STAMP();   // alpha head done
     // ---- bottleneck: Dense(256), no activation (modules.py:149-150) ----
-    bias_acc<2>(acc, prm + A.po.bn_b, wave * 64, lane);
+    bias_set<2>(acc, bnext);
     mfma_k_loop<2, true>(acc, act, 16, wpk4 + (A.pk.fwd_bn / 4) + wave * 64 * 64, lane, wnext);
     const float4* wrgb = wpk4 + (A.pk.fwd_rgbh / 4) + wave * 32 * 64;
     const WQuad<1> wrgb0 = prefetch_quad<1>(wrgb, lane);
@@ -265,6 +277,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
       __syncthreads();   // scratch (aliases pe) is free again for the next tile's prologue
     }
   }
+#ifdef NRF_TIMELINE_BUILD
   if (A.timeline && tid == 0) {   // per-workgroup residency record: start, end (shader clock), HW_ID, XCC_ID
     unsigned long long* rec = A.timeline + 1024 + 4 * (size_t)blockIdx.x;
     rec[0] = wg_t0; rec[1] = clock64();
@@ -272,10 +285,13 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     rec[3] = (__builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11)) & 0xf)   // HW_REG_XCC_ID
              | ((wall_clock64() - wg_w0) << 8);                               // residency in 100 MHz ticks
   }
+#endif
 }
 
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream) {
   const size_t lds = (size_t)(ACT_FLOATS + a.PK * TILE_ROWS) * sizeof(float);
+  ChainFwdArgs1 p;
+  p.a[0] = a;
   if (getenv("NRF_DEBUG_OCC")) {
     int nb = -1;
     (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -287,10 +303,10 @@ void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t s
   }
   if (stash) {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nerf_mlp_fwd_kernel<true>, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(nerf_mlp_fwd_kernel<true>, dim3(grid), dim3(256), lds, stream, p);
   } else {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nerf_mlp_fwd_kernel<false>, dim3(grid), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL(nerf_mlp_fwd_kernel<false>, dim3(grid), dim3(256), lds, stream, p);
   }
 }
 

@@ -317,6 +317,12 @@ int k_old_for(int ntiles, int grid, int num_cus, double dflt_share) {
   return k < 1 ? 1 : (k > K - 1 ? K - 1 : k);
 }
 
+// workgroups per CU of the SE3 chain kernels' launches
+int warp_grid_mul() {
+  static const int m = getenv("NRF_WARP_GRID_MUL") ? atoi(getenv("NRF_WARP_GRID_MUL")) : NRF_WARP_WAVES;
+  return m < 1 ? 1 : (m > 4 ? 4 : m);
+}
+
 int* tile_counter_or_null(float* base, int idx) {
   static const bool dynamic = getenv("NRF_DYNAMIC_TILES") != nullptr;
   return dynamic ? reinterpret_cast<int*>(base) + idx : nullptr;
@@ -628,7 +634,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
       L.w_dw4 = take(nt * TILE_ROWS * 4);
       L.w_dv4 = take(nt * TILE_ROWS * 4);
-      L.w_small_part = take((size_t)2 * G * WARP_SMALL_PART);
+      L.w_small_part = take((size_t)4 * G * WARP_SMALL_PART);
     }
   };
   p.cond = take((size_t)B * (h->R > 0 ? h->R : 1));
@@ -860,7 +866,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       }
       if (h->warp && lv == 0) {   // ONE SE3 dgrad launch (coarse + fine + background tiles), one set of bias partials
         const int nt_w = nt_mlp + (bgN > 0 ? p.ntiles[BG] : 0);
-        warp_bias_descs(0, nt_w < 2 * G ? nt_w : 2 * G, 0);
+        warp_bias_descs(0, nt_w < warp_grid_mul() * G ? nt_w : warp_grid_mul() * G, 0);
       }
     }
   }
@@ -1068,7 +1074,8 @@ void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_ray
   ta.st_win = ws + T.w_st_win; ta.st_h = ws + T.w_st_h; ta.st_wv = reinterpret_cast<float4*>(ws + T.w_st_wv);
   ta.bits = nullptr; ta.points_out = ws + T.wpoints; ta.points_raw = nullptr;
   ta.tile_counter = tile_counter_or_null(ws + p.counters, CT_TAN_FWD);
-  const int tgrid = ta.ntiles < gmul * h->num_cus ? ta.ntiles : gmul * h->num_cus;
+  (void)gmul;
+  const int tgrid = ta.ntiles < warp_grid_mul() * h->num_cus ? ta.ntiles : warp_grid_mul() * h->num_cus;
   h->prof.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[lv], stream);
   launch_warp_fwd(ta, nullptr, true, tgrid, stream);
   h->prof.end(stream);
@@ -1164,7 +1171,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       WarpFwdArgs bga;
       if (with_bg) bga = bg_fwd_args(h, params, bg, scalars, ws);
       const int wnt = p.ntiles[lv] + (with_bg ? p.ntiles[BG] : 0);
-      const int wgrid = wnt < gmul * h->num_cus ? wnt : gmul * h->num_cus;
+      const int wgrid = wnt < warp_grid_mul() * h->num_cus ? wnt : warp_grid_mul() * h->num_cus;
       pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * (p.rows[lv] + (with_bg ? p.bgN : 0)), stream);
       launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars, ws, train || jac), with_bg ? &bga : nullptr,
                       train || jac, wgrid, stream);
@@ -1415,8 +1422,9 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       w.point_ids = bg_ids_of(p, bg, ws);
       w.grad_embed = grad + h->wpo.embed;
     }
+    const int GW = warp_grid_mul() * h->num_cus;
     h->prof.begin("warp_dgrad", warp_dgrad_flops_row(h) * rows_all, stream);
-    launch_warp_bwd(wa[0], nlev > 1 ? &wa[1] : nullptr, nlev > 2 ? &wa[2] : nullptr, nt_all < G2 ? nt_all : G2, stream);
+    launch_warp_bwd(wa[0], nlev > 1 ? &wa[1] : nullptr, nlev > 2 ? &wa[2] : nullptr, nt_all < GW ? nt_all : GW, stream);
     h->prof.end(stream);
     if (el_on) {   // reverse of the tangent pass
       const LevelWs& T = p.L[TG];
@@ -1426,7 +1434,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       ta.d_points = nullptr; ta.st_win = nullptr; ta.st_wv = nullptr;
       ta.dy = ws + T.w_dy; ta.d_w4 = reinterpret_cast<float4*>(ws + T.w_dw4); ta.d_v4 = reinterpret_cast<float4*>(ws + T.w_dv4);
       ta.small_part = nullptr;
-      const int tgrid = p.ntiles[TG] < G2 ? p.ntiles[TG] : G2;
+      const int tgrid = p.ntiles[TG] < GW ? p.ntiles[TG] : GW;
       h->prof.begin("warp_tangent_dgrad", 3.0 * warp_dgrad_flops_row(h) * p.rows[0], stream);
       launch_warp_bwd(ta, nullptr, nullptr, tgrid, stream);
       h->prof.end(stream);

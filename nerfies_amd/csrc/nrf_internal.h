@@ -25,6 +25,11 @@ constexpr int WARP_SKIP = 4;
 constexpr int WACT_FLOATS = WARP_W * TILE_ROWS;
 constexpr int WARP_SMALL_PART = 784;   // db_trunk[6][128] | db_w[3] | db_v[3] | pad
 constexpr int WARP_MAX_IN = 64;        // padded trunk input width (3 + 6 F_w + G <= 64)
+// workgroups of the SE3 chain kernels resident per CU (= waves per SIMD the register allocation leaves room for): 48 KiB of
+// LDS each, so three fit once the kernels stay within 168 VGPRs
+#ifndef NRF_WARP_WAVES
+#define NRF_WARP_WAVES 2
+#endif
 
 // Offsets (in floats) of one NeRF MLP's leaves inside the flat parameter buffer
 // (canonical flax layout: kernel [in,out] row-major, then bias).

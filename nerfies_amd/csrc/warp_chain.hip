@@ -220,10 +220,12 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
     const int nq_in = PKw / 16, nit_in = PKw / 8;
     const float4* wL0 = wpk4 + (A.pk.fwd_L[0] / 4) + wave * nit_in * 64;
     WQuad<1> wnext = prefetch_quad<1>(wL0, lane);
+    BiasRegs<1> bnext;
+    if (!TANGENT) bnext = bias_load<1>(prm + A.po.trunk_b[0], wave * 32, lane);
 #pragma unroll 1
     for (int l = 0; l < WARP_DEPTH; ++l) {
       if (TANGENT) zero_acc<1>(acc);
-      else bias_acc<1>(acc, prm + A.po.trunk_b[l], wave * 32, lane);
+      else bias_set<1>(acc, bnext);
       if (l == 0) {
         mfma_k_loop<1, false>(acc, win, nq_in, wL0, lane, wnext);
       } else {
@@ -234,6 +236,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
         }
       }
       wnext = prefetch_quad<1>(wpk4 + (A.pk.fwd_L[l + 1 < WARP_DEPTH ? l + 1 : l] / 4) + wave * 16 * 64, lane);
+      if (!TANGENT) bnext = bias_load<1>(prm + A.po.trunk_b[l + 1 < WARP_DEPTH ? l + 1 : l], wave * 32, lane);   // before the stash stores
       __builtin_amdgcn_sched_barrier(0);
       if (TANGENT)
         fwd_epilogue<1, EPI_MASK, STASH>(
@@ -303,7 +306,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
 // (scalar loads; one copy of the tile code).
 struct WarpFwdArgs2 { WarpFwdArgs a[2]; int nt0, ntot; };
 template <bool STASH, bool TANGENT>
-__global__ __launch_bounds__(256, 2) void se3_warp_fwd_kernel(const WarpFwdArgs2 P) {
+__global__ __launch_bounds__(256, NRF_WARP_WAVES) void se3_warp_fwd_kernel(const WarpFwdArgs2 P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int nt0 = P.nt0, ntot = P.ntot;
 #pragma unroll 1
@@ -509,7 +512,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
 // The bias partials of all levels add up in the workgroup's registers and are flushed once (the leaves are shared).
 struct WarpBwdArgs3 { WarpBwdArgs a[3]; int n0, n01, ntot; };
 template <bool TANGENT>
-__global__ __launch_bounds__(256, 2) void se3_warp_bwd_kernel(const WarpBwdArgs3 P) {
+__global__ __launch_bounds__(256, NRF_WARP_WAVES) void se3_warp_bwd_kernel(const WarpBwdArgs3 P) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* dwv = smem + WACT_FLOATS;
   const int tid = threadIdx.x;

@@ -88,7 +88,7 @@ CASES = [(37, {}), (401, {}), (50, dict(num_nerf_point_freqs=10, use_camera_meta
 WARP_ALPHA = 4.0
 
 
-def check_forward_and_stash(setup):
+def check_forward_and_stash(setup, ulp_frac=0.05):
   """Step 1a: loss, rendered outputs and every stashed activation against the float64 oracle with the same roundings.
   float32 vs float64 accumulation moves a pre-activation by ~1e-7 relative, which flips the bfloat16 rounding of about
   one element in 3000 by one ulp (0.4 %), and later layers inherit those: per layer the relative L2 distance stays below
@@ -122,7 +122,8 @@ def check_forward_and_stash(setup):
       err = (got - want).abs()
       assert err.max().item() <= 2e-2 * want.abs().max().item(), (what, err.max().item(), want.abs().max().item())
       assert (err.norm() / want.norm()).item() <= 5e-3, (what, (err.norm() / want.norm()).item())
-      assert ((err > 2.0 ** -7 * want.abs() + 1e-6 * want.abs().max()).float().mean().item()) < 0.05, what
+      frac = (err > 2.0 ** -7 * want.abs() + 1e-6 * want.abs().max()).float().mean().item()
+      assert frac < ulp_frac, (what, frac)
     for l in range(8):
       close(hs[l][:, :tw], acts[(f'{name}/MLP_0', l)], (name, l))
       assert (hs[l][:, tw:] == 0).all()   # padded units of a narrower trunk stay dead

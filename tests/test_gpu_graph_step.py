@@ -66,7 +66,7 @@ def test_graph_replay_equals_eager_config_a_shape():
     key = next_key
     assert abs(st_e['fine']['loss/rgb'].item() - st_g['fine']['loss/rgb'].item()) < 1e-7
     assert abs(st_e['coarse']['metric/psnr'].item() - st_g['coarse']['metric/psnr'].item()) < 1e-4
-    w = _close(sg.optimizer.grad.cpu(), se.optimizer.grad.cpu(), mg.layout, 2e-6, f'gradient of step {k}')
+    w = _close(sg.optimizer.grad.cpu(), se.optimizer.grad.cpu(), mg.layout, 2e-5, f'gradient of step {k}')
     # Adam turns rounding-level gradient entries into sign-like updates: parameters within lr per step, and tight in L2
     dp = (sg.optimizer.target.flat - se.optimizer.target.flat)
     assert dp.abs().max().item() <= 2e-3 * (k + 1) and dp.norm().item() <= 2e-2 * (se.optimizer.target.flat - 0).norm().item() * 1e-3 * (k + 1) + 1e-4

@@ -1,7 +1,9 @@
 """RCCL on the one GPU a box has: a world-size-1 `nccl` process group loads librccl and pushes the step's fused
 [grad | stats] all-reduce (training.py:266-267), render_image's packed all_gather_into_tensor (eval.py:339) and bench.py's
-all-reduce timing through it, on the library's stream.  Results must equal the run without torch.distributed bit for bit
-(a one-rank sum / gather is the identity), so the first multi-GPU run only adds ranks to a path that has already executed.
+all-reduce timing through it, on the library's stream, so the first multi-GPU run only adds ranks to a path that has
+already executed.  A one-rank sum / gather is the identity: checked BITWISE on the step's own fused buffer and on a rendered
+chunk; the training run as a whole is compared with a run without torch.distributed to float32 summation order (two runs of
+the same step differ in the order of their float atomics, with or without a collective in between).
 Runs in a child process: a process group cannot be re-initialised inside the pytest process."""
 import json
 import os
@@ -49,7 +51,18 @@ out = {'params_sum': float(fp.flat.double().sum()), 'params_abs': float(fp.flat.
        'params_bits': int(fp.flat.view(torch.int32).to(torch.int64).sum().item()), 'losses': losses,
        'rgb_bits': int(img['rgb'].contiguous().view(torch.int32).to(torch.int64).sum().item()), 'rgb_shape': list(img['rgb'].shape),
        'rccl': None}
+grad1, _ = model.loss_and_grad(state.optimizer.target, batch, warp_extra=state.warp_extra, rngs={'coarse': 5, 'fine': 6},
+                               elastic={'weight': 0.01, 'reduce_method': 'weight'})
+out['grad_abs'] = float(grad1.double().abs().sum())
 if use_dist:
+  fused = state.optimizer._gs.clone()
+  before = fused.clone()
+  dist.all_reduce(fused)                                    # the step's own collective, on the step's own buffer
+  out['allreduce_identity'] = bool(torch.equal(fused, before))
+  packed = img['rgb'].reshape(-1, 3).contiguous()
+  gathered = torch.empty_like(packed)
+  dist.all_gather_into_tensor(gathered, packed)             # render_image's collective
+  out['allgather_identity'] = bool(torch.equal(gathered, packed))
   v = torch.cuda.nccl.version()
   out['rccl'] = list(v) if isinstance(v, (tuple, list)) else v
   out['backend'] = dist.get_backend()
@@ -71,8 +84,12 @@ def test_train_step_and_render_through_a_one_rank_rccl_communicator():
   plain = _run(False, 0)
   rccl = _run(True, 29517)
   assert rccl['backend'] == 'nccl' and rccl['rccl'], rccl
-  for k in ('params_bits', 'rgb_bits', 'losses', 'rgb_shape', 'params_sum'):
-    assert plain[k] == rccl[k], (k, plain[k], rccl[k])   # bit-identical: a one-rank all-reduce / gather is the identity
+  assert rccl['allreduce_identity'] and rccl['allgather_identity']        # bitwise: a one-rank sum / gather is the identity
+  assert plain['rgb_shape'] == rccl['rgb_shape'] == [5, 7, 3]
+  for a, b in zip(sum(plain['losses'], []), sum(rccl['losses'], [])):      # the same three steps, to float32 summation order
+    assert abs(a - b) <= 1e-6 + 5e-3 * abs(a), (plain['losses'], rccl['losses'])
+  assert abs(plain['grad_abs'] - rccl['grad_abs']) <= 1e-3 * plain['grad_abs']
+  assert abs(plain['params_abs'] - rccl['params_abs']) <= 1e-5 * plain['params_abs']
 
 
 def test_bench_line_through_rccl(tmp_path):

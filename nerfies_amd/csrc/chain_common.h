@@ -67,6 +67,22 @@ __device__ __forceinline__ int frag_index(int k, int p) {   // float index of el
   return (((k >> 5) * 8 + q) * 64 + (k & 31) + 32 * kk) * 4 + (p & 3);
 }
 
+// A [features][64 rows] LDS tile (plain rows, pitch 64: the posenc / trunk-input tile of the prologues) -> its fragment-order
+// stash tile in HBM, nblocks x 32 features (features >= kvalid are zero): every wave instruction stores 1 KiB contiguous.
+// (Rounds 1-2 stored the prologue's stash element by element from the threads that computed it -- ~16 scattered 4-byte
+// stores per thread, each behind a frag_index computation, with vmcnt(0) waits between the loops.)
+__device__ __forceinline__ void stash_tile_from_lds(const float* tile_lds, int kvalid, int nblocks, float* stash_tile, int wave, int lane) {
+  const __amdgpu_buffer_rsrc_t r = make_rsrc(stash_tile, nblocks * 32 * TILE_ROWS * 4);
+  const int j = lane & 31, kk = lane >> 5;
+  for (int pid = wave; pid < nblocks * 8; pid += 4) {
+    const int blk = pid >> 3, q = pid & 7;
+    const int k = blk * 32 + j, g = (q & 1) + 2 * kk + 4 * (q >> 1);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k < kvalid) v = *reinterpret_cast<const float4*>(tile_lds + k * TILE_ROWS + 4 * g);
+    buf_store4(v, r, lane * 16, pid * 1024);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // K loop:  acc[rb][cb] += A[64 x K] * B[K x 32*NCB]  for this wave.
 //   lds_in : feature-major tile, pitch 64 floats; SWZ selects the swizzled act layout.

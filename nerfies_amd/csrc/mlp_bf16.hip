@@ -443,14 +443,13 @@ template <bool DPTS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_bwd_bf16_kernel(const ChainBwdBf16Args A) {
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   constexpr int NW = 8;
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = lane & 31, h = lane >> 5;
   const int niter = (A.rows + 255) / 256;
   const BfStash& S = A.st;
 
   BfStream st;
-  st.src = reinterpret_cast<const char*>(A.wpk) + lane * 16;
+  st.src = reinterpret_cast<const char*>(A.wpk) + lane0 * 16;
   st.soff = 0;
   st.cur = 0;
   bf_dma<DG1, NW>(st.src, 0, bf_lds, 0, wave);      // G1
@@ -460,6 +459,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 #pragma unroll 1
   for (int it = blockIdx.x; it < niter; it += gridDim.x) {
+    int lo = lane0;
+    asm volatile("" : "+v"(lo));   // per-iteration opaque lane: see mlp_chain.hip's backward tile
+    const int lane = lo, n = lane & 31, h = lane >> 5;
     const size_t gidx = (size_t)it * 8 + wave;
     const int row = it * 256 + wave * 32 + n;
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);

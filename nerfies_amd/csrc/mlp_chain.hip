@@ -49,12 +49,9 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* act = smem;                 // [256][64] swizzled
   float* pe = smem + ACT_FLOATS;     // [PK][64]; reused as scratch after the skip layer
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int j = lane & 31, h = lane >> 5;
-  const int p = lane;                // tile row handled in the per-row (VALU) phases
-  const int part = wave;             // ... by 4 threads, one per wave
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int part = wave;             // per-row (VALU) phases: 4 threads per tile row, one per wave
   const float* __restrict__ prm = A.params;
   const int PK = A.PK;
   const int PKS = (PK + 31) / 32 * 32;   // features per posenc stash tile (whole 32-feature blocks)
@@ -64,11 +61,11 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
 #ifdef NRF_TIMELINE_BUILD
   int stamp_i = 0;
   auto STAMP = [&]() {
-    if (A.timeline && blockIdx.x == 0 && lane == 0 && stamp_i < 64) A.timeline[wave * 64 + stamp_i] = clock64();
+    if (A.timeline && blockIdx.x == 0 && (tid0 & 63) == 0 && stamp_i < 64) A.timeline[wave * 64 + stamp_i] = clock64();
     ++stamp_i;
   };
   unsigned long long wg_t0 = 0, wg_w0 = 0;
-  if (A.timeline && tid == 0) { wg_t0 = clock64(); wg_w0 = wall_clock64(); }
+  if (A.timeline && tid0 == 0) { wg_t0 = clock64(); wg_w0 = wall_clock64(); }
 #else
   auto STAMP = [&]() {};
 #endif
@@ -77,6 +74,14 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
   for (int tile = A.tile_counter ? next_tile(A.tile_counter, tslot) : ti.first; tile < (A.tile_counter ? A.ntiles : ti.end);
        tile = A.tile_counter ? next_tile(A.tile_counter, tslot, tile) : tile + ti.step) {
     STAMP();   // tile start
+    // the lane index is made opaque once per tile: everything derived from it (fragment addresses, row indices, mask shifts)
+    // is then recomputed per tile instead of being hoisted out of the tile loop into registers that live -- i.e. spill -- across
+    // the whole kernel (hipcc hoists ~50 such per-lane constants otherwise)
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int p = lane;                // tile row handled in the per-row (VALU) phases
     // ---- prologue: sample point + SinusoidalEncoder (modules.py:213-228) ----
     {
       int r = tile * TILE_ROWS + p;
@@ -91,17 +96,12 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
         for (int c = 0; c < 3; ++c)   // origins + z_vals * directions  (model_utils.py:72-73)
           x[c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
       }
-      float* stp = STASH ? A.st_pe + (size_t)tile * PKS * TILE_ROWS : nullptr;
-      auto put = [&](int k, float v) {
-        pe[k * TILE_ROWS + p] = v;
-        if (STASH) stp[frag_index(k, p)] = v;
-      };
+      auto put = [&](int k, float v) { pe[k * TILE_ROWS + p] = v; };
       if (part == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) put(c, x[c]);
       } else if (part == 1) {
         for (int k = A.P; k < PK; ++k) put(k, 0.f);
-        if (STASH) for (int k = PK; k < PKS; ++k) stp[frag_index(k, p)] = 0.f;
       }
       const float half_pi = 1.57079632679489661923f;   // fp32(pi/2), modules.py:222
       for (int f = part; f < A.F; f += 4) {
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
       }
     }
     __syncthreads();
+    if (STASH) stash_tile_from_lds(pe, PK, PKS / 32, A.st_pe + (size_t)tile * PKS * TILE_ROWS, wave, lane);   // posenc stash, coalesced
 
     STAMP();   // prologue done
     f32x16 acc[2][2];
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
     }
   }
 #ifdef NRF_TIMELINE_BUILD
-  if (A.timeline && tid == 0) {   // per-workgroup residency record: start, end (shader clock), HW_ID, XCC_ID
+  if (A.timeline && tid0 == 0) {   // per-workgroup residency record: start, end (shader clock), HW_ID, XCC_ID
     unsigned long long* rec = A.timeline + 1024 + 4 * (size_t)blockIdx.x;
     rec[0] = wg_t0; rec[1] = clock64();
     rec[2] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));    // HW_REG_HW_ID
@@ -335,7 +336,8 @@ __device__ __forceinline__ void bwd_acc_zero(BwdAcc& c) {
 __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, float* smem, BwdAcc& C) {
   float* act = smem;                 // [256][64] swizzled: current dpre tile
   float* dr = smem + ACT_FLOATS;     // [4][64]: d raw rgb (3) and d raw sigma of the tile rows
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -357,6 +359,9 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
 
     // ---- rgb logit^T (3 -> 128) on the VALU, ReLU mask of the rgb hidden layer ----
     {
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // section-local lane constants (see the d posenc section)
+      const int lane = ln, j = ln & 31, h = ln >> 5;
       const int n = wave * 32 + j;
       const float w0 = prm[A.po.logit_k + 3 * n], w1 = prm[A.po.logit_k + 3 * n + 1], w2 = prm[A.po.logit_k + 3 * n + 2];
       const uint32_t mb = A.bits_rgbh[((size_t)tile * 4 + wave) * 64 + lane];
@@ -379,7 +384,9 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
     // ---- per-ray sums of dpre_rgbh (gradient of the per-ray condition columns of the rgb branch):
     //      thread (n, half) walks 32 tile rows of feature n in LDS and flushes at ray boundaries ----
     {
-      const int n = tid & 127, hf = tid >> 7;
+      int t2 = tid;
+      asm volatile("" : "+v"(t2));
+      const int n = t2 & 127, hf = t2 >> 7;
       const int row0 = 32 * hf;
       const int grow0 = tile * TILE_ROWS + row0;
       int ray = grow0 / A.S;
@@ -415,6 +422,9 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
     {
       const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy_bn + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
       __syncthreads();
+      int le = tid;
+      asm volatile("" : "+v"(le));
+      const int lane = le & 63, j = lane & 31, h = lane >> 5;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
         const int n = wave * 64 + 32 * cb + j;
@@ -451,6 +461,9 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
       const __amdgpu_buffer_rsrc_t dy =
           make_rsrc(A.dy_trunk + (size_t)(l - 1) * layer_fl + (size_t)tile * FRAG_TILE_256, FRAG_TILE_256 * 4);
       __syncthreads();
+      int le = tid;
+      asm volatile("" : "+v"(le));   // epilogue-local lane constants: not live across the K loop
+      const int lane = le & 63, j = lane & 31, h = lane >> 5;
       float bs[2];
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
@@ -484,21 +497,42 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
       if (A.d_points && (l - 1 == SKIP_LAYER || l == 1)) {
         float* dpe = dr;
         const bool first = (l - 1 == SKIP_LAYER);
-        const float4* wq = wpk4 + ((first ? A.pk.bwd_L4bT : A.pk.bwd_L0T) / 4) + lane;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // opaque: the per-lane constants of this section are recomputed here, not hoisted out of
+                                       // the tile loop into registers that live (= spill) across the trunk layers
+        const float4* wq = wpk4 + ((first ? A.pk.bwd_L4bT : A.pk.bwd_L0T) / 4) + ln;
         const int rb = wave & 1, cb = wave >> 1;
         f32x16 a2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) a2[r] = 0.f;
-        const int i = lane & 31, kk = lane >> 5;
+        const int j = ln & 31, h = ln >> 5;
+        const int i = j, kk = h;
         const int aoff = 2 * (i & 1) + rb;
-#pragma unroll 4
-        for (int it = 0; it < 64; ++it) {
-          const float4 b = wq[it * 64];
-          const int k0 = 4 * it + kk;
-          const float a0 = act[act_addr(k0, i >> 1) + aoff];
-          const float a1 = act[act_addr(k0 + 2, i >> 1) + aoff];
-          a2 = mfma32(a0, cb ? b.y : b.x, a2);
-          a2 = mfma32(a1, cb ? b.w : b.z, a2);
+        const int PKS = (A.PK + 31) / 32 * 32;
+        const int npw = PKS / 32 * 2;   // pieces per wave: 2 or 4
+        // B from L2 in batches of 4 float4, the next batch in flight under the current one's MFMAs
+        auto load_b = [&](float4 (&b)[4], int bt) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) b[u] = wq[(bt * 4 + u) * 64];
+        };
+        auto mma_b = [&](const float4 (&b)[4], int bt) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int k0 = 4 * (bt * 4 + u) + kk;
+            const float a0 = act[act_addr(k0, i >> 1) + aoff];
+            const float a1 = act[act_addr(k0 + 2, i >> 1) + aoff];
+            a2 = mfma32(a0, cb ? b[u].y : b[u].x, a2);
+            a2 = mfma32(a1, cb ? b[u].w : b[u].z, a2);
+          }
+        };
+        float4 b0[4], b1[4];
+        load_b(b0, 0);
+#pragma unroll 1
+        for (int bt = 0; bt < 16; bt += 2) {
+          load_b(b1, bt + 1);
+          mma_b(b0, bt);
+          if (bt + 2 < 16) load_b(b0, bt + 2);
+          mma_b(b1, bt + 1);
         }
         const int n = 32 * cb + j;
         if (n < A.PK) {
@@ -510,26 +544,50 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
           }
         }
         __syncthreads();
-        if (!first && tid < TILE_ROWS) {
+        if (!first) {
           // chain rule through SinusoidalEncoder: d sin(f x) = f cos(f x), d sin(f x + pi/2) = -f sin(f x),
-          // with sin / cos taken from the forward posenc stash.
-          const int row = tile * TILE_ROWS + tid;
-          const int PKS = (A.PK + 31) / 32 * 32;
-          const float* pe = A.st_pe + (size_t)tile * PKS * TILE_ROWS;
-          float dx[3];
+          // with sin / cos taken from the forward posenc stash.  Every thread holds 4 rows of one feature per piece:
+          // feature k's term  -+ 2^f * pe[k] * dpe[partner(k)]  goes to the contrib tile (act is dead), element (k, row)
+          // at k*64 + (row ^ (k & 31)); 192 threads then sum their (row, c) over the 2F features in a fixed order.
+          float* contrib = act;
+          const int nfeat = 3 + 6 * A.F;
+          float4 pv[4];
+          {
+            const float4* pe4 = reinterpret_cast<const float4*>(A.st_pe + (size_t)tile * PKS * TILE_ROWS) + ln;
 #pragma unroll
-          for (int c = 0; c < 3; ++c) dx[c] = dpe[c * TILE_ROWS + (tid ^ c)];
-          for (int f = 0; f < A.F; ++f) {
-            const float fr = (float)(1 << f);
+            for (int u = 0; u < 4; ++u)
+              if (u < npw) pv[u] = pe4[(wave + 4 * u) * 64];
+          }
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              const int ns = 3 + 6 * f + c, nc = ns + 3;
-              const float sn = pe[frag_index(ns, tid)], cs = pe[frag_index(nc, tid)];
-              dx[c] += fr * (cs * dpe[ns * TILE_ROWS + (tid ^ (ns & 31))] - sn * dpe[nc * TILE_ROWS + (tid ^ (nc & 31))]);
+          for (int u = 0; u < 4; ++u) {
+            if (u < npw) {
+              const int pid = wave + 4 * u, q = pid & 7;
+              const int k = (pid >> 3) * 32 + j, g = (q & 1) + 2 * h + 4 * (q >> 1);
+              if (k >= 3 && k < nfeat) {
+                const int f = (k - 3) / 6, r = (k - 3) - 6 * f;
+                const int partner = r < 3 ? k + 3 : k - 3;
+                const float sgn = r < 3 ? -(float)(1 << f) : (float)(1 << f);
+                const float* dp = dpe + partner * TILE_ROWS;
+                float* co = contrib + k * TILE_ROWS;
+                const float pvv[4] = {pv[u].x, pv[u].y, pv[u].z, pv[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const int row = 4 * g + e;
+                  co[row ^ (k & 31)] = sgn * pvv[e] * dp[row ^ (partner & 31)];
+                }
+              }
             }
           }
-          float* o = A.d_points + (size_t)row * 3;
-          o[0] = dx[0]; o[1] = dx[1]; o[2] = dx[2];
+          __syncthreads();
+          if (tid < 3 * TILE_ROWS) {
+            const int row = tid / 3, c = tid - 3 * row;
+            float dx = dpe[c * TILE_ROWS + (row ^ c)];
+            for (int f = 0; f < A.F; ++f) {
+              const int ns = 3 + 6 * f + c, nc = ns + 3;
+              dx += contrib[ns * TILE_ROWS + (row ^ (ns & 31))] + contrib[nc * TILE_ROWS + (row ^ (nc & 31))];
+            }
+            A.d_points[(size_t)tile * TILE_ROWS * 3 + tid] = dx;
+          }
         }
         if (!first) __syncthreads();   // dr (aliased) is rewritten by the next tile
       }

@@ -28,7 +28,7 @@ constexpr int WARP_MAX_IN = 64;        // padded trunk input width (3 + 6 F_w + 
 // workgroups of the SE3 chain kernels resident per CU (= waves per SIMD the register allocation leaves room for): 48 KiB of
 // LDS each, so three fit once the kernels stay within 168 VGPRs
 #ifndef NRF_WARP_WAVES
-#define NRF_WARP_WAVES 2
+#define NRF_WARP_WAVES 3
 #endif
 
 // Offsets (in floats) of one NeRF MLP's leaves inside the flat parameter buffer

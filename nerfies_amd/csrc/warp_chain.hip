@@ -116,6 +116,18 @@ __device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, 
   dw = c.A * cross(x, g) + c.B * (D(x) + cross(v, g)) + c.C * D(v) + sa * w;
 }
 
+// In-kernel timeline (scripts/exp_warp_timeline.py), compiled in only with -DNRF_TIMELINE_BUILD: shader-clock stamps of the
+// first tile of workgroup 0, per wave, of the LAST launch of each kernel flavour: [fwd primal, fwd tangent, bwd primal,
+// bwd tangent][wave][stamp].
+#ifdef NRF_TIMELINE_BUILD
+__device__ unsigned long long g_warp_tl[4][4][64];
+#define WSTAMP_INIT(K) int stamp_i_ = 0; const int stamp_k_ = (K); const bool stamp_on_ = blockIdx.x == 0 && tile == 0 && (threadIdx.x & 63) == 0
+#define WSTAMP() do { if (stamp_on_ && stamp_i_ < 64) g_warp_tl[stamp_k_][threadIdx.x >> 6][stamp_i_] = clock64(); ++stamp_i_; } while (0)
+#else
+#define WSTAMP_INIT(K)
+#define WSTAMP()
+#endif
+
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
@@ -126,7 +138,9 @@ template <bool STASH, bool TANGENT>
 __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int tile, float* smem) {
   float* act = smem;                  // [128][64] swizzled
   float* win = smem + WACT_FLOATS;    // [PKw][64] trunk input; reused as scratch after the skip layer
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));       // opaque per tile: per-lane constants are recomputed per tile, not hoisted out of the tile
+                                      // loop into registers that live across the whole kernel (mlp_chain.hip, bwd_tile)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = lane, part = wave;    // per-row phases: 4 threads per tile row
@@ -135,6 +149,8 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
   const int PKS = (PKw + 31) / 32 * 32;
   const float4* wpk4 = reinterpret_cast<const float4*>(A.wpk);
   const size_t st_layer = (size_t)A.ntiles * FRAG_TILE_128;
+  WSTAMP_INIT(TANGENT ? 1 : 0);
+  WSTAMP();   // tile start
   {
     // ---- prologue: sample point, AnnealedSinusoidalEncoder (modules.py:231-294), GLO code ----
     float x[3] = {0.f, 0.f, 0.f};
@@ -144,17 +160,12 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
       // d input / d x_c from the primal input tile: d(win sin a) = f (win cos a), d(win cos a) = -f (win sin a)
       const int c = tile / A.nt_prim;
       const float* pw = A.prim_win + (size_t)tprim * PKS * TILE_ROWS;
-      float* stp = STASH ? A.st_win + (size_t)tile * PKS * TILE_ROWS : nullptr;
-      auto put = [&](int k, float v) {
-        win[k * TILE_ROWS + p] = v;
-        if (STASH) stp[frag_index(k, p)] = v;
-      };
+      auto put = [&](int k, float v) { win[k * TILE_ROWS + p] = v; };
       if (part == 0) {
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) put(cc, cc == c ? 1.f : 0.f);
       } else if (part == 1) {
         for (int k = 3 + 6 * A.F; k < PKw; ++k) put(k, 0.f);
-        if (STASH) for (int k = PKw; k < PKS; ++k) stp[frag_index(k, p)] = 0.f;
       }
       for (int f = part; f < A.F; f += 4) {
         const float fr = (float)(1 << f);
@@ -180,11 +191,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
           x[c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
         id = A.warp_ids ? A.warp_ids[ray] : ray;   // nullptr: per-ray codes (metadata_encoded / TimeEncoder output)
       }
-      float* stp = STASH ? A.st_win + (size_t)tile * PKS * TILE_ROWS : nullptr;
-      auto put = [&](int k, float v) {
-        win[k * TILE_ROWS + p] = v;
-        if (STASH) stp[frag_index(k, p)] = v;
-      };
+      auto put = [&](int k, float v) { win[k * TILE_ROWS + p] = v; };
       if (part == 0) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) put(c, x[c]);
@@ -195,7 +202,6 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
         const float* __restrict__ code = A.embed_table + (int64_t)id * A.G;   // glo.py:50-53
         for (int g = 0; g < A.G; ++g) put(3 + 6 * A.F + g, code[g]);
         for (int k = A.Win; k < PKw; ++k) put(k, 0.f);
-        if (STASH) for (int k = PKw; k < PKS; ++k) stp[frag_index(k, p)] = 0.f;
       }
       const float half_pi = 1.57079632679489661923f;
       const float pi = 3.14159265358979323846f;
@@ -214,6 +220,8 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
       }
     }
     __syncthreads();
+    WSTAMP();   // prologue
+    if (STASH) stash_tile_from_lds(win, PKw, PKS / 32, A.st_win + (size_t)tile * PKS * TILE_ROWS, wave, lane);   // trunk-input stash, coalesced
 
     // ---- trunk: 6 x Dense(128)+ReLU, skip concat [h, inputs] at layer 4 (warping.py:264-269) ----
     f32x16 acc[2][1];
@@ -235,6 +243,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
           mfma_k_loop<1, false>(acc, win, nq_in, w4b, lane, prefetch_quad<1>(w4b, lane));
         }
       }
+      WSTAMP();   // layer l: K loop
       wnext = prefetch_quad<1>(wpk4 + (A.pk.fwd_L[l + 1 < WARP_DEPTH ? l + 1 : l] / 4) + wave * 16 * 64, lane);
       if (!TANGENT) bnext = bias_load<1>(prm + A.po.trunk_b[l + 1 < WARP_DEPTH ? l + 1 : l], wave * 32, lane);   // before the stash stores
       __builtin_amdgcn_sched_barrier(0);
@@ -248,6 +257,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
             acc, wave * 32, act,
             make_rsrc(STASH ? A.st_h + l * st_layer + (size_t)tile * FRAG_TILE_128 : nullptr, FRAG_TILE_128 * 4),
             wave * 8 * 1024, STASH ? A.bits + (((size_t)l * A.ntiles + tile) * 4 + wave) * 64 : nullptr, lane);
+      WSTAMP();   // layer l: epilogue
     }
 
     // ---- heads: w = Dense(128->3)(h), v = Dense(128->3)(h)  (warping.py:271-288, 328-329) ----
@@ -276,6 +286,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
 #pragma unroll
       for (int c = 0; c < 6; ++c) win[(6 * part + c) * TILE_ROWS + p] = s[c];
       __syncthreads();
+      WSTAMP();   // heads
       if (part == 0 && TANGENT) {
 #pragma unroll
         for (int c = 0; c < 6; ++c)
@@ -296,6 +307,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
         }
       }
       __syncthreads();   // scratch (aliases win) is free again for the next tile's prologue
+      WSTAMP();   // exp_se3 + outputs
     }
   }
 }
@@ -344,7 +356,8 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
   float* dwv = smem + WACT_FLOATS;         // [8][64]: dL/dw (0..2), dL/dv (3..5) of the tile rows
   float* dcs = dwv + 8 * TILE_ROWS;        // [8][64]: dL/dcode of the tile rows
   int* ids_s = reinterpret_cast<int*>(dcs + 8 * TILE_ROWS);   // [64]: warp id of the tile rows (-1: padding)
-  const int tid = threadIdx.x;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));       // opaque per tile (see warp_fwd_tile)
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
@@ -356,6 +369,8 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
   const int n = wave * 32 + j;             // this lane's trunk column
   float (&db)[WARP_DEPTH] = C.db;
   float (&hsum)[6] = C.hsum;
+  WSTAMP_INIT(TANGENT ? 3 : 2);
+  WSTAMP();   // tile start
   {
     const int tprim = TANGENT ? tile % A.nt_prim : tile;
     // ---- exp_se3 VJP per row ----
@@ -387,6 +402,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       hsum[0] += dw.x; hsum[1] += dw.y; hsum[2] += dw.z; hsum[3] += dv.x; hsum[4] += dv.y; hsum[5] += dv.z;
     }
     __syncthreads();
+    WSTAMP();   // exp_se3 VJP
 
     // ---- heads^T (6 -> 128) on the VALU, ReLU mask of trunk layer 5 -> dpre_5 ----
     {
@@ -415,6 +431,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       db[WARP_DEPTH - 1] += bsum;
     }
     __syncthreads();
+    WSTAMP();   // heads^T
 
     // GLO-code gradient: d code[g] = dpre_l . W_l[row_base + g][:]^T for the two layers that see the
     // input (l = 4 via the skip rows, l = 0), K = 128 on the VALU; thread = (row p, codes 2*part, 2*part+1).
@@ -447,10 +464,11 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
     WQuad<1> wnext = prefetch_quad<1>(wpk4 + (A.pk.bwd_LT[WARP_DEPTH - 1] / 4) + wave * 16 * 64, lane);
 #pragma unroll 1
     for (int l = WARP_DEPTH - 1; l >= 1; --l) {
-      if (!TANGENT && l == WARP_SKIP) code_grad(A.po.trunk_k[WARP_SKIP] + (int64_t)(WARP_W + 3 + 6 * A.F) * WARP_W);
+      if (!TANGENT && l == WARP_SKIP) { code_grad(A.po.trunk_k[WARP_SKIP] + (int64_t)(WARP_W + 3 + 6 * A.F) * WARP_W); WSTAMP(); }
       const uint32_t mb = A.bits[(((size_t)(l - 1) * A.nt_prim + tprim) * 4 + wave) * 64 + lane];
       zero_acc<1>(acc);
       mfma_k_loop<1, true>(acc, act, 8, wpk4 + (A.pk.bwd_LT[l] / 4) + wave * 16 * 64, lane, wnext);
+      WSTAMP();   // step l: K loop
       wnext = prefetch_quad<1>(wpk4 + (A.pk.bwd_LT[l > 1 ? l - 1 : 1] / 4) + wave * 16 * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
       const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy + (size_t)(l - 1) * layer_fl + (size_t)tile * FRAG_TILE_128, FRAG_TILE_128 * 4);
@@ -468,9 +486,11 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       for (int q = 0; q < WARP_DEPTH; ++q)
         if (q == l - 1) db[q] += bsum;
       __syncthreads();
+      WSTAMP();   // step l: epilogue
     }
     if (TANGENT) return;
     code_grad(A.po.trunk_k[0] + (int64_t)(3 + 6 * A.F) * WARP_W);
+    WSTAMP();   // code gradient (layer 0 rows)
 
     // ---- sums of d code over the rows of the tile that share a warp id -> scatter-add into the embedding-table
     //      gradient.  One atomic per (distinct id of the tile, code): the background batch carries a random id per point
@@ -504,6 +524,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       }
     }
     __syncthreads();
+    WSTAMP();   // embedding-gradient scatter
   }
 }
 
@@ -805,3 +826,9 @@ void launch_elastic(const ElasticArgs& a, hipStream_t stream) {
 }
 
 }  // namespace nrf
+
+#ifdef NRF_TIMELINE_BUILD
+extern "C" __attribute__((visibility("default"))) int nrf_debug_warp_timeline(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nrf::g_warp_tl), sizeof(nrf::g_warp_tl));
+}
+#endif

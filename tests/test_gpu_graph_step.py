@@ -69,7 +69,10 @@ def test_graph_replay_equals_eager_config_a_shape():
     w = _close(sg.optimizer.grad.cpu(), se.optimizer.grad.cpu(), mg.layout, 2e-5, f'gradient of step {k}')
     # Adam turns rounding-level gradient entries into sign-like updates: parameters within lr per step, and tight in L2
     dp = (sg.optimizer.target.flat - se.optimizer.target.flat)
-    assert dp.abs().max().item() <= 2e-3 * (k + 1) and dp.norm().item() <= 2e-2 * (se.optimizer.target.flat - 0).norm().item() * 1e-3 * (k + 1) + 1e-4
+    assert dp.abs().max().item() <= 2e-3 and dp.norm().item() <= 2e-2 * (se.optimizer.target.flat - 0).norm().item() * 1e-3 + 1e-4
+    # ... and bring the two replicas together again, so that every step's comparison is of ONE step from the same state
+    for dst, src in ((sg.optimizer.target.flat, se.optimizer.target.flat), (sg.optimizer.m, se.optimizer.m), (sg.optimizer.v, se.optimizer.v)):
+      dst.copy_(src)
   assert sg.optimizer.step == se.optimizer.step == 4
   print(f'[graphed step, config A shape] last-step gradient: worst leaf {w:.1e} of its max-abs vs eager')
 

@@ -37,6 +37,10 @@ batch['background_points'] = (torch.rand(512, 3, generator=torch.Generator().man
 model, fp = H.gpu_model(spec, oparams, B)
 state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=2.5)
 sp = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, background_loss_weight=1.0)
+# the gradient at the initial parameters (before Adam's normalised updates amplify rounding-level differences between two runs)
+grad0, _ = model.loss_and_grad(state.optimizer.target, batch, warp_extra=state.warp_extra, rngs={'coarse': 5, 'fine': 6},
+                               elastic={'weight': 0.01, 'reduce_method': 'weight'})
+grad_abs0 = float(grad0.double().abs().sum())
 key, losses = 7, []
 for _ in range(3):
   state, stats, key = training.train_step(model, key, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight',
@@ -51,9 +55,7 @@ out = {'params_sum': float(fp.flat.double().sum()), 'params_abs': float(fp.flat.
        'params_bits': int(fp.flat.view(torch.int32).to(torch.int64).sum().item()), 'losses': losses,
        'rgb_bits': int(img['rgb'].contiguous().view(torch.int32).to(torch.int64).sum().item()), 'rgb_shape': list(img['rgb'].shape),
        'rccl': None}
-grad1, _ = model.loss_and_grad(state.optimizer.target, batch, warp_extra=state.warp_extra, rngs={'coarse': 5, 'fine': 6},
-                               elastic={'weight': 0.01, 'reduce_method': 'weight'})
-out['grad_abs'] = float(grad1.double().abs().sum())
+out['grad_abs'] = grad_abs0
 if use_dist:
   fused = state.optimizer._gs.clone()
   before = fused.clone()
@@ -88,7 +90,7 @@ def test_train_step_and_render_through_a_one_rank_rccl_communicator():
   assert plain['rgb_shape'] == rccl['rgb_shape'] == [5, 7, 3]
   for a, b in zip(sum(plain['losses'], []), sum(rccl['losses'], [])):      # the same three steps, to float32 summation order
     assert abs(a - b) <= 1e-6 + 5e-3 * abs(a), (plain['losses'], rccl['losses'])
-  assert abs(plain['grad_abs'] - rccl['grad_abs']) <= 1e-3 * plain['grad_abs']
+  assert abs(plain['grad_abs'] - rccl['grad_abs']) <= 1e-4 * plain['grad_abs']     # at the initial parameters
   assert abs(plain['params_abs'] - rccl['params_abs']) <= 1e-5 * plain['params_abs']
 
 

@@ -16,7 +16,7 @@ extra = sys.argv[2:]
 sys.argv = ['bench.py', '--mode', mode, '--steps', '6', '--warmup', '3', '--burn-in-s', '0', '--no-cpu-baseline'] + extra
 with contextlib.redirect_stdout(io.StringIO()):
   bench.main()
-lib = L.load()
+lib = L.load_library()
 buf = (C.c_uint64 * (4 * 4 * 64))()
 fn = lib.nrf_debug_warp_timeline
 fn.argtypes = [C.c_void_p]

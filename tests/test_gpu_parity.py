@@ -143,6 +143,36 @@ def test_sample_pdf(Nc, Nf, stratified):
   assert (err < 5e-6).double().mean() > 0.998
 
 
+def test_sample_pdf_with_ties_and_a_coarse_list_that_is_not_ascending():
+  """The merge in sample_fine_kernel relies on z_coarse ascending and falls back to rank counting per block when it is not;
+  equal z values (coarse/coarse, coarse/fine) must come out as a sorted list either way."""
+  L, lib = _lib()
+  rng = np.random.default_rng(5)
+  B, Nc, Nf = 23, 64, 128
+  zc = torch.tensor(np.sort(rng.uniform(0.05, 1.0, size=(B, Nc)), -1), dtype=torch.float32)
+  zc[2, 6] = zc[2, 5]                       # a tie inside a sorted list
+  zc[9, [10, 11]] = zc[9, [11, 10]]         # one inversion: this ray's block takes the fallback
+  zc[20, [0, 63]] = zc[20, [63, 0]]
+  w = torch.tensor(rng.uniform(size=(B, Nc)) ** 4, dtype=torch.float32)
+  u = torch.tensor(rng.uniform(size=(B, Nf)), dtype=torch.float32)
+  u[3, 7] = u[3, 8]                         # a tie between two fine draws
+  zo = torch.empty(B, Nc + Nf, device=DEV)
+  g = [t.to(DEV) for t in (zc, w, u)]
+  L.check(lib.nrf_sample_pdf(_p(g[0]), _p(g[1]), B, Nc, Nf, 1, _p(g[2]), 0, 0, _p(zo), _stream()))
+  got = zo.cpu()
+  assert (got[:, 1:] >= got[:, :-1]).all()
+  zmid = .5 * (zc[..., 1:] + zc[..., :-1]).double()
+  o = torch.zeros(B, 3, dtype=torch.float64)
+  ref, _ = O.sample_pdf(zmid, w[..., 1:-1].double(), o, o, zc.double(), Nf, True, u.double())
+  sorted_rows = [r for r in range(B) if r not in (9, 20)]      # the cdf of an unsorted bin list is the oracle's business too,
+  err = (got.double() - ref).abs()                              # but its fp32 noise model is the sorted one: bound those rows loosely
+  assert err[sorted_rows].max() < 2e-4 and (err[sorted_rows] < 5e-6).double().mean() > 0.998
+  assert err.max() < 5e-3
+  # every coarse value is present, bit for bit
+  for r in (2, 9, 20):
+    assert set(zc[r].tolist()) <= set(got[r].tolist())
+
+
 @pytest.mark.parametrize('B', [64, 37])
 def test_forward_parity(B):
   spec, model, fp, gb, p64, b64 = _make(B)

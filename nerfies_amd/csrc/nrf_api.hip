@@ -638,7 +638,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     }
   };
   p.cond = take((size_t)B * (h->R > 0 ? h->R : 1));
-  p.mse = take(64);
+  p.mse = take((size_t)2 * B);   // [level][ray] squared error
   p.zero_rgb = take((size_t)B * 3);
   for (int lv = 0; lv < h->nlevels; ++lv) {
     LevelWs& L = p.L[lv];
@@ -1285,7 +1285,6 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     ZeroArgs z;
     memset(&z, 0, sizeof(z));
     z.add(grad, h->nparams);
-    z.add(ws + p.mse, 64);
     if (warp_on && h->time_enc) z.add(ws + p.t_dcodes, (long long)B * h->G);
     if (wr_on) z.add(ws + p.wr_sums, 64);
     if (el_on) z.add(ws + p.el_sums, 64);
@@ -1295,13 +1294,21 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   }
   const int G2 = 2 * h->num_cus;   // chain kernels: two workgroups per CU
   h->prof.begin("composite_bwd", 0, stream);
-  for (int lv = 0; lv < h->nlevels; ++lv) {
-    const LevelWs& L = p.L[lv];
-    const float loss_scale = 2.0f / (3.0f * (float)B);   // d/d rgb of mean over (B,3) (training.py:172)
-    launch_composite_bwd(reinterpret_cast<const float4*>(ws + L.out4), ws + L.z, rays->directions, B, p.S[lv],
-                         d.use_white_background, d.use_sample_at_infinity, d.sigma_activation, ws + L.rgb, target,
-                         target ? nullptr : d_rgb[lv], loss_scale, reinterpret_cast<float4*>(ws + L.d_raw4),
-                         p.ntiles[lv] * TILE_ROWS, ws + p.mse + lv, h->A > 0 ? ws + L.dsig_ray : nullptr, stream);
+  {
+    CompositeBwdArgs ca[2];
+    for (int lv = 0; lv < h->nlevels; ++lv) {
+      const LevelWs& L = p.L[lv];
+      CompositeBwdArgs& c = ca[lv];
+      memset(&c, 0, sizeof(c));
+      c.out4 = reinterpret_cast<const float4*>(ws + L.out4); c.z = ws + L.z; c.dirs = rays->directions;
+      c.B = B; c.S = p.S[lv]; c.white_bkgd = d.use_white_background; c.sample_at_inf = d.use_sample_at_infinity;
+      c.sigma_act = d.sigma_activation;
+      c.rgb_out = ws + L.rgb; c.target = target; c.d_rgb = target ? nullptr : d_rgb[lv];
+      c.loss_scale = 2.0f / (3.0f * (float)B);   // d/d rgb of mean over (B,3) (training.py:172)
+      c.d_raw4 = reinterpret_cast<float4*>(ws + L.d_raw4); c.rows_pad = p.ntiles[lv] * TILE_ROWS;
+      c.mse_ray = ws + p.mse + (size_t)lv * B; c.dsig_ray = h->A > 0 ? ws + L.dsig_ray : nullptr;
+    }
+    launch_composite_bwd(ca[0], h->nlevels > 1 ? &ca[1] : nullptr, stream);
   }
   h->prof.end(stream);
   double mlp_rows = 0;
@@ -1441,9 +1448,10 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     }
   }
   h->prof.begin("cond_wgrad", 0, stream);
+  launch_cond_wgrad(ws + p.cond, ws + p.L[0].dray, h->nlevels > 1 ? ws + p.L[1].dray : nullptr, B, h->R, ws + p.L[0].cond_grad,
+                    h->nlevels > 1 ? ws + p.L[1].cond_grad : nullptr, stream);
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
-    launch_cond_wgrad(ws + p.cond, ws + L.dray, B, h->R, ws + L.cond_grad, stream);
     launch_cond_embed_grad(params, ws + L.dray, rays->appearance_ids, rays->camera_ids, B, h->V,
                            h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
                            d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->po[lv].rgbh_k, grad, stream);
@@ -1491,7 +1499,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   if (stats) {
     StatsArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.mse_sums = ws + p.mse; sa.B = B;
+    sa.mse_ray = ws + p.mse; sa.B = B; sa.nlevels = h->nlevels;
     if (bg_on) { sa.bg_sum = ws + p.bg_loss; sa.bgN = p.bgN; sa.bg_weight = bg->loss_weight; }
     if (el_on) {
       sa.el_sums = ws + p.el_sums; sa.el_rows = el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]; sa.el_jac_rows = p.rows[0];

@@ -379,10 +379,17 @@ void launch_sample_points(const float* origins, const float* dirs, const float* 
 void launch_composite_fwd(const float4* out4, const float* z, const float* dirs, int B, int S,
                           int white_bkgd, int sample_at_inf, float* rgb, float* depth,
                           float* med_depth, float* acc, float* weights, hipStream_t stream);
-void launch_composite_bwd(const float4* out4, const float* z, const float* dirs, int B, int S,
-                          int white_bkgd, int sample_at_inf, int sigma_act, const float* rgb_out,
-                          const float* target, const float* d_rgb, float loss_scale,
-                          float4* d_raw4, int rows_pad, float* mse_sum, float* dsig_ray, hipStream_t stream);
+struct CompositeBwdArgs {
+  const float4* out4; const float* z; const float* dirs;
+  int B, S, white_bkgd, sample_at_inf, sigma_act;
+  const float* rgb_out; const float* target; const float* d_rgb;   // target: MSE gradient; else d_rgb as given
+  float loss_scale;
+  float4* d_raw4; int rows_pad;
+  float* mse_ray;      // [B] squared error per ray (or nullptr)
+  float* dsig_ray;     // [B] sum of d sigma_raw over the ray (use_alpha_condition) or nullptr
+};
+struct CompositeBwdArgs2 { CompositeBwdArgs a[2]; };
+void launch_composite_bwd(const CompositeBwdArgs& a0, const CompositeBwdArgs* a1, hipStream_t stream);   // a1: second level or nullptr
 // use_alpha_condition: gradient of the appearance-code rows of the alpha head and of the codes through it
 void launch_alpha_cond_grad(const float* params, const float* cond, const float* dsig_ray, const int32_t* app_ids, int B, int R,
                             int V, int app_feat, int64_t app_off, int64_t alpha_k, float* grad, hipStream_t stream);
@@ -395,13 +402,13 @@ void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int N
 // training.compute_background_loss's draws (training.py:121-126) on the device: id = choices[floor(U n)], x += std N(0,1)
 void launch_background_draw(const float* points, int N, const int32_t* choices, int nchoices, float noise_std, uint64_t seed,
                             uint64_t offset, const nrf_dynamic_scalars* dyn, float* out_points, int32_t* out_ids, hipStream_t stream);
-void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst /*[R][128]*/,
-                       hipStream_t stream);
+void launch_cond_wgrad(const float* cond, const float* dray0, const float* dray1, int B, int R, float* dst0, float* dst1,
+                       hipStream_t stream);   // dray1 / dst1: the second level (nullptr: one level)
 void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
                             int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
                             float* grad, hipStream_t stream);
 struct StatsArgs {
-  const float* mse_sums; int B;
+  const float* mse_ray; int B, nlevels;    // [nlevels][B] squared error per ray
   const float* bg_sum; int bgN; float bg_weight;
   const float* el_sums; int el_rows, el_jac_rows; float el_weight;
   const float* wr_sums; float wr_weight;   // [4]: loss coarse, residual coarse, loss fine, residual fine

@@ -203,11 +203,20 @@ void launch_composite_fwd(const float4* out4, const float* z, const float* dirs,
 // With g_i = c_i . dL/drgb, t_i = 1-alpha_i+1e-10 and Q_i = sum_{k>i} g_k alpha_k prod_{i<j<k} t_j
 // (reverse affine recurrence Q_i = g_{i+1} alpha_{i+1} + t_{i+1} Q_{i+1}; division free):
 //   dL/dalpha_i = T_i (g_i - Q_i);  dL/dsigma_i = dist_i exp(-sigma_i dist_i) dL/dalpha_i;  dL/dc_i = w_i dL/drgb.
-__global__ __launch_bounds__(256) void composite_bwd_kernel(
-    const float4* __restrict__ out4, const float* __restrict__ z, const float* __restrict__ dirs, int B, int S,
-    int white_bkgd, int sample_at_inf, int sigma_act, const float* __restrict__ rgb_out,
-    const float* __restrict__ target, const float* __restrict__ d_rgb, float loss_scale,
-    float4* __restrict__ d_raw4, int rows_pad, float* __restrict__ mse_sum, float* __restrict__ dsig_ray) {
+__global__ __launch_bounds__(256) void composite_bwd_kernel(const CompositeBwdArgs2 P) {
+  const CompositeBwdArgs& A = P.a[blockIdx.y];   // blockIdx.y = level: both levels in one launch (kernarg-indexed, scalar loads)
+  const float4* __restrict__ out4 = A.out4;
+  const float* __restrict__ z = A.z;
+  const float* __restrict__ dirs = A.dirs;
+  const int B = A.B, S = A.S, white_bkgd = A.white_bkgd, sample_at_inf = A.sample_at_inf, sigma_act = A.sigma_act;
+  const float* __restrict__ rgb_out = A.rgb_out;
+  const float* __restrict__ target = A.target;
+  const float* __restrict__ d_rgb = A.d_rgb;
+  const float loss_scale = A.loss_scale;
+  float4* __restrict__ d_raw4 = A.d_raw4;
+  const int rows_pad = A.rows_pad;
+  float* __restrict__ mse_ray = A.mse_ray;
+  float* __restrict__ dsig_ray = A.dsig_ray;
   const int lane = threadIdx.x & 63;
   const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (blockIdx.x == 0) {   // zero the tile padding rows so they contribute nothing to any gradient
@@ -215,12 +224,15 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
   }
   if (ray >= B) return;
   float g0, g1, g2;
-  if (d_rgb) { g0 = d_rgb[3 * ray]; g1 = d_rgb[3 * ray + 1]; g2 = d_rgb[3 * ray + 2]; }
+  if (d_rgb) {
+    g0 = d_rgb[3 * ray]; g1 = d_rgb[3 * ray + 1]; g2 = d_rgb[3 * ray + 2];
+    if (lane == 0 && mse_ray) mse_ray[ray] = 0.f;
+  }
   else {
     const float e0 = rgb_out[3 * ray] - target[3 * ray], e1 = rgb_out[3 * ray + 1] - target[3 * ray + 1],
                 e2 = rgb_out[3 * ray + 2] - target[3 * ray + 2];
     g0 = loss_scale * e0; g1 = loss_scale * e1; g2 = loss_scale * e2;   // d mean((rgb-t)^2) (training.py:172)
-    if (lane == 0 && mse_sum) atomicAdd(mse_sum, e0 * e0 + e1 * e1 + e2 * e2);
+    if (lane == 0 && mse_ray) mse_ray[ray] = e0 * e0 + e1 * e1 + e2 * e2;   // summed in a fixed order by finish_stats_kernel
   }
   const float gsum = g0 + g1 + g2;
   const float dx = dirs[3 * ray], dy = dirs[3 * ray + 1], dz = dirs[3 * ray + 2];
@@ -294,11 +306,10 @@ __global__ __launch_bounds__(256) void composite_bwd_kernel(
   }
 }
 
-void launch_composite_bwd(const float4* out4, const float* z, const float* dirs, int B, int S, int white_bkgd,
-                          int sample_at_inf, int sigma_act, const float* rgb_out, const float* target, const float* d_rgb,
-                          float loss_scale, float4* d_raw4, int rows_pad, float* mse_sum, float* dsig_ray, hipStream_t stream) {
-  hipLaunchKernelGGL(composite_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, out4, z, dirs, B, S, white_bkgd,
-                     sample_at_inf, sigma_act, rgb_out, target, d_rgb, loss_scale, d_raw4, rows_pad, mse_sum, dsig_ray);
+void launch_composite_bwd(const CompositeBwdArgs& a0, const CompositeBwdArgs* a1, hipStream_t stream) {
+  CompositeBwdArgs2 p;
+  p.a[0] = a0; p.a[1] = a1 ? *a1 : a0;
+  hipLaunchKernelGGL(composite_bwd_kernel, dim3((a0.B + 3) / 4, a1 ? 2 : 1), dim3(256), 0, stream, p);
 }
 
 // ------------------------------------------------------------------ hierarchical sampling
@@ -411,9 +422,12 @@ void launch_sample_fine(const float* z_c, const float* w_c, int B, int Nc, int N
 // ------------------------------------------------------------------ small gradient pieces
 // dW_rgbh[256+c][n] = sum_ray cond[ray][c] * dray[ray][n].  One block per condition column c:
 // 8 ray groups x 128 outputs, 4 independent accumulators per thread, LDS tree over the groups.
-__global__ __launch_bounds__(1024) void cond_wgrad_kernel(const float* __restrict__ cond, const float* __restrict__ dray,
-                                                          int B, int R, float* __restrict__ dst) {
+__global__ __launch_bounds__(1024) void cond_wgrad_kernel(const float* __restrict__ cond, const float* __restrict__ dray0,
+                                                          const float* __restrict__ dray1, int B, int R,
+                                                          float* __restrict__ dst0, float* __restrict__ dst1) {
   __shared__ float red[8][RGB_W];
+  const float* __restrict__ dray = blockIdx.y ? dray1 : dray0;   // blockIdx.y = level: both levels in one launch
+  float* __restrict__ dst = blockIdx.y ? dst1 : dst0;
   const int c = blockIdx.x, n = threadIdx.x & 127, g = threadIdx.x >> 7;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   int ray = g;
@@ -434,30 +448,30 @@ __global__ __launch_bounds__(1024) void cond_wgrad_kernel(const float* __restric
   }
 }
 
-void launch_cond_wgrad(const float* cond, const float* dray, int B, int R, float* dst, hipStream_t stream) {
-  if (R > 0) hipLaunchKernelGGL(cond_wgrad_kernel, dim3(R), dim3(1024), 0, stream, cond, dray, B, R, dst);
+void launch_cond_wgrad(const float* cond, const float* dray0, const float* dray1, int B, int R, float* dst0, float* dst1,
+                       hipStream_t stream) {
+  if (R > 0)
+    hipLaunchKernelGGL(cond_wgrad_kernel, dim3(R, dray1 ? 2 : 1), dim3(1024), 0, stream, cond, dray0, dray1, B, R, dst0, dst1);
 }
 
 // dL/d(GLO code) of the rgb-branch conditions -> scatter-add into the embedding-table gradients
-// (transpose of the nn.Embed gathers of models.py:197-214).  One block per ray:
-// d cond[c] = sum_n dray[ray][n] * W_rgbh[256 + V + c][n].
-__global__ __launch_bounds__(128) void cond_embed_grad_kernel(
+// (transpose of the nn.Embed gathers of models.py:197-214).  One WAVE per ray (lane holds dray[n], n = lane and lane + 64):
+// d cond[c] = sum_n dray[ray][n] * W_rgbh[256 + V + c][n], one shuffle reduction + one atomic per code entry, no barrier.
+__global__ __launch_bounds__(256) void cond_embed_grad_kernel(
     const float* __restrict__ params, const float* __restrict__ dray, const int32_t* __restrict__ app_ids,
-    const int32_t* __restrict__ cam_ids, int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
+    const int32_t* __restrict__ cam_ids, int B, int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
     int64_t rgbh_k, float* __restrict__ grad) {
-  __shared__ float red[2];
-  const int ray = blockIdx.x, t = threadIdx.x;
-  const float d = dray[(size_t)ray * RGB_W + t];
+  const int lane = threadIdx.x & 63;
+  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ray >= B) return;
+  const float d0 = dray[(size_t)ray * RGB_W + lane], d1 = dray[(size_t)ray * RGB_W + 64 + lane];
+  const float* __restrict__ w = params + rgbh_k + (int64_t)(TRUNK_W + V) * RGB_W;
   for (int c = 0; c < app_feat + cam_feat; ++c) {
-    const float s = wave_sum(d * params[rgbh_k + (int64_t)(TRUNK_W + V + c) * RGB_W + t]);
-    if ((t & 63) == 0) red[t >> 6] = s;
-    __syncthreads();
-    if (t == 0) {
-      const float tot = red[0] + red[1];
+    const float tot = wave_sum(fmaf(d0, w[(int64_t)c * RGB_W + lane], d1 * w[(int64_t)c * RGB_W + 64 + lane]));
+    if (lane == 0) {
       if (c < app_feat) atomicAdd(grad + app_off + (int64_t)app_ids[ray] * app_feat + c, tot);
       else atomicAdd(grad + cam_off + (int64_t)cam_ids[ray] * cam_feat + (c - app_feat), tot);
     }
-    __syncthreads();
   }
 }
 
@@ -465,8 +479,8 @@ void launch_cond_embed_grad(const float* params, const float* dray, const int32_
                             int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
                             float* grad, hipStream_t stream) {
   if (app_feat + cam_feat > 0)
-    hipLaunchKernelGGL(cond_embed_grad_kernel, dim3(B), dim3(128), 0, stream, params, dray, app_ids, cam_ids, V, app_feat,
-                       app_off, cam_feat, cam_off, rgbh_k, grad);
+    hipLaunchKernelGGL(cond_embed_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, params, dray, app_ids, cam_ids, B, V,
+                       app_feat, app_off, cam_feat, cam_off, rgbh_k, grad);
 }
 
 // use_alpha_condition: the alpha head is Dense([bottleneck, appearance code] -> 1) (modules.py:152-157).  Its
@@ -499,11 +513,19 @@ void launch_alpha_cond_grad(const float* params, const float* cond, const float*
                        app_feat, app_off, alpha_k, grad);
 }
 
-__global__ void finish_stats_kernel(const StatsArgs A) {
+__global__ __launch_bounds__(64) void finish_stats_kernel(const StatsArgs A) {
+  // per-ray squared errors of the two levels (composite_bwd_kernel) -> their sums, in a fixed order (no atomics: two runs of
+  // the same step report the same loss bits)
+  float sc = 0.f, sf = 0.f;
+  for (int r = threadIdx.x; r < A.B; r += 64) {
+    sc += A.mse_ray[r];
+    if (A.nlevels > 1) sf += A.mse_ray[A.B + r];
+  }
+  sc = wave_sum(sc); sf = wave_sum(sf);
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float* stats = A.stats;
     const float B = (float)A.B;
-    const float mc = A.mse_sums[0] / (3.f * B), mf = A.mse_sums[1] / (3.f * B);
+    const float mc = sc / (3.f * B), mf = sf / (3.f * B);
     const float bgl = A.bg_sum ? A.bg_sum[0] / (float)A.bgN : 0.f;
     const float ell = A.el_sums ? A.el_sums[0] / B : 0.f;          // sum over samples, mean over rays (training.py:194)
     const float wrc = A.wr_sums ? A.wr_sums[0] / B : 0.f, wrf = A.wr_sums ? A.wr_sums[2] / B : 0.f;

@@ -178,6 +178,8 @@ class CfgEval(Cfg):
 
 
 # training workloads: rays per GPU, model config, regularisers, warp alpha, the gin shape they stand for
+NUM_FRAMES = 256   # frames of the synthetic capture: warp / appearance ids per frame
+
 TRAIN_MODES = {
     'train': dict(rays=RAYS_PER_GPU, cfg=Cfg, reg=False, alpha=0.0, metric='train rays/sec (192 samples/ray)',
                   workload='gpu_quarterhd.gin shape: {rays} rays/GPU x (64+128) samples, F_p=8, warp off, stratified, '
@@ -409,18 +411,23 @@ def main():
   bf16 = bf16 or bool(M.get('force_bf16'))
   cfg = M['cfg']
   rays_per_gpu = args.rays_per_gpu or M['rays']
-  model, fp = models.construct_nerf(0, cfg, rays_per_gpu, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
+  # metadata ids as a capture has them: one warp / appearance id per FRAME (a vrig capture has a few hundred frames and a batch
+  # draws rays uniformly over all of them), two camera ids (left / right rig camera).  Rounds 1-2 drew the ids from 4 frames,
+  # which turns the embedding-table gradient into ~800 same-address atomics per table row and step -- an artefact of the
+  # synthetic batch, not of the workload.
+  frames = list(range(NUM_FRAMES))
+  model, fp = models.construct_nerf(0, cfg, rays_per_gpu, frames, [0, 1], frames, 0.0206, 0.826, device=dev)
   state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=M['alpha'])
   batch = synthetic_batch(rays_per_gpu, seed=100 + rank, device=dev)   # each rank: its own ray shard
   kw = {}
   if M['reg']:
     sp = training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.0, elastic_loss_weight=M['elastic_w'])
     g = torch.Generator().manual_seed(rank)
-    md = {'warp': torch.randint(0, 4, (rays_per_gpu, 1), generator=g).to(dev)}
+    md = {'warp': torch.randint(0, NUM_FRAMES, (rays_per_gpu, 1), generator=g).to(dev)}
     if getattr(cfg, 'use_camera_metadata', False):
       md['camera'] = torch.randint(0, 2, (rays_per_gpu, 1), generator=g).to(dev)
     if getattr(cfg, 'use_appearance_metadata', False):
-      md['appearance'] = torch.randint(0, 4, (rays_per_gpu, 1), generator=g).to(dev)
+      md['appearance'] = torch.randint(0, NUM_FRAMES, (rays_per_gpu, 1), generator=g).to(dev)
     batch['metadata'] = md
     # train.py:186-197: min(len(points), n_dev * 16384) points per step, sharded -> 16384 per device
     batch['background_points'] = ((torch.rand(16384, 3, generator=g) - 0.5) * 0.8).to(dev)
@@ -509,7 +516,8 @@ def main():
         'dtype': ('bf16 NeRF MLPs + f32 warp field' if mixed else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': M['workload'].format(rays=rays_per_gpu) + (BF16_NOTE if bf16 else '') +
                                (' [whole step replayed from one hipGraph]' if args.graph else ''),
-                   'rays_per_gpu': rays_per_gpu, 'global_batch': world * rays_per_gpu, 'parallelism': f'ray-shard dp{world}'},
+                   'rays_per_gpu': rays_per_gpu, 'global_batch': world * rays_per_gpu, 'parallelism': f'ray-shard dp{world}',
+                   'metadata_frames': NUM_FRAMES if M['reg'] else None},
         'roofline': roofline,
         'step_tflops': step_flops / (ms_per_step * 1e-3) / 1e12,
         ('step_frac_of_bf16_mfma_peak' if step_peak == PEAK_BF16_MFMA_TFLOPS else 'step_frac_of_fp32_mfma_peak'):

@@ -179,6 +179,34 @@ __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* 
   for (int q = 1; q < nquads; ++q) quad();
 }
 
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Narrow heads (N <= 32 output columns) on the MFMA pipe with K split over the workgroup's waves: this wave's slice
+// C[rb][64 rows x 32 cols] = A[:, k_lo : k_lo + 32] * B, A from the swizzled LDS tile, B[k][n] = bfn(k) evaluated per lane
+// (lane = column n = lane & 31, k parity lane >> 5).  16 k-steps x 2 row blocks = 32 MFMAs per wave; the caller sums the
+// four waves' partials through LDS.  (VALU dot products for these heads were 12-15 % of an SE3 tile: VALU phases stretch
+// 3-6x while the co-resident workgroups stream MFMAs.)
+template <class BF>
+__device__ __forceinline__ void mfma_kslice32(f32x16 (&acc)[2], const float* act, int k_lo, int lane, BF bfn) {
+  const int i = lane & 31, kk = lane >> 5;
+  float b[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) b[s] = bfn(k_lo + 2 * s + kk);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    const int k = k_lo + 2 * s + kk;
+    const float2 a = *reinterpret_cast<const float2*>(act + act_addr(k, i >> 1) + 2 * (i & 1));
+    acc[0] = mfma32(a.x, b[s], acc[0]);
+    acc[1] = mfma32(a.y, b[s], acc[1]);
+  }
+}
+
 // Tile hand-out.  counter == nullptr (default): static round-robin split.  Otherwise workgroups pull 64-row
 // tiles from a global counter (zeroed by the host before the launch; `slot` is one free LDS word at the tile
 // boundary).  Two workgroups share a CU and the older one wins the MFMA arbitration, so with the static split it

@@ -262,29 +262,22 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
 
     // ---- heads: w = Dense(128->3)(h), v = Dense(128->3)(h)  (warping.py:271-288, 328-329) ----
     {
-      // [128][3] each: this part's 32 k = 96 consecutive floats per head, in chunks of 16 k (wave-uniform loads)
-      const float4* __restrict__ ww4 = reinterpret_cast<const float4*>(prm + A.po.w_k) + part * 24;
-      const float4* __restrict__ wv4 = reinterpret_cast<const float4*>(prm + A.po.v_k) + part * 24;
-      float s[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      const int k0 = part * 32;
-#pragma unroll 1
-      for (int kc = 0; kc < 2; ++kc) {
-        float4 a4[12], b4[12];
+      // on the MFMA pipe, K split over the four waves (mfma_kslice32): columns 0..2 = w, 3..5 = v; [128][3] leaves, element
+      // (k, c) at 3k + c.  Lanes n < 6 hold this wave's partial sums of column n -> scratch [wave][column][row].
+      float s[6];
+      {
+        const int n = lane & 31, hh = lane >> 5;
+        const float* __restrict__ wsrc = prm + (n < 3 ? A.po.w_k + n : A.po.v_k + (n < 6 ? n - 3 : 0));
+        f32x16 hacc[2];
+        mfma_kslice32(hacc, act, 32 * part, lane, [&](int k) { return n < 6 ? wsrc[3 * k] : 0.f; });
+        if (n < 6) {
 #pragma unroll
-        for (int i = 0; i < 12; ++i) { a4[i] = ww4[12 * kc + i]; b4[i] = wv4[12 * kc + i]; }
-        const float* wf = reinterpret_cast<const float*>(a4);
-        const float* vf = reinterpret_cast<const float*>(b4);
-        float a[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = act[act_elem(k0 + 16 * kc + i, p)];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) { s[c] = fmaf(a[i], wf[3 * i + c], s[c]); s[3 + c] = fmaf(a[i], vf[3 * i + c], s[3 + c]); }
+          for (int reg = 0; reg < 16; ++reg) {
+            const int r0 = 2 * c_row(reg, hh);
+            *reinterpret_cast<float2*>(win + (6 * part + n) * TILE_ROWS + r0) = make_float2(hacc[0][reg], hacc[1][reg]);
+          }
         }
       }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) win[(6 * part + c) * TILE_ROWS + p] = s[c];
       __syncthreads();
       WSTAMP();   // heads
       if (part == 0 && TANGENT) {
@@ -356,6 +349,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
   float* dwv = smem + WACT_FLOATS;         // [8][64]: dL/dw (0..2), dL/dv (3..5) of the tile rows
   float* dcs = dwv + 8 * TILE_ROWS;        // [8][64]: dL/dcode of the tile rows
   int* ids_s = reinterpret_cast<int*>(dcs + 8 * TILE_ROWS);   // [64]: warp id of the tile rows (-1: padding)
+  float* cgp = dcs + 9 * TILE_ROWS;        // [4 waves][8 codes][64]: K-slice partials of the GLO-code gradient
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));       // opaque per tile (see warp_fwd_tile)
   const int lane = tid & 63;
@@ -437,26 +431,31 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
     // input (l = 4 via the skip rows, l = 0), K = 128 on the VALU; thread = (row p, codes 2*part, 2*part+1).
     float dcode[2] = {0.f, 0.f};
     auto code_grad = [&](int64_t krow_off) {
-      const int g0 = 2 * part;
-      // the two weight rows of this thread's codes, 16 k at a time (wave-uniform loads, no per-k scalar waits)
-      const float4* __restrict__ r0 = reinterpret_cast<const float4*>(prm + krow_off + (int64_t)min(g0, A.G - 1) * WARP_W);
-      const float4* __restrict__ r1 = reinterpret_cast<const float4*>(prm + krow_off + (int64_t)min(g0 + 1, A.G - 1) * WARP_W);
-      float d0 = 0.f, d1 = 0.f;
-#pragma unroll 1
-      for (int kc = 0; kc < WARP_W / 16; ++kc) {
-        float4 w0[4], w1[4];
+      // on the MFMA pipe, K split over the four waves (mfma_kslice32): B[k][g] = W_l[row_base + g][k]; lanes n < 8 hold this
+      // wave's partial of code n -> cgp[wave][code][row]; thread (p, part) then sums its two codes over the four partials
+      {
+        int lo = lane;
+        asm volatile("" : "+v"(lo));   // section-local lane constants
+        const int nn = lo & 31, hh = lo >> 5;
+        const float* __restrict__ wsrc = prm + krow_off + (int64_t)min(nn, A.G - 1) * WARP_W;
+        f32x16 cacc[2];
+        mfma_kslice32(cacc, act, 32 * wave, lo, [&](int k) { return nn < A.G ? wsrc[k] : 0.f; });
+        if (nn < 8) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { w0[i] = r0[4 * kc + i]; w1[i] = r1[4 * kc + i]; }
-        const float* f0 = reinterpret_cast<const float*>(w0);
-        const float* f1 = reinterpret_cast<const float*>(w1);
-        float a[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) a[i] = act[act_elem(16 * kc + i, p)];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { d0 = fmaf(a[i], f0[i], d0); d1 = fmaf(a[i], f1[i], d1); }
+          for (int reg = 0; reg < 16; ++reg) {
+            const int r0 = 2 * c_row(reg, hh);
+            *reinterpret_cast<float2*>(cgp + (wave * 8 + nn) * TILE_ROWS + r0) = make_float2(cacc[0][reg], cacc[1][reg]);
+          }
+        }
       }
-      if (g0 < A.G) dcode[0] += d0;
-      if (g0 + 1 < A.G) dcode[1] += d1;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int g = 2 * part + q;
+        if (g < A.G)
+          dcode[q] += (cgp[(0 * 8 + g) * TILE_ROWS + p] + cgp[(1 * 8 + g) * TILE_ROWS + p]) +
+                      (cgp[(2 * 8 + g) * TILE_ROWS + p] + cgp[(3 * 8 + g) * TILE_ROWS + p]);
+      }
     };
 
     // ---- l = 5..1: d h_l = dpre_l . W_l[0:128]^T ; mask h_l > 0 -> dpre_{l-1} ----
@@ -505,8 +504,19 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       if (grow < A.rows) id = A.point_ids ? A.point_ids[grow] : A.warp_ids ? A.warp_ids[grow / A.S] : grow / A.S;
       ids_s[tid] = id;
     }
-    __syncthreads();
-    {
+    // all valid rows of the tile share one id (a ray has >= 64 samples: the usual case for the sample levels): two codes per
+    // wave, one shuffle reduction + one atomic each
+    const int id0 = ids_s[0] < 0 ? -1 : ids_s[0];
+    if (__syncthreads_and(ids_s[lane] == id0 || ids_s[lane] < 0)) {
+      if (id0 >= 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int g = 2 * wave + q;
+          const float sm = wave_sum_f(ids_s[lane] >= 0 && g < A.G ? dcs[(g < 8 ? g : 0) * TILE_ROWS + lane] : 0.f);
+          if (lane == 0 && g < A.G && sm != 0.f) atomicAdd(A.grad_embed + (size_t)id0 * A.G + g, sm);
+        }
+      }
+    } else {
       const int g = tid & 7;
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
@@ -578,7 +588,7 @@ __global__ __launch_bounds__(256, NRF_WARP_WAVES) void se3_warp_bwd_kernel(const
 }
 
 void launch_warp_bwd(const WarpBwdArgs& a, const WarpBwdArgs* a1, const WarpBwdArgs* a2, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)(WACT_FLOATS + 17 * TILE_ROWS) * sizeof(float);
+  const size_t lds = (size_t)(WACT_FLOATS + (17 + 32) * TILE_ROWS) * sizeof(float);
   WarpBwdArgs3 p;
   p.a[0] = a; p.a[1] = a1 ? *a1 : a; p.a[2] = a2 ? *a2 : a;
   p.n0 = a.ntiles; p.n01 = p.n0 + (a1 ? a1->ntiles : 0); p.ntot = p.n01 + (a2 ? a2->ntiles : 0);

@@ -100,7 +100,11 @@ struct Prof {
   std::vector<ProfSlot> slots;   // events recorded and not yet read
   size_t next = 0;
   std::vector<ProfAcc> acc;
+  // NRF_TRACE_REGIONS=1 (debugging aid): name every region on stderr and synchronise the stream behind it, so that a device
+  // fault is attributed to the kernel group that raised it
+  static bool trace() { static const bool t = getenv("NRF_TRACE_REGIONS") != nullptr; return t; }
   void begin(const char* name, double flops, hipStream_t st) {
+    if (trace()) { fprintf(stderr, "[nrf] %s ...", name); fflush(stderr); }
     if (!on) return;
     if (next == slots.size()) { slots.emplace_back(); (void)hipEventCreate(&slots.back().a); (void)hipEventCreate(&slots.back().b); }
     ProfSlot& s = slots[next];
@@ -108,6 +112,7 @@ struct Prof {
     (void)hipEventRecord(s.a, st);
   }
   void end(hipStream_t st) {
+    if (trace()) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr); }
     if (!on) return;
     (void)hipEventRecord(slots[next].b, st);
     ++next;

@@ -504,6 +504,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       if (grow < A.rows) id = A.point_ids ? A.point_ids[grow] : A.warp_ids ? A.warp_ids[grow / A.S] : grow / A.S;
       ids_s[tid] = id;
     }
+    __syncthreads();
     // all valid rows of the tile share one id (a ray has >= 64 samples: the usual case for the sample levels): two codes per
     // wave, one shuffle reduction + one atomic each
     const int id0 = ids_s[0] < 0 ? -1 : ids_s[0];

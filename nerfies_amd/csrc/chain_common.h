@@ -126,11 +126,18 @@ __device__ __forceinline__ void mfma_half(f32x16 (&acc)[2][NCB], const float2 (&
   }
 }
 
+// Experiment knob (-DNRF_KLOOP_PRIO=1, scripts/build_variant.py): wave priority 0 inside the K loops, 2 everywhere else, so that a
+// wave in a short VALU / LDS / barrier phase is not starved by the co-resident workgroups' MFMA streams.
+#ifndef NRF_KLOOP_PRIO
+#define NRF_KLOOP_PRIO 0
+#endif
+
 template <int NCB, bool SWZ>
 __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* lds_in, int nquads,
                                             const float4* __restrict__ wp, int lane, const WQuad<NCB>& first) {
   constexpr int NB = NCB == 2 ? 4 : 2;
   constexpr int QUAD_FLOATS = 16 * TILE_ROWS;
+  if (NRF_KLOOP_PRIO) __builtin_amdgcn_s_setprio(0);
   const int i = lane & 31, kk = lane >> 5;
   int off[8];   // per-lane float offsets of the quad's 8 A reads (k = 2t + kk)
 #pragma unroll
@@ -177,6 +184,7 @@ __device__ __forceinline__ void mfma_k_loop(f32x16 (&acc)[2][NCB], const float* 
   if (nquads > 0) quad();
 #pragma unroll 2
   for (int q = 1; q < nquads; ++q) quad();
+  if (NRF_KLOOP_PRIO) __builtin_amdgcn_s_setprio(2);
 }
 
 __device__ __forceinline__ float wave_sum_f(float v) {

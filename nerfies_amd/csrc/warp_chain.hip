@@ -243,7 +243,7 @@ __device__ __forceinline__ void warp_fwd_tile(const WarpFwdArgs& A, const int ti
           mfma_k_loop<1, false>(acc, win, nq_in, w4b, lane, prefetch_quad<1>(w4b, lane));
         }
       }
-      WSTAMP();   // layer l: K loop
+          WSTAMP();   // layer l: K loop
       wnext = prefetch_quad<1>(wpk4 + (A.pk.fwd_L[l + 1 < WARP_DEPTH ? l + 1 : l] / 4) + wave * 16 * 64, lane);
       if (!TANGENT) bnext = bias_load<1>(prm + A.po.trunk_b[l + 1 < WARP_DEPTH ? l + 1 : l], wave * 32, lane);   // before the stash stores
       __builtin_amdgcn_sched_barrier(0);
@@ -398,28 +398,29 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
     __syncthreads();
     WSTAMP();   // exp_se3 VJP
 
-    // ---- heads^T (6 -> 128) on the VALU, ReLU mask of trunk layer 5 -> dpre_5 ----
+    // ---- heads^T (6 -> 128): d h5 = [dw | dv] . [Ww | Wv]^T as 4 MFMA k-steps (K = 6 padded to 8), ReLU mask of trunk
+    //      layer 5 -> dpre_5 through the same epilogue as the trunk steps ----
     {
-      float wh[6];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { wh[c] = prm[A.po.w_k + 3 * n + c]; wh[3 + c] = prm[A.po.v_k + 3 * n + c]; }
       const uint32_t mb = A.bits[(((size_t)(WARP_DEPTH - 1) * A.nt_prim + tprim) * 4 + wave) * 64 + lane];
       const __amdgpu_buffer_rsrc_t dy =
           make_rsrc(A.dy + (size_t)(WARP_DEPTH - 1) * layer_fl + (size_t)tile * FRAG_TILE_128, FRAG_TILE_128 * 4);
+      f32x16 hacc[2][1];
+      zero_acc<1>(hacc);
+#pragma unroll
+      for (int sk = 0; sk < 3; ++sk) {   // k = 2 sk + h < 6
+        const int k = 2 * sk + h;
+        const float b = prm[(k < 3 ? A.po.w_k + k : A.po.v_k + (k - 3)) + 3 * n];      // [128][3] leaves: element (n, c) at 3n + c
+        const float2 a = *reinterpret_cast<const float2*>(dwv + k * TILE_ROWS + 2 * j);   // tile rows 2j, 2j+1 of component k
+        hacc[0][0] = mfma32(a.x, b, hacc[0][0]);
+        hacc[1][0] = mfma32(a.y, b, hacc[1][0]);
+      }
       float bsum = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int g = q_granule(q, h);
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-          const float4 d = *reinterpret_cast<const float4*>(dwv + c * TILE_ROWS + 4 * g);
-          v4.x = fmaf(d.x, wh[c], v4.x); v4.y = fmaf(d.y, wh[c], v4.y);
-          v4.z = fmaf(d.z, wh[c], v4.z); v4.w = fmaf(d.w, wh[c], v4.w);
-        }
+        float4 v4 = acc_piece<1>(hacc, 0, q);
         v4 = mask4(v4, (mb >> (4 * q)) & 15u);
         bsum += (v4.x + v4.y) + (v4.z + v4.w);
-        *reinterpret_cast<float4*>(act + act_addr(n, g)) = v4;
+        *reinterpret_cast<float4*>(act + act_addr(n, q_granule(q, h))) = v4;
         buf_store4(v4, dy, lane * 16, (wave * 8 + q) * 1024);
       }
       db[WARP_DEPTH - 1] += bsum;
@@ -429,32 +430,24 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
 
     // GLO-code gradient: d code[g] = dpre_l . W_l[row_base + g][:]^T for the two layers that see the
     // input (l = 4 via the skip rows, l = 0), K = 128 on the VALU; thread = (row p, codes 2*part, 2*part+1).
-    float dcode[2] = {0.f, 0.f};
-    auto code_grad = [&](int64_t krow_off) {
+    auto code_grad = [&](int64_t krow_off, bool first) {
       // on the MFMA pipe, K split over the four waves (mfma_kslice32): B[k][g] = W_l[row_base + g][k]; lanes n < 8 hold this
-      // wave's partial of code n -> cgp[wave][code][row]; thread (p, part) then sums its two codes over the four partials
-      {
-        int lo = lane;
-        asm volatile("" : "+v"(lo));   // section-local lane constants
-        const int nn = lo & 31, hh = lo >> 5;
-        const float* __restrict__ wsrc = prm + krow_off + (int64_t)min(nn, A.G - 1) * WARP_W;
-        f32x16 cacc[2];
-        mfma_kslice32(cacc, act, 32 * wave, lo, [&](int k) { return nn < A.G ? wsrc[k] : 0.f; });
-        if (nn < 8) {
+      // wave's partial of code n and keep it in their own LDS slot cgp[wave][code][row] (the layer-0 call adds onto the
+      // layer-4 call's values: same lanes, same slot, no barrier); the four partials are summed once, in the scatter below
+      int lo = lane;
+      asm volatile("" : "+v"(lo));   // section-local lane constants
+      const int nn = lo & 31, hh = lo >> 5;
+      const float* __restrict__ wsrc = prm + krow_off + (int64_t)min(nn, A.G - 1) * WARP_W;
+      f32x16 cacc[2];
+      mfma_kslice32(cacc, act, 32 * wave, lo, [&](int k) { return nn < A.G ? wsrc[k] : 0.f; });
+      if (nn < 8) {
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int r0 = 2 * c_row(reg, hh);
-            *reinterpret_cast<float2*>(cgp + (wave * 8 + nn) * TILE_ROWS + r0) = make_float2(cacc[0][reg], cacc[1][reg]);
-          }
+        for (int reg = 0; reg < 16; ++reg) {
+          float2* slot = reinterpret_cast<float2*>(cgp + (wave * 8 + nn) * TILE_ROWS + 2 * c_row(reg, hh));
+          float2 v = make_float2(cacc[0][reg], cacc[1][reg]);
+          if (!first) { const float2 o = *slot; v.x += o.x; v.y += o.y; }
+          *slot = v;
         }
-      }
-      __syncthreads();
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int g = 2 * part + q;
-        if (g < A.G)
-          dcode[q] += (cgp[(0 * 8 + g) * TILE_ROWS + p] + cgp[(1 * 8 + g) * TILE_ROWS + p]) +
-                      (cgp[(2 * 8 + g) * TILE_ROWS + p] + cgp[(3 * 8 + g) * TILE_ROWS + p]);
       }
     };
 
@@ -463,11 +456,11 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
     WQuad<1> wnext = prefetch_quad<1>(wpk4 + (A.pk.bwd_LT[WARP_DEPTH - 1] / 4) + wave * 16 * 64, lane);
 #pragma unroll 1
     for (int l = WARP_DEPTH - 1; l >= 1; --l) {
-      if (!TANGENT && l == WARP_SKIP) { code_grad(A.po.trunk_k[WARP_SKIP] + (int64_t)(WARP_W + 3 + 6 * A.F) * WARP_W); WSTAMP(); }
+      if (!TANGENT && l == WARP_SKIP) { code_grad(A.po.trunk_k[WARP_SKIP] + (int64_t)(WARP_W + 3 + 6 * A.F) * WARP_W, true); WSTAMP(); }
       const uint32_t mb = A.bits[(((size_t)(l - 1) * A.nt_prim + tprim) * 4 + wave) * 64 + lane];
       zero_acc<1>(acc);
       mfma_k_loop<1, true>(acc, act, 8, wpk4 + (A.pk.bwd_LT[l] / 4) + wave * 16 * 64, lane, wnext);
-      WSTAMP();   // step l: K loop
+          WSTAMP();   // step l: K loop
       wnext = prefetch_quad<1>(wpk4 + (A.pk.bwd_LT[l > 1 ? l - 1 : 1] / 4) + wave * 16 * 64, lane);
       __builtin_amdgcn_sched_barrier(0);
       const __amdgpu_buffer_rsrc_t dy = make_rsrc(A.dy + (size_t)(l - 1) * layer_fl + (size_t)tile * FRAG_TILE_128, FRAG_TILE_128 * 4);
@@ -488,7 +481,7 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
       WSTAMP();   // step l: epilogue
     }
     if (TANGENT) return;
-    code_grad(A.po.trunk_k[0] + (int64_t)(3 + 6 * A.F) * WARP_W);
+    code_grad(A.po.trunk_k[0] + (int64_t)(3 + 6 * A.F) * WARP_W, false);
     WSTAMP();   // code gradient (layer 0 rows)
 
     // ---- sums of d code over the rows of the tile that share a warp id -> scatter-add into the embedding-table
@@ -496,40 +489,52 @@ __device__ __forceinline__ void warp_bwd_tile(const WarpBwdArgs& A, const int ti
     //      (training.py:121-123), where summing runs of equal ids sent 64 x G atomics per tile to a table of a few rows
     //      (same-address device atomics serialise at ~12 ns: round 2's warp_dgrad_bg spent more time there than in its
     //      MFMAs).  Thread (g, q): if row q is the first of the tile with its id, it owns that id's sum. ----
-#pragma unroll
-    for (int q = 0; q < 2; ++q) dcs[(2 * part + q) * TILE_ROWS + p] = dcode[q];
-    if (tid < TILE_ROWS) {
-      const int grow = tile * TILE_ROWS + tid;
-      int id = -1;
+    // every wave looks at the ids of all 64 rows (lane = row): the waves agree on the path without a barrier
+    int id;
+    {
+      const int grow = tile * TILE_ROWS + lane;
+      id = -1;
       if (grow < A.rows) id = A.point_ids ? A.point_ids[grow] : A.warp_ids ? A.warp_ids[grow / A.S] : grow / A.S;
-      ids_s[tid] = id;
     }
-    __syncthreads();
-    // all valid rows of the tile share one id (a ray has >= 64 samples: the usual case for the sample levels): two codes per
-    // wave, one shuffle reduction + one atomic each
-    const int id0 = ids_s[0] < 0 ? -1 : ids_s[0];
-    if (__syncthreads_and(ids_s[lane] == id0 || ids_s[lane] < 0)) {
-      if (id0 >= 0) {
+    const int id0 = __shfl(id, 0);   // row 0 of a tile is never padding
+    const bool one_id = __all(id == id0 || id < 0);
+    __syncthreads();   // cgp complete
+    if (one_id) {
+      // all valid rows share one id (a ray has >= 64 samples: the sample levels): wave w owns codes 2w, 2w+1 -- sum of the four
+      // K-slice partials per row, one shuffle reduction over the rows, one atomic
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const int g = 2 * wave + q;
-          const float sm = wave_sum_f(ids_s[lane] >= 0 && g < A.G ? dcs[(g < 8 ? g : 0) * TILE_ROWS + lane] : 0.f);
-          if (lane == 0 && g < A.G && sm != 0.f) atomicAdd(A.grad_embed + (size_t)id0 * A.G + g, sm);
-        }
+      for (int q = 0; q < 2; ++q) {
+        const int g = 2 * wave + q;
+        float v = 0.f;
+        if (id >= 0 && g < A.G)
+          v = (cgp[(0 * 8 + g) * TILE_ROWS + lane] + cgp[(1 * 8 + g) * TILE_ROWS + lane]) +
+              (cgp[(2 * 8 + g) * TILE_ROWS + lane] + cgp[(3 * 8 + g) * TILE_ROWS + lane]);
+        const float sm = wave_sum_f(v);
+        if (lane == 0 && g < A.G && sm != 0.f) atomicAdd(A.grad_embed + (size_t)id0 * A.G + g, sm);
       }
     } else {
+      // per-point ids (the background batch): thread (g, q) -- if row q is the first of the tile with its id, it owns that
+      // id's sum
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int g = 2 * part + q;
+        dcs[g * TILE_ROWS + p] = (cgp[(0 * 8 + g) * TILE_ROWS + p] + cgp[(1 * 8 + g) * TILE_ROWS + p]) +
+                                 (cgp[(2 * 8 + g) * TILE_ROWS + p] + cgp[(3 * 8 + g) * TILE_ROWS + p]);
+      }
+      if (wave == 0) ids_s[lane] = id;
+      __syncthreads();
       const int g = tid & 7;
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
         const int q = (tid >> 3) + 32 * half;
-        const int id = ids_s[q];
-        if (g < A.G && id >= 0) {
+        const int idq = ids_s[q];
+        if (g < A.G && idq >= 0) {
           bool leader = true;
-          for (int e = 0; e < q; ++e) leader = leader && ids_s[e] != id;
+          for (int e = 0; e < q; ++e) leader = leader && ids_s[e] != idq;
           if (leader) {
             float sm = 0.f;
-            for (int e = q; e < TILE_ROWS; ++e) sm += ids_s[e] == id ? dcs[g * TILE_ROWS + e] : 0.f;
-            if (sm != 0.f) atomicAdd(A.grad_embed + (size_t)id * A.G + g, sm);
+            for (int e = q; e < TILE_ROWS; ++e) sm += ids_s[e] == idq ? dcs[g * TILE_ROWS + e] : 0.f;
+            if (sm != 0.f) atomicAdd(A.grad_embed + (size_t)idq * A.G + g, sm);
           }
         }
       }

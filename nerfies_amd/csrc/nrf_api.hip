@@ -719,8 +719,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   p.counters = take(64);
   p.timeline = take(2 * (2 * 4 * 64 + 1024 + 4 * 4096));
 
-  // ---- pack descriptors (both levels, forward and transposed streams) ----
-  for (int lv = 0; lv < h->nlevels; ++lv) {
+  // ---- pack descriptors (both levels, forward and transposed streams); a bf16 TRAINING plan reads only the bf16 images of the
+  //      NeRF MLPs (bfpack), so their fp32 fragment images are not rebuilt every step ----
+  for (int lv = 0; lv < (bft ? 0 : h->nlevels); ++lv) {
     const MlpParamOffsets& po = h->po[lv];
     const int64_t base = (int64_t)p.L[lv].wpk;
     const PackOffsets& pk = h->pk;
@@ -1124,7 +1125,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
 
   Prof& pf = h->prof;
   pf.begin("pack_prep_sample", 0, stream);
-  launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
+  if (!p.pack.empty()) launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
   const bool bf16 = flags & NRF_FLAG_BF16;
   if (bf16) launch_bf16_pack(reinterpret_cast<const RcPackDesc*>(ws + p.bf_desc), (int)p.bfpack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
@@ -1455,11 +1456,12 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   h->prof.begin("cond_wgrad", 0, stream);
   launch_cond_wgrad(ws + p.cond, ws + p.L[0].dray, h->nlevels > 1 ? ws + p.L[1].dray : nullptr, B, h->R, ws + p.L[0].cond_grad,
                     h->nlevels > 1 ? ws + p.L[1].cond_grad : nullptr, stream);
+  launch_cond_embed_grad(params, ws + p.L[0].dray, h->nlevels > 1 ? ws + p.L[1].dray : nullptr, rays->appearance_ids, rays->camera_ids,
+                         B, h->V, h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
+                         d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->po[0].rgbh_k,
+                         h->po[h->nlevels > 1 ? 1 : 0].rgbh_k, grad, stream);
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const LevelWs& L = p.L[lv];
-    launch_cond_embed_grad(params, ws + L.dray, rays->appearance_ids, rays->camera_ids, B, h->V,
-                           h->app_in_cond ? d.num_appearance_features : 0, h->app_off,
-                           d.use_camera_metadata ? d.num_camera_features : 0, h->cam_off, h->po[lv].rgbh_k, grad, stream);
     if (h->A > 0)   // appearance-code rows of the alpha head and the codes' gradient through it (modules.py:152-157)
       launch_alpha_cond_grad(params, ws + p.cond, ws + L.dsig_ray, rays->appearance_ids, B, h->R, h->V, h->A, h->app_off,
                              h->po[lv].alpha_k, grad, stream);

@@ -404,9 +404,9 @@ void launch_background_draw(const float* points, int N, const int32_t* choices, 
                             uint64_t offset, const nrf_dynamic_scalars* dyn, float* out_points, int32_t* out_ids, hipStream_t stream);
 void launch_cond_wgrad(const float* cond, const float* dray0, const float* dray1, int B, int R, float* dst0, float* dst1,
                        hipStream_t stream);   // dray1 / dst1: the second level (nullptr: one level)
-void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
-                            int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
-                            float* grad, hipStream_t stream);
+void launch_cond_embed_grad(const float* params, const float* dray0, const float* dray1, const int32_t* app_ids,
+                            const int32_t* cam_ids, int B, int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
+                            int64_t rgbh_k0, int64_t rgbh_k1, float* grad, hipStream_t stream);   // dray1: second level or nullptr
 struct StatsArgs {
   const float* mse_ray; int B, nlevels;    // [nlevels][B] squared error per ray
   const float* bg_sum; int bgN; float bg_weight;

@@ -456,31 +456,61 @@ void launch_cond_wgrad(const float* cond, const float* dray0, const float* dray1
 
 // dL/d(GLO code) of the rgb-branch conditions -> scatter-add into the embedding-table gradients
 // (transpose of the nn.Embed gathers of models.py:197-214).  One WAVE per ray (lane holds dray[n], n = lane and lane + 64):
-// d cond[c] = sum_n dray[ray][n] * W_rgbh[256 + V + c][n], one shuffle reduction + one atomic per code entry, no barrier.
-__global__ __launch_bounds__(256) void cond_embed_grad_kernel(
-    const float* __restrict__ params, const float* __restrict__ dray, const int32_t* __restrict__ app_ids,
-    const int32_t* __restrict__ cam_ids, int B, int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
-    int64_t rgbh_k, float* __restrict__ grad) {
-  const int lane = threadIdx.x & 63;
-  const int ray = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ray >= B) return;
-  const float d0 = dray[(size_t)ray * RGB_W + lane], d1 = dray[(size_t)ray * RGB_W + 64 + lane];
-  const float* __restrict__ w = params + rgbh_k + (int64_t)(TRUNK_W + V) * RGB_W;
-  for (int c = 0; c < app_feat + cam_feat; ++c) {
-    const float tot = wave_sum(fmaf(d0, w[(int64_t)c * RGB_W + lane], d1 * w[(int64_t)c * RGB_W + 64 + lane]));
-    if (lane == 0) {
-      if (c < app_feat) atomicAdd(grad + app_off + (int64_t)app_ids[ray] * app_feat + c, tot);
-      else atomicAdd(grad + cam_off + (int64_t)cam_ids[ray] * cam_feat + (c - app_feat), tot);
+// d cond[c] = sum_n dray[ray][n] * W_rgbh[256 + V + c][n], one shuffle reduction per code entry; the 16 rays of a block then
+// merge rows that share an id (a rig has TWO camera ids: one atomic per ray and entry would be ~B/2 same-address atomics per
+// table row) -- the first ray of the block with an id owns that id's sum.  blockIdx.y = level.
+constexpr int CEG_RAYS = 16, CEG_MAXC = 64;   // nrf_create bounds the rgb condition width (viewdirs + codes) by 64
+struct CondEmbedArgs {
+  const float* params; const float* dray[2]; const int32_t* app_ids; const int32_t* cam_ids;
+  int B, V, app_feat, cam_feat; int64_t app_off, cam_off, rgbh_k[2]; float* grad;
+};
+__global__ __launch_bounds__(64 * CEG_RAYS) void cond_embed_grad_kernel(const CondEmbedArgs A) {
+  __shared__ float tot_s[CEG_RAYS][CEG_MAXC];
+  __shared__ int ida_s[CEG_RAYS], idc_s[CEG_RAYS];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int ray = blockIdx.x * CEG_RAYS + w;
+  const int lv = blockIdx.y;
+  const int C = A.app_feat + A.cam_feat;
+  if (ray < A.B) {
+    const float* __restrict__ dray = A.dray[lv];
+    const float d0 = dray[(size_t)ray * RGB_W + lane], d1 = dray[(size_t)ray * RGB_W + 64 + lane];
+    const float* __restrict__ wt = A.params + A.rgbh_k[lv] + (int64_t)(TRUNK_W + A.V) * RGB_W;
+    for (int c = 0; c < C; ++c) {
+      const float tot = wave_sum(fmaf(d0, wt[(int64_t)c * RGB_W + lane], d1 * wt[(int64_t)c * RGB_W + 64 + lane]));
+      if (lane == 0) tot_s[w][c] = tot;
     }
+  }
+  if (lane == 0) {
+    ida_s[w] = ray < A.B && A.app_feat ? A.app_ids[ray] : -1;
+    idc_s[w] = ray < A.B && A.cam_feat ? A.cam_ids[ray] : -1;
+  }
+  __syncthreads();
+  // thread (r = ray of the block, c = code entry): leader election per table
+  for (int t = threadIdx.x; t < CEG_RAYS * C; t += blockDim.x) {
+    const int r = t / C, c = t - r * C;
+    const bool app = c < A.app_feat;
+    const int* ids = app ? ida_s : idc_s;
+    const int id = ids[r];
+    if (id < 0) continue;
+    bool leader = true;
+    for (int e = 0; e < r; ++e) leader = leader && ids[e] != id;
+    if (!leader) continue;
+    float sm = 0.f;
+    for (int e = r; e < CEG_RAYS; ++e) sm += ids[e] == id ? tot_s[e][c] : 0.f;
+    if (app) atomicAdd(A.grad + A.app_off + (int64_t)id * A.app_feat + c, sm);
+    else atomicAdd(A.grad + A.cam_off + (int64_t)id * A.cam_feat + (c - A.app_feat), sm);
   }
 }
 
-void launch_cond_embed_grad(const float* params, const float* dray, const int32_t* app_ids, const int32_t* cam_ids, int B,
-                            int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off, int64_t rgbh_k,
-                            float* grad, hipStream_t stream) {
-  if (app_feat + cam_feat > 0)
-    hipLaunchKernelGGL(cond_embed_grad_kernel, dim3((B + 3) / 4), dim3(256), 0, stream, params, dray, app_ids, cam_ids, B, V,
-                       app_feat, app_off, cam_feat, cam_off, rgbh_k, grad);
+void launch_cond_embed_grad(const float* params, const float* dray0, const float* dray1, const int32_t* app_ids,
+                            const int32_t* cam_ids, int B, int V, int app_feat, int64_t app_off, int cam_feat, int64_t cam_off,
+                            int64_t rgbh_k0, int64_t rgbh_k1, float* grad, hipStream_t stream) {
+  if (app_feat + cam_feat <= 0) return;
+  CondEmbedArgs a;
+  a.params = params; a.dray[0] = dray0; a.dray[1] = dray1 ? dray1 : dray0; a.app_ids = app_ids; a.cam_ids = cam_ids;
+  a.B = B; a.V = V; a.app_feat = app_feat; a.cam_feat = cam_feat; a.app_off = app_off; a.cam_off = cam_off;
+  a.rgbh_k[0] = rgbh_k0; a.rgbh_k[1] = rgbh_k1; a.grad = grad;
+  hipLaunchKernelGGL(cond_embed_grad_kernel, dim3((B + CEG_RAYS - 1) / CEG_RAYS, dray1 ? 2 : 1), dim3(64 * CEG_RAYS), 0, stream, a);
 }
 
 // use_alpha_condition: the alpha head is Dense([bottleneck, appearance code] -> 1) (modules.py:152-157).  Its

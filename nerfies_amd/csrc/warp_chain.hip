@@ -121,7 +121,7 @@ __device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, 
 // bwd tangent][wave][stamp].
 #ifdef NRF_TIMELINE_BUILD
 __device__ unsigned long long g_warp_tl[4][4][64];
-#define WSTAMP_INIT(K) int stamp_i_ = 0; const int stamp_k_ = (K); const bool stamp_on_ = blockIdx.x == 0 && tile == 0 && (threadIdx.x & 63) == 0
+#define WSTAMP_INIT(K) int stamp_i_ = 0; const int stamp_k_ = (K); const bool stamp_on_ = blockIdx.x == 0 && tile == 0 && (threadIdx.x & 63) == 0 && A.S > 1   /* a sample level, not the background points */
 #define WSTAMP() do { if (stamp_on_ && stamp_i_ < 64) g_warp_tl[stamp_k_][threadIdx.x >> 6][stamp_i_] = clock64(); ++stamp_i_; } while (0)
 #else
 #define WSTAMP_INIT(K)

@@ -168,8 +168,14 @@ def test_sample_pdf_with_ties_and_a_coarse_list_that_is_not_ascending():
   err = (got.double() - ref).abs()                              # but its fp32 noise model is the sorted one: bound those rows loosely
   assert err[sorted_rows].max() < 2e-4 and (err[sorted_rows] < 5e-6).double().mean() > 0.998
   # an inverted bin edge puts a jump of the size of the inversion into one bin: where that bin's pdf mass is ~1e-5 the fp32
-  # rounding of the cdf moves a draw by a visible fraction of the jump, so these rows are held to "mostly equal"
-  assert (err[[9, 20]] < 1e-4).double().mean() > 0.9
+  # rounding of the cdf moves a draw across the jump, and ONE moved draw shifts every sorted position between its two places.
+  # These rows are therefore compared as multisets: nearly every oracle value has a value of ours next to it.
+  for r in (9, 20):
+    ours = np.sort(got[r].double().numpy())
+    want = ref[r].numpy()
+    k = np.clip(np.searchsorted(ours, want), 1, len(ours) - 1)
+    nearest = np.minimum(np.abs(ours[k] - want), np.abs(ours[k - 1] - want))
+    assert (nearest < 1e-4).mean() > 0.95, (r, (nearest < 1e-4).mean())
   # every coarse value is present, bit for bit
   for r in (2, 9, 20):
     assert set(zc[r].tolist()) <= set(got[r].tolist())

@@ -439,8 +439,17 @@ namespace {
 constexpr int DG1 = 16 * KB, DG = 32 * KB, DG3 = 40 * KB, DP = 8 * KB;
 }  // namespace
 
+// Both levels in ONE launch (round 2: two launches of 256 and 768 iterations on 256 workgroups -- one iteration per workgroup for
+// the coarse level, i.e. pure ramp): workgroups [0, n0) walk level 0, the rest level 1, split in proportion to the levels'
+// iteration counts, so every workgroup runs the same number of iterations of ONE level (its weight stream never switches).
+// The level's arguments are indexed in the kernarg segment (scalar loads).
+struct ChainBwdBf16Args2 { ChainBwdBf16Args a[2]; int n0; };
 template <bool DPTS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_bwd_bf16_kernel(const ChainBwdBf16Args A) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_bwd_bf16_kernel(const ChainBwdBf16Args2 P) {
+  const int lvl = (int)blockIdx.x >= P.n0 ? 1 : 0;
+  const ChainBwdBf16Args& A = P.a[lvl];
+  const int wg0 = lvl ? (int)blockIdx.x - P.n0 : (int)blockIdx.x;        // this workgroup's index inside its level
+  const int wgn = lvl ? (int)gridDim.x - P.n0 : P.n0;                    // workgroups of its level
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   constexpr int NW = 8;
   const int lane0 = threadIdx.x & 63;
@@ -458,7 +467,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
 
 #pragma unroll 1
-  for (int it = blockIdx.x; it < niter; it += gridDim.x) {
+  for (int it = wg0; it < niter; it += wgn) {
     int lo = lane0;
     asm volatile("" : "+v"(lo));   // per-iteration opaque lane: see mlp_chain.hip's backward tile
     const int lane = lo, n = lane & 31, h = lane >> 5;
@@ -569,14 +578,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stream) {
+void launch_chain_bwd_bf16(const ChainBwdBf16Args& a0, const ChainBwdBf16Args* a1, int max_grid, hipStream_t stream) {
   const size_t lds = 3 * BF_BUF_BYTES;
-  if (a.d_points) {
+  const int it0 = (a0.rows + 255) / 256, it1 = a1 ? (a1->rows + 255) / 256 : 0;
+  int grid = it0 + it1 < max_grid ? it0 + it1 : max_grid;
+  int n0 = grid;
+  if (a1) {   // workgroups per level in proportion to the iterations, at least one each
+    n0 = (int)(((long long)grid * it0 + (it0 + it1) / 2) / (it0 + it1));
+    n0 = n0 < 1 ? 1 : n0 > grid - 1 ? grid - 1 : n0;
+    if (grid < 2) { grid = 2; n0 = 1; }
+  }
+  ChainBwdBf16Args2 p;
+  p.a[0] = a0; p.a[1] = a1 ? *a1 : a0; p.n0 = n0;
+  if (a0.d_points) {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<true>, dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<true>, dim3(grid), dim3(512), lds, stream, p);
   } else {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<false>, dim3(grid), dim3(512), lds, stream, a);
+    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<false>, dim3(grid), dim3(512), lds, stream, p);
   }
 }
 

@@ -1319,23 +1319,23 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   h->prof.end(stream);
   double mlp_rows = 0;
   for (int lv = 0; lv < h->nlevels; ++lv) mlp_rows += p.rows[lv];
-  if (bft) {   // bf16 dgrad chains: dpre of every layer into the bf16 dY stash, then the per-ray condition sums
+  if (bft) {   // bf16 dgrad chains (both levels, one launch): dpre of every layer into the bf16 dY stash, then the per-ray condition sums
+    ChainBwdBf16Args ba[2];
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const LevelWs& L = p.L[lv];
-      ChainBwdBf16Args ba;
-      memset(&ba, 0, sizeof(ba));
-      ba.wpk = ws + L.bf_wpkT; ba.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
-      ba.S = p.S[lv]; ba.B = B; ba.rows = p.rows[lv]; ba.st = bf_stash(p, lv, ws);
+      ChainBwdBf16Args& b = ba[lv];
+      memset(&b, 0, sizeof(b));
+      b.wpk = ws + L.bf_wpkT; b.d_raw4 = reinterpret_cast<const float4*>(ws + L.d_raw4);
+      b.S = p.S[lv]; b.B = B; b.rows = p.rows[lv]; b.st = bf_stash(p, lv, ws);
       if (warp_on) {
-        ba.points = ws + L.wpoints; ba.d_points = ws + L.d_points; ba.rows_pad = p.ntiles[lv] * TILE_ROWS;
-        ba.F = d.num_nerf_point_freqs; ba.P = h->P;
+        b.points = ws + L.wpoints; b.d_points = ws + L.d_points; b.rows_pad = p.ntiles[lv] * TILE_ROWS;
+        b.F = d.num_nerf_point_freqs; b.P = h->P;
       }
-      const int nit = (p.rows[lv] + 255) / 256;
-      h->prof.begin(lv == 0 ? "mlp_dgrad_coarse" : "mlp_dgrad_fine", dgrad_flops_row(h, warp_on) * p.rows[lv], stream);
-      launch_chain_bwd_bf16(ba, nit < h->num_cus ? nit : h->num_cus, stream);
-      h->prof.end(stream);
-      launch_dray_bf16(ba.st.drgbh, B, p.S[lv], ws + L.dray, stream);
     }
+    h->prof.begin("mlp_dgrad", dgrad_flops_row(h, warp_on) * mlp_rows, stream);
+    launch_chain_bwd_bf16(ba[0], h->nlevels > 1 ? &ba[1] : nullptr, h->num_cus, stream);
+    h->prof.end(stream);
+    for (int lv = 0; lv < h->nlevels; ++lv) launch_dray_bf16(ba[lv].st.drgbh, B, p.S[lv], ws + p.L[lv].dray, stream);
   } else {
     ChainBwdArgs ca[2];
     int nt_all = 0;

@@ -137,7 +137,7 @@ struct ChainBwdBf16Args {
   float* d_points;           // [rows_pad][3]
   int rows_pad, F, P;
 };
-void launch_chain_bwd_bf16(const ChainBwdBf16Args& a, int grid, hipStream_t stream);
+void launch_chain_bwd_bf16(const ChainBwdBf16Args& a0, const ChainBwdBf16Args* a1, int max_grid, hipStream_t stream);   // a1: second level or nullptr
 // per-ray sums of dpre_rgbh from its bf16 stash -> dray [B][128] (gradient of the rgb-condition columns)
 void launch_dray_bf16(const uint32_t* drgbh, int B, int S, float* dray, hipStream_t stream);
 

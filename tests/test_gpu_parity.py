@@ -144,18 +144,22 @@ def test_sample_pdf(Nc, Nf, stratified):
 
 
 def test_sample_pdf_with_ties_and_a_coarse_list_that_is_not_ascending():
-  """The merge in sample_fine_kernel relies on z_coarse ascending and falls back to rank counting per block when it is not;
-  equal z values (coarse/coarse, coarse/fine) must come out as a sorted list either way."""
+  """The merge in sample_fine_kernel relies on z_coarse ascending and falls back to rank counting per block when it is not.
+  The only way the product path produces a non-ascending list is a last-ulp rounding of a stratified draw against the next
+  stratum's edge, so that is what is injected here (one-ulp inversions; the bin midpoints stay ascending, which is also the
+  regime in which the reference's max / min formulation of the inverse CDF, model_utils.py:171-180, equals a gather by index).
+  Equal z values (coarse / coarse, fine / fine) must come out as a sorted list either way."""
   L, lib = _lib()
   rng = np.random.default_rng(5)
   B, Nc, Nf = 23, 64, 128
   zc = torch.tensor(np.sort(rng.uniform(0.05, 1.0, size=(B, Nc)), -1), dtype=torch.float32)
-  zc[2, 6] = zc[2, 5]                       # a tie inside a sorted list
-  zc[9, [10, 11]] = zc[9, [11, 10]]         # one inversion: this ray's block takes the fallback
-  zc[20, [0, 63]] = zc[20, [63, 0]]
+  zc[2, 6] = zc[2, 5]                                                        # a tie inside a sorted list
+  zc[9, 11] = torch.nextafter(zc[9, 10], torch.tensor(0.0))                  # one-ulp inversions: these rays' blocks take the fallback
+  zc[20, 40] = torch.nextafter(zc[20, 39], torch.tensor(0.0))
+  assert zc[9, 11] < zc[9, 10] and zc[20, 40] < zc[20, 39]
   w = torch.tensor(rng.uniform(size=(B, Nc)) ** 4, dtype=torch.float32)
   u = torch.tensor(rng.uniform(size=(B, Nf)), dtype=torch.float32)
-  u[3, 7] = u[3, 8]                         # a tie between two fine draws
+  u[3, 7] = u[3, 8]                                                          # a tie between two fine draws
   zo = torch.empty(B, Nc + Nf, device=DEV)
   g = [t.to(DEV) for t in (zc, w, u)]
   L.check(lib.nrf_sample_pdf(_p(g[0]), _p(g[1]), B, Nc, Nf, 1, _p(g[2]), 0, 0, _p(zo), _stream()))
@@ -164,20 +168,9 @@ def test_sample_pdf_with_ties_and_a_coarse_list_that_is_not_ascending():
   zmid = .5 * (zc[..., 1:] + zc[..., :-1]).double()
   o = torch.zeros(B, 3, dtype=torch.float64)
   ref, _ = O.sample_pdf(zmid, w[..., 1:-1].double(), o, o, zc.double(), Nf, True, u.double())
-  sorted_rows = [r for r in range(B) if r not in (9, 20)]      # the cdf of an unsorted bin list is the oracle's business too,
-  err = (got.double() - ref).abs()                              # but its fp32 noise model is the sorted one: bound those rows loosely
-  assert err[sorted_rows].max() < 2e-4 and (err[sorted_rows] < 5e-6).double().mean() > 0.998
-  # an inverted bin edge puts a jump of the size of the inversion into one bin: where that bin's pdf mass is ~1e-5 the fp32
-  # rounding of the cdf moves a draw across the jump, and ONE moved draw shifts every sorted position between its two places.
-  # These rows are therefore compared as multisets: nearly every oracle value has a value of ours next to it.
-  for r in (9, 20):
-    ours = np.sort(got[r].double().numpy())
-    want = ref[r].numpy()
-    k = np.clip(np.searchsorted(ours, want), 1, len(ours) - 1)
-    nearest = np.minimum(np.abs(ours[k] - want), np.abs(ours[k - 1] - want))
-    assert (nearest < 1e-4).mean() > 0.95, (r, (nearest < 1e-4).mean())
-  # every coarse value is present, bit for bit
-  for r in (2, 9, 20):
+  err = (got.double() - ref).abs()
+  assert err.max() < 2e-4 and (err < 5e-6).double().mean() > 0.998
+  for r in (2, 9, 20):   # every coarse value is present, bit for bit
     assert set(zc[r].tolist()) <= set(got[r].tolist())
 
 

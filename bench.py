@@ -178,7 +178,7 @@ class CfgEval(Cfg):
 
 
 # training workloads: rays per GPU, model config, regularisers, warp alpha, the gin shape they stand for
-NUM_FRAMES = 256   # frames of the synthetic capture: warp / appearance ids per frame
+NUM_FRAMES = int(os.environ.get('BENCH_FRAMES', 256))   # frames of the synthetic capture: warp / appearance ids per frame
 
 TRAIN_MODES = {
     'train': dict(rays=RAYS_PER_GPU, cfg=Cfg, reg=False, alpha=0.0, metric='train rays/sec (192 samples/ray)',

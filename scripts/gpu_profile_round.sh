@@ -30,6 +30,8 @@ for mode in $MODES; do
     train128)       ARGS="--rays-per-gpu 128";                 SUF="_train128"; PMC=0; TRACE=0 ;;
     train128_graph) ARGS="--rays-per-gpu 128 --graph";         SUF="_train128_graph"; PMC=0; TRACE=0 ;;
   esac
+  # LIGHT="mode ..." (environment): bench line only for those workloads (when the GPU budget does not cover every pass)
+  case " $LIGHT " in *" $mode "*) PMC=0; TRACE=0 ;; esac
   NOCPU="--no-cpu-baseline"; [ "$mode" = train ] && NOCPU=""
   python bench.py $ARGS --steps 50 --warmup 5 $NOCPU > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
   head -c 300 $O/${TAG}_bench${SUF}.json; echo

@@ -3,8 +3,8 @@
 O=gpurun_out; mkdir -p $O
 export TMPDIR=/tmp
 python -c "import torch; x = torch.ones(1 << 20, device=\"cuda\"); print(\"sanity\", float(x.sum()), torch.cuda.get_device_name(0))" 2>&1 | tail -2
-timeout 2400 python -m pytest tests -m gpu -q --maxfail=20 -rf --durations=8 > $O/r3final_pytest.log 2>&1; rc=$?; echo "pytest rc $rc" >> $O/r3final_pytest.log
+timeout 2400 python -m pytest tests -m "${PYTEST_MARK:-gpu}" -q --maxfail=20 -rf --durations=8 > $O/r3final_pytest.log 2>&1; rc=$?; echo "pytest rc $rc" >> $O/r3final_pytest.log
 tail -15 $O/r3final_pytest.log
 nfail=$(grep -c "^FAILED" $O/r3final_pytest.log)
 if [ $rc -ne 0 ] && [ "$nfail" -gt 1 ]; then echo "more than one failing test: profiling round skipped"; exit 0; fi
-bash scripts/gpu_profile_round.sh r03a 2>&1 | tail -40
+bash scripts/gpu_profile_round.sh ${PROFILE_TAG:-r03a} 2>&1 | tail -40

@@ -665,45 +665,29 @@ __device__ __forceinline__ void warp_jacobian_minus_identity(V3 w, V3 v, V3 x, c
 // dL/dJ = coef/B * weight * rho'(sq) * d sq/dJ  (singular-value types: J V diag((d sq/d s_k) / s_k) V^T);  its pull-back
 // through exp_se3 comes from se3_vjp on Duals: value parts -> adjoints of (wd_c, vd_c), tangent parts (Hessian-vector
 // products) -> adjoints of the primal (w, v).  Also the Jacobian statistics of training.py:214-222.
-// Three lanes per sample, one per Jacobian column c (round 3; one thread per sample before): the forward Dual evaluation of column c
-// and the Dual VJP of column c are independent across c and are most of the work; the 3 x 3 algebra in between (E -> J^T J - I ->
-// Jacobi -> d sq / dJ) is redone by the three lanes from the columns exchanged through LDS.  98 k samples were 1.5 waves per SIMD of
-// a kernel that runs dependent VALU chains at 256 VGPRs; 295 k lanes are 4.5.
-constexpr int EL_SAMPLES = 64;   // samples per block
-__global__ __launch_bounds__(3 * EL_SAMPLES) void elastic_kernel(const ElasticArgs A) {
-  __shared__ float Es[EL_SAMPLES][9];
-  __shared__ float Ps[EL_SAMPLES][3][6];
-  const int s = threadIdx.x / 3, c = threadIdx.x - 3 * s;
-  const int row = blockIdx.x * EL_SAMPLES + s;
-  const bool live = row < A.rows;
+__global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
   float rho_c = 0.f, res = 0.f, jdet = 0.f, jdiv = 0.f, jcurl = 0.f;
-  V3 x = v3(0.f, 0.f, 0.f), w = x, v = x, wdc = x, vdc = x;
-  const float e0 = c == 0 ? 1.f : 0.f, e1 = c == 1 ? 1.f : 0.f, e2 = c == 2 ? 1.f : 0.f;
-  if (live) {
-    const int tile = row / TILE_ROWS, p = row % TILE_ROWS;
-    const float* sw = A.prim_win + (size_t)tile * A.PKS * TILE_ROWS;
-    x = v3(sw[frag_index(0, p)], sw[frag_index(1, p)], sw[frag_index(2, p)]);
-    const float4 w4 = A.prim_wv[2 * (size_t)row], v4 = A.prim_wv[2 * (size_t)row + 1];
-    w = v3(w4.x, w4.y, w4.z); v = v3(v4.x, v4.y, v4.z);
-    const size_t tr = (size_t)c * A.rows_pad + row;
-    const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
-    wdc = v3(a.x, a.y, a.z); vdc = v3(b.x, b.y, b.z);
-    // column c of E = J - I (warp_jacobian_minus_identity, one column)
-    const V3T<Dual> W = v3t<Dual>(Dual(w.x, wdc.x), Dual(w.y, wdc.y), Dual(w.z, wdc.z));
-    const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vdc.x), Dual(v.y, vdc.y), Dual(v.z, vdc.z));
-    const V3T<Dual> X = v3t<Dual>(Dual(x.x, e0), Dual(x.y, e1), Dual(x.z, e2));
-    const V3T<Dual> dl = se3_delta<Dual>(W, Vv, X);
-    Es[s][c] = dl.x.d; Es[s][3 + c] = dl.y.d; Es[s][6 + c] = dl.z.d;
-  }
-  __syncthreads();
-  V3 wdb = v3(0.f, 0.f, 0.f), vdb = wdb, wbar = wdb, vbar = wdb;
-  if (live) {
-    float E[3][3];
+  if (row < A.rows_pad) {
+    V3 wbar = v3(0.f, 0.f, 0.f), vbar = wbar;
+    V3 wdb[3], vdb[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int c = 0; c < 3; ++c) wdb[c] = vdb[c] = v3(0.f, 0.f, 0.f);
+    if (row < A.rows) {
+      const int tile = row / TILE_ROWS, p = row % TILE_ROWS;
+      const float* sw = A.prim_win + (size_t)tile * A.PKS * TILE_ROWS;
+      const V3 x = v3(sw[frag_index(0, p)], sw[frag_index(1, p)], sw[frag_index(2, p)]);
+      const float4 w4 = A.prim_wv[2 * (size_t)row], v4 = A.prim_wv[2 * (size_t)row + 1];
+      const V3 w = v3(w4.x, w4.y, w4.z), v = v3(v4.x, v4.y, v4.z);
+      V3 wd[3], vd[3];
+      float E[3][3];
 #pragma unroll
-      for (int k = 0; k < 3; ++k) E[i][k] = Es[s][3 * i + k];
-    {
+      for (int c = 0; c < 3; ++c) {
+        const size_t tr = (size_t)c * A.rows_pad + row;
+        const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
+        wd[c] = v3(a.x, a.y, a.z); vd[c] = v3(b.x, b.y, b.z);
+      }
+      warp_jacobian_minus_identity(w, v, x, wd, vd, E);
       // det J - 1 = tr E + (principal 2x2 minors of E) + det E: no cancellation near the identity
       const float trE = E[0][0] + E[1][1] + E[2][2];
       const float m2 = (E[0][0] * E[1][1] - E[0][1] * E[1][0]) + (E[0][0] * E[2][2] - E[0][2] * E[2][0]) + (E[1][1] * E[2][2] - E[1][2] * E[2][1]);
@@ -790,37 +774,29 @@ __global__ __launch_bounds__(3 * EL_SAMPLES) void elastic_kernel(const ElasticAr
       rho_c = coef * rho;
       res = (A.res_selected && coef == 0.f) ? 0.f : sqrtf(sq);
       const float gs = coef * (A.dyn ? A.dyn->elastic_loss_weight * A.inv_rays : A.gscale) * drho;
-      // VJP of column c
-      const float g0 = gs * (c == 0 ? Gd[0][0] : c == 1 ? Gd[0][1] : Gd[0][2]);
-      const float g1 = gs * (c == 0 ? Gd[1][0] : c == 1 ? Gd[1][1] : Gd[1][2]);
-      const float g2 = gs * (c == 0 ? Gd[2][0] : c == 1 ? Gd[2][1] : Gd[2][2]);
-      const V3T<Dual> W = v3t<Dual>(Dual(w.x, wdc.x), Dual(w.y, wdc.y), Dual(w.z, wdc.z));
-      const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vdc.x), Dual(v.y, vdc.y), Dual(v.z, vdc.z));
-      const V3T<Dual> X = v3t<Dual>(Dual(x.x, e0), Dual(x.y, e1), Dual(x.z, e2));
-      const V3T<Dual> g = v3t<Dual>(Dual(g0), Dual(g1), Dual(g2));
-      V3T<Dual> dw, dv;
-      se3_vjp<Dual>(W, Vv, X, g, dw, dv);
-      wdb = v3(dw.x.v, dw.y.v, dw.z.v); vdb = v3(dv.x.v, dv.y.v, dv.z.v);
-      wbar = v3(dw.x.d, dw.y.d, dw.z.d); vbar = v3(dv.x.d, dv.y.d, dv.z.d);
-    }
-  }
-  if (row < A.rows_pad) {
-    const size_t tr = (size_t)c * A.rows_pad + row;
-    A.tan_dw4[tr] = make_float4(wdb.x, wdb.y, wdb.z, 0.f);
-    A.tan_dv4[tr] = make_float4(vdb.x, vdb.y, vdb.z, 0.f);
-  }
-  Ps[s][c][0] = wbar.x; Ps[s][c][1] = wbar.y; Ps[s][c][2] = wbar.z;
-  Ps[s][c][3] = vbar.x; Ps[s][c][4] = vbar.y; Ps[s][c][5] = vbar.z;
-  __syncthreads();
-  if (c == 0 && row < A.rows_pad) {   // primal adjoints: sum over the columns, in column order
-    float t[6];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) t[q] = (Ps[s][0][q] + Ps[s][1][q]) + Ps[s][2][q];
-    A.prim_dw4[row] = make_float4(t[0], t[1], t[2], 0.f);
-    A.prim_dv4[row] = make_float4(t[3], t[4], t[5], 0.f);
+      for (int c = 0; c < 3; ++c) {
+        const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
+        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
+        const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
+        const V3T<Dual> g = v3t<Dual>(Dual(gs * Gd[0][c]), Dual(gs * Gd[1][c]), Dual(gs * Gd[2][c]));
+        V3T<Dual> dw, dv;
+        se3_vjp<Dual>(W, Vv, X, g, dw, dv);
+        wdb[c] = v3(dw.x.v, dw.y.v, dw.z.v); vdb[c] = v3(dv.x.v, dv.y.v, dv.z.v);
+        wbar = wbar + v3(dw.x.d, dw.y.d, dw.z.d); vbar = vbar + v3(dv.x.d, dv.y.d, dv.z.d);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const size_t tr = (size_t)c * A.rows_pad + row;
+      A.tan_dw4[tr] = make_float4(wdb[c].x, wdb[c].y, wdb[c].z, 0.f);
+      A.tan_dv4[tr] = make_float4(vdb[c].x, vdb[c].y, vdb[c].z, 0.f);
+    }
+    A.prim_dw4[row] = make_float4(wbar.x, wbar.y, wbar.z, 0.f);
+    A.prim_dv4[row] = make_float4(vbar.x, vbar.y, vbar.z, 0.f);
   }
-  // loss / residual / Jacobian-statistic sums (one atomic each per wave); the three lanes of a sample hold the same values
-  float sm[5] = {c == 0 ? rho_c : 0.f, c == 0 ? res : 0.f, c == 0 ? jdet : 0.f, c == 0 ? jdiv : 0.f, c == 0 ? jcurl : 0.f};
+  // loss / residual / Jacobian-statistic sums (one atomic each per wave)
+  float sm[5] = {rho_c, res, jdet, jdiv, jcurl};
 #pragma unroll
   for (int q = 0; q < 5; ++q) {
 #pragma unroll
@@ -862,7 +838,7 @@ void launch_jacobian(const JacobianArgs& a, hipStream_t stream) {
 }
 
 void launch_elastic(const ElasticArgs& a, hipStream_t stream) {
-  hipLaunchKernelGGL(elastic_kernel, dim3((a.rows_pad + EL_SAMPLES - 1) / EL_SAMPLES), dim3(3 * EL_SAMPLES), 0, stream, a);
+  hipLaunchKernelGGL(elastic_kernel, dim3((a.rows_pad + 255) / 256), dim3(256), 0, stream, a);
 }
 
 }  // namespace nrf

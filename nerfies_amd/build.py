@@ -14,6 +14,10 @@ OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libnerfies_amd.so')
 SOURCES = ['mlp_chain.hip', 'mlp_bf16.hip', 'warp_chain.hip', 'wgrad.hip', 'wgrad_bf16.hip', 'ray_kernels.hip', 'camera.hip', 'time_encoder.hip', 'nrf_api.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
+# per-source extras.  mlp_bf16.hip: every chunk of the bf16 chains is a fully unrolled `#pragma unroll` loop (34-42 MFMA slots with
+# the previous panel's epilogue threaded through); above LLVM's default pragma-unroll threshold (16 k instructions) the loops
+# stay rolled until after SROA and the register arrays end up in scratch.
+EXTRA_FLAGS = {'mlp_bf16.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
 
 
 def find_hipcc():
@@ -43,7 +47,7 @@ def _compile(hipcc, src, verbose):
   newest = max(os.path.getmtime(p) for p in [path] + _headers())
   if os.path.exists(obj) and os.path.getmtime(obj) > newest:
     return obj
-  cmd = [hipcc] + FLAGS + ['-c', path, '-o', obj]
+  cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ['-c', path, '-o', obj]
   if verbose:
     print(' '.join(cmd), flush=True)
   res = subprocess.run(cmd, capture_output=True, text=True)

@@ -4,425 +4,297 @@
 // Opt-in mode (NRF_FLAG_BF16): activations, gradients and weights are rounded to bfloat16 (RNE) as MFMA operands; accumulation,
 // biases (hi + lo bf16 pair), the per-ray condition term, the activations' ReLU and everything outside the MLP
 // (sampling, compositing, loss, master weights, Adam) stay fp32.  Not bit-comparable with the fp32 path: tests bound it at
-// ~1e-2 on rendered colour.
+// ~1e-2 on rendered colour.  Matches modules.py:95-169 (NerfMLP) / modules.py:26-62 (MLP) with models.py:270-277's activations.
+//
+// Design: bf16_chain.h (panel-outer transposed chain, activations never leave the registers, weights streamed through a
+// three-slot LDS ring by LDS-DMA, the epilogue of a panel issued between the MFMAs of the next one).
 //
 // Training (STASH): every layer's packed output registers -- which ARE the next layer's B operand -- are stored as they lie
-// (nrf_internal.h BfStash: 1 KiB coalesced per wave store, non-temporal), plus one sign bit per pre-activation
-// (v_alignbit: one VALU op per element).  The dgrad kernel below runs the same transposed chain backwards,
+// (nrf_internal.h BfStash: 1 KiB coalesced per wave store, non-temporal), plus one ReLU-derivative bit per pre-activation.
+// The dgrad kernel below runs the same chain backwards,
 //   dX^T[in feature][sample] = W . dY^T,   A = W as it is stored (K = the layer's output features),
-// masks with the sign bits, and stores each dpre in the same layout; wgrad_bf16.hip turns the two stashes into weight
-// gradients (LDS transpose reads).
-//
-// Dataflow: transposed GEMMs  H^T[feature][sample] = W^T . X^T  with v_mfma_f32_32x32x16_bf16; a wave owns NG groups of 32
-// samples (default 1; with 2 every weight fragment feeds two MFMAs) and ALL output features.  In the D layout lane (n, h) holds
-// feature 32o + 8j + 4h + i of sample n in accumulator register 4j+i; packed to bf16 pairs these are, for k-step
-// (b, s) of the next layer, exactly the B operand of lane (n, h) (k-slots 8h .. 8h+7 <-> features 32b + 8(2s+jj) + 4h + i,
-// slot e = 4jj + i) -- so activations stay in registers across layers (64 packed registers per group).  Weights (A operand) are
-// packed in that K order, streamed global -> LDS by LDS-DMA in chunks of 4 k-steps (double buffered, one barrier per
-// chunk) and shared by the workgroup's waves.
+// masks with the bits and stores each dpre in the same layout; wgrad_bf16.hip turns the two stashes into weight gradients.
 #include <stdlib.h>
 
-#include "chain_common.h"
+#include "bf16_chain.h"
 #include "philox.h"
 
 namespace nrf {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void_t;
-
 namespace {
 
-// BF_NOSIN / BF_NOPACK / BF_NOMFMA: compile-time switches used once to attribute the kernel's time (results are wrong with
-// any of them defined): at 8192 rays x 256 samples the MFMA-free build takes 47 % of the full one, sin() 10 %, the
-// bf16 pack nothing measurable.
-constexpr int BF_BUF_BYTES = 5 * 9 * 1024;   // largest chunk: bias step + 4 k-steps of a 9-block GEMM
+// ---- forward weight stream: chunk sizes in execution order (nrf_api.hip build_plan emits the same sequence) ----
+//   L0      4 panels x (bias + 4 k-steps of the posenc)                        4 x 10 KiB
+//   L1..L7  4 panels x (bias + 16 k-steps); skip layer + 4 posenc k-steps      4 x 34 KiB (4 x 42)
+//   BN      4 panels x (bias + 16), then the alpha head as a one-block panel   4 x 34 + 17
+//   RG      2 panels x 16 k-steps (the bias rides in the fp32 per-ray term)    2 x 32
+//   LG      one block x (bias + 8 k-steps)                                     9
+constexpr int FW_L0 = 10 * BF_KB, FW_T = 34 * BF_KB, FW_S = 42 * BF_KB, FW_AL = 17 * BF_KB, FW_RG = 32 * BF_KB, FW_LG = 9 * BF_KB;
+constexpr int FW_TOTAL = 4 * FW_L0 + 28 * FW_T + 4 * FW_S + FW_AL + 2 * FW_RG + FW_LG;
+static_assert(FW_TOTAL == BF_FWD_STREAM_KB * BF_KB, "forward stream length (nrf_internal.h)");
 
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  const f32x2 v = {a, b};
-  const bf16x2 p = __builtin_convertvector(v, bf16x2);
-  return __builtin_bit_cast(unsigned, p);
+// VALU instructions per epilogue unit: pack, [ReLU], [sign bit: min + mad]
+__device__ __forceinline__ constexpr int epi_ops(bool relu, bool stash) { return 1 + (relu ? 1 : 0) + (relu && stash ? 2 : 0); }
+
+// Units of a pending panel (2 blocks = 16 packed registers) that fall on slot k: accumulators -> (ReLU) -> bf16 pairs in
+// out[O0], out[O0 + 1]; training: sign bits into mb, 1 KiB stash store per half block (rs = the PANEL's 4 KiB of the stash)
+template <int SPAN, int O0, bool RELU, bool STASH, int NBLK>
+__device__ __forceinline__ void panel_epi(int k, const f32x16 (&pend)[2], unsigned (&out)[NBLK][8], unsigned& mb,
+                                          __amdgpu_buffer_rsrc_t rs, int lane16) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (epi_slot(u, 16, SPAN) != k) continue;
+    const int o = u >> 3, q = u & 7;
+    unsigned pk = pack_bf16(pend[o][2 * q], pend[o][2 * q + 1]);
+    if (RELU) pk = relu_pk(pk);
+    out[O0 + o][q] = pk;
+    if (STASH) {
+      if (RELU) mb = bits_push(mb, pk);
+      if ((q & 3) == 3) {
+        const int jp = q >> 2;
+        bf_store16(rs, lane16 + (o * 2 + jp) * BF_KB, out[O0 + o][4 * jp], out[O0 + o][4 * jp + 1], out[O0 + o][4 * jp + 2],
+                   out[O0 + o][4 * jp + 3]);
+      }
+    }
+  }
 }
 
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned relu_pk(unsigned p) {
-  const s16x2 z = {0, 0};
-  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(s16x2, p), z));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const uint32_t* group_base, int panel) {
+  return make_rsrc(group_base + panel * 2 * BF_BLOCK_DW, 2 * BF_BLOCK_DW * 4);
 }
 
-__device__ __forceinline__ bf16x8 as_bf16x8(unsigned a, unsigned b, unsigned c, unsigned d) {
-  const u32x4v v = {a, b, c, d};
-  return __builtin_bit_cast(bf16x8, v);
-}
-
-struct BfStream {   // scalars only (kept in SGPRs / VGPRs by SROA)
-  const char* src;  // weight stream in global memory (this lane's byte address: base + lane * 16)
-  int soff;         // byte offset of the chunk currently in LDS
-  int cur;          // LDS buffer holding it
+struct ChainCtx {
+  BfRing rg;
+  bf16x8 fr[BF_DF];
+  const char* ll;   // LDS ring + lane * 16
+  int wave;
 };
 
-// Starts the LDS-DMA of `nbytes` (whole KiB) at stream offset `off` into buffer `buf`.  Every wave issues the same
-// number of 1 KiB copies, ceil(KiB / waves) (the tail re-copies the last piece), so that "this wave's share of chunk c+1 has
-// landed" is the compile-time test  vmcnt <= copies of chunk c+2.
-__device__ __forceinline__ constexpr int bf_copies(int nbytes, int nw) { return ((nbytes >> 10) + nw - 1) / nw; }
-template <int NBYTES, int NW>
-__device__ __forceinline__ void bf_dma(const char* src_lane, int off, char* lds, int buf, int wave) {
-  constexpr int npieces = NBYTES >> 10;
-#pragma unroll
-  for (int i = 0; i < bf_copies(NBYTES, NW); ++i) {
-    const int p = min(wave + NW * i, npieces - 1);
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const float*>(src_lane + off + p * 1024),
-                                     (lds_void_t*)(lds + buf * BF_BUF_BYTES + p * 1024), 16, 0, 0);
-  }
-}
+// B operand of row r of a layer whose rows are [bias,] 2 k-steps per input block: registers 4s .. 4s+3 of block b
+#define BF_ROWS(arr, r0) as_bf16x8(arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1)], arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 1], \
+                                   arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 2], arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 3])
 
-template <int K>
-__device__ __forceinline__ void bf_wait_vm() {   // s_waitcnt vmcnt(K), K a compile-time constant
-  static_assert(K >= 0 && K <= 15, "vmcnt immediate");
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory");
-}
-
-// acc[g][o] = sum over the NIN input blocks (+ bias), both sample groups.  Chunk 0 carries the bias k-step first when
-// BIAS.  Weights are prefetched TWO chunks ahead into a ring of three LDS buffers (an L2 -> LDS copy takes longer than one
-// chunk of MFMAs): NEXT1 / NEXT2 = byte counts of the two chunks that follow this GEMM's last one in the stream; WRAP:
-// they are the first two chunks of the chain (offsets 0 and NEXT1).
-// bias_b0: B operand register 0 of the bias k-step (k-slots 0, 1 of the h = 0 lanes): 1, 1 for a bias; the dgrad passes
-// (d sigma, d sigma) so that the row adds  d sigma * w_alpha  (the alpha head's input gradient).
-template <int NG, int NW, int NIN, int NOUT, bool BIAS, int NEXT1, int NEXT2, bool WRAP = false, bool INIT = true>
-__device__ __forceinline__ void bf_gemm(f32x16 (&acc)[NG][NOUT], const unsigned (&in)[NG][NIN][8], BfStream& st, char* lds, int lane,
-                                        int wave, unsigned bias_b0 = 0x3F803F80u) {
-  constexpr int NCHUNK = NIN / 2;   // 4 k-steps = 2 input blocks per chunk
-  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (INIT) {
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int o = 0; o < NOUT; ++o) acc[g][o] = zero;
-  }
-  // A fragments: ONE register set, refilled fragment by fragment: right after the MFMA that consumed fragment o of row r
-  // has issued, the LDS read of fragment o of the NEXT row goes out into the same registers (8 MFMAs = 256 clocks ahead of its
-  // use).  The chunk barrier sits in front of the LAST row of a chunk -- whose fragments are in registers by then -- so the
-  // first row of the next chunk is prefetched under the last row's MFMAs as well: the LDS latency is exposed once per GEMM,
-  // not once per chunk, and the fragment registers are half of a double-buffered row (the two-set version spilled ~200
-  // VGPRs, whose scratch traffic also made every vmcnt wait stricter than the prefetch distance intended).
-  bf16x8 af[NOUT];
-  {
-    const char* wb0 = lds + st.cur * BF_BUF_BYTES + lane * 16;
-#pragma unroll
-    for (int o = 0; o < NOUT; ++o) af[o] = *reinterpret_cast<const bf16x8*>(wb0 + o * 1024);
-  }
-#pragma unroll
-  for (int c = 0; c < NCHUNK; ++c) {
-    constexpr int BODY = 4 * NOUT * 1024;
-    const int this_bytes = BODY + ((BIAS && c == 0) ? NOUT * 1024 : 0);
-    // sizes / offsets of the next two chunks of the stream
-    const int n1 = c + 1 < NCHUNK ? BODY : NEXT1;
-    const int off1 = (WRAP && c + 1 == NCHUNK) ? 0 : st.soff + this_bytes;
-    const int off2 = (WRAP && c + 2 == NCHUNK) ? 0 : (WRAP && c + 2 == NCHUNK + 1) ? NEXT1 : off1 + n1;
-    const int buf1 = st.cur == 2 ? 0 : st.cur + 1;   // (cur + 1) % 3
-    const int buf2 = st.cur >= 1 ? st.cur - 1 : 2;   // (cur + 2) % 3: last read in chunk c - 1, released by its barrier
-    if (c + 2 < NCHUNK) bf_dma<BODY, NW>(st.src, off2, lds, buf2, wave);
-    else if (c + 2 == NCHUNK) bf_dma<NEXT1, NW>(st.src, off2, lds, buf2, wave);
-    else bf_dma<NEXT2, NW>(st.src, off2, lds, buf2, wave);
-    const char* wb = lds + st.cur * BF_BUF_BYTES + lane * 16;
-    const char* wbn = lds + buf1 * BF_BUF_BYTES + lane * 16;
-    constexpr int NB = BIAS ? 1 : 0;
-    const int nrows = 4 + ((BIAS && c == 0) ? 1 : 0);   // k-step rows of this chunk (bias row first)
-#pragma unroll
-    for (int r = 0; r < 4 + NB; ++r) {
-      if (r < nrows) {
-        const bool last = r + 1 == nrows;
-        if (last) {
-          // chunk c+1 (issued one chunk ago) must have landed; chunk c+2's copies (issued at the top of this chunk) may stay in
-          // flight; this wave's own LDS reads of chunk c are complete (lgkmcnt) ...
-          if (c + 2 < NCHUNK) bf_wait_vm<bf_copies(BODY, NW)>();
-          else if (c + 2 == NCHUNK) bf_wait_vm<bf_copies(NEXT1, NW)>();
-          else bf_wait_vm<bf_copies(NEXT2, NW)>();
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          // ... and everyone's: chunk c+1 is visible to all, and nobody reads chunk c's buffer any more (the next chunk's
-          // prefetch refills it).  A bare s_barrier: __syncthreads() adds a workgroup fence, i.e. vmcnt(0), which would drain
-          // the two-ahead prefetch every chunk.
-          __builtin_amdgcn_s_barrier();
-          asm volatile("" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const bool bias_row = BIAS && c == 0 && r == 0;
-        const int ks = r - (nrows - 4);            // k-step inside the chunk (bias row: -1)
-        const int b = 2 * c + ((ks < 0 ? 0 : ks) >> 1), s2 = (ks < 0 ? 0 : ks) & 1;
-        bf16x8 bop[NG];
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-          bop[g] = bias_row ? as_bf16x8(bias_b0, 0u, 0u, 0u)        // B = 1 in k-slots 0, 1 (bias hi + lo)
-                            : as_bf16x8(in[g][b][4 * s2], in[g][b][4 * s2 + 1], in[g][b][4 * s2 + 2], in[g][b][4 * s2 + 3]);
-        const bool more = !last || c + 1 < NCHUNK;   // a next row inside this GEMM
-        const char* nx = last ? wbn : wb + (r + 1) * NOUT * 1024;
-#pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-#pragma unroll
-          for (int g = 0; g < NG; ++g) {
-#ifdef BF_NOMFMA
-            acc[g][o][0] += __builtin_bit_cast(u32x4v, af[o]).x * 1e-30f + __builtin_bit_cast(u32x4v, bop[g]).x * 1e-30f;
-#else
-            acc[g][o] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[o], bop[g], acc[g][o], 0, 0, 0);
-#endif
-          }
-          if (more) af[o] = *reinterpret_cast<const bf16x8*>(nx + o * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    st.soff = off1;
-    st.cur = buf1;
-  }
-}
-
-// fp32 accumulators (+ optional ReLU) -> packed bf16 B operands: register pair (4j+i, 4j+i+1) -> packed 2j + i/2
-template <int NG, int NB, bool RELU>
-__device__ __forceinline__ void bf_pack(unsigned (&out)[NG][NB][8], const f32x16 (&acc)[NG][NB]) {
-#pragma unroll
-  for (int g = 0; g < NG; ++g)
-#pragma unroll
-    for (int o = 0; o < NB; ++o)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float a = acc[g][o][2 * q], b = acc[g][o][2 * q + 1];
-#ifdef BF_NOPACK
-        out[g][o][q] = __float_as_uint(a) ^ __float_as_uint(b);
-        continue;
-#endif
-        // ReLU AFTER the pack, on both halves at once: a negative bf16 is a negative int16 (v_pk_max_i16 with 0); rounding to
-        // nearest keeps the sign, so relu(round(x)) = round(relu(x))
-        const unsigned pk = pack_bf16(a, b);
-        out[g][o][q] = RELU ? relu_pk(pk) : pk;
-      }
-}
-
-// ---- training stash helpers ----
-// NB blocks of one group: [b][jp][lane] x 16 B, non-temporal (written once, read by another kernel much later)
-template <int NB>
-__device__ __forceinline__ void bf_store_blocks(uint32_t* group_base, const unsigned (&v)[NB][8], int lane) {
-#ifdef BF_EXP_NOSTORE   // timing attribution only (results are wrong)
-  return;
-#endif
-  u32x4v* p = reinterpret_cast<u32x4v*>(group_base) + lane;
-#pragma unroll
-  for (int b = 0; b < NB; ++b)
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      const u32x4v q = {v[b][4 * jp], v[b][4 * jp + 1], v[b][4 * jp + 2], v[b][4 * jp + 3]};
-      __builtin_nontemporal_store(q, p + (b * 2 + jp) * 64);
-    }
-}
-// ReLU derivative bits of NB blocks of accumulators: element (o, r) -> bit 31 - (16 (o & 1) + r) of dword o >> 1, 1 where
-// pre > 0 (the sign bit of 0 - pre: +0 and -0 both give 0, as jax's relu gradient does); a v_sub + a v_alignbit per element
-template <int NB>
-__device__ __forceinline__ void bf_signbits(unsigned (&mb)[(NB + 1) / 2], const f32x16 (&acc)[NB]) {
-#ifdef BF_EXP_NOBITS    // timing attribution only (results are wrong)
-  return;
-#endif
-#pragma unroll
-  for (int o = 0; o < NB; ++o)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) mb[o >> 1] = __builtin_amdgcn_alignbit(mb[o >> 1], __float_as_uint(__fsub_rn(0.f, acc[o][r])), 31);
-}
-// acc = 0 where the stashed pre-activation was not positive
-template <int NB>
-__device__ __forceinline__ void bf_mask(f32x16 (&acc)[NB], const unsigned (&mb)[(NB + 1) / 2]) {
-#ifdef BF_EXP_NOBITS
-  return;
-#endif
-#pragma unroll
-  for (int o = 0; o < NB; ++o)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int keep = __builtin_amdgcn_sbfe((int)mb[o >> 1], 31 - (16 * (o & 1) + r), 1);   // -1 where pre > 0
-      acc[o][r] = __uint_as_float(__float_as_uint(acc[o][r]) & (unsigned)keep);
-    }
+// One 256-wide layer of the forward chain, 4 panels of 2 blocks.  `in` = packed input (its blocks 6, 7 arrive from acc1 = the
+// previous layer's last panel during chunk 0 when PEND), out = packed output blocks 0..5; blocks 6, 7 stay pending in acc1.
+//   R: rows per panel (bias + k-steps); bsel(r): B operand of row r; PRELU / RELU: activation of the previous / this layer;
+//   st_prev / st: their stash groups (8 blocks each); mbp / mbn: their sign-bit words; b2_*: sizes of the chunks two ahead
+template <int R, bool PEND, bool PRELU, bool RELU, bool STASH, class BSel>
+__device__ __forceinline__ void layer256(ChainCtx& c, f32x16 (&acc0)[2], f32x16 (&acc1)[2], unsigned (&in)[8][8], unsigned (&out)[8][8],
+                                         unsigned (&mbp)[4], unsigned (&mbn)[4], const uint32_t* st_prev, const uint32_t* st,
+                                         int b2_01, int b2_23, int lane16, BSel bsel) {
+  const __amdgpu_buffer_rsrc_t rp3 = panel_rsrc(st_prev, 3), rn0 = panel_rsrc(st, 0), rn1 = panel_rsrc(st, 1), rn2 = panel_rsrc(st, 2);
+  constexpr int NF = 2 * R;
+  constexpr int SP0 = NF - 1 < 24 ? NF - 1 : 24;   // chunk 0: the pending blocks are this chunk's k-steps 12..15 (slots >= 26)
+  constexpr int OPP = epi_ops(PRELU, STASH), OPN = epi_ops(RELU, STASH);
+  if constexpr (PEND)
+    bf_chunk<2, R, true, SP0, OPP, STASH>(acc0, c.fr, c.rg, c.ll, c.wave, b2_01, bsel,
+        [&](int k) __attribute__((always_inline)) { panel_epi<SP0, 6, PRELU, STASH>(k, acc1, in, mbp[3], rp3, lane16); });
+  else
+    bf_chunk<2, R, true, 0, 0, false>(acc0, c.fr, c.rg, c.ll, c.wave, b2_01, bsel, [&](int) __attribute__((always_inline)) {});
+  bf_chunk<2, R, true, NF - 1, OPN, STASH>(acc1, c.fr, c.rg, c.ll, c.wave, b2_01, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 0, RELU, STASH>(k, acc0, out, mbn[0], rn0, lane16); });
+  bf_chunk<2, R, true, NF - 1, OPN, STASH>(acc0, c.fr, c.rg, c.ll, c.wave, b2_23, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 2, RELU, STASH>(k, acc1, out, mbn[1], rn1, lane16); });
+  bf_chunk<2, R, true, NF - 1, OPN, STASH>(acc1, c.fr, c.rg, c.ll, c.wave, b2_23, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 4, RELU, STASH>(k, acc0, out, mbn[2], rn2, lane16); });
 }
 
 __device__ __forceinline__ float bf_sigma(float x, int kind) {
   return kind == 1 ? fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))) : fmaxf(x, 0.f);
 }
 
-// chunk-0 byte counts of each GEMM of the chain (what the GEMM before it prefetches)
-constexpr int KB = 1024;
-constexpr int T0 = 40 * KB, T1 = 32 * KB;           // trunk GEMM: first chunk (bias row + 4 k-steps of 8 blocks), later chunks
-constexpr int BN0 = 45 * KB, BN1 = 36 * KB;         // bottleneck + alpha: 9 blocks
-constexpr int RG = 16 * KB;                         // rgb hidden: 4 blocks
-constexpr int LG0 = 20 * KB, LG1 = 16 * KB;         // rgb logits, padded to 4 blocks so that every chunk is whole 4-KiB groups
+// the ring's first two chunks, the first fragments
+__device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* wpk, int total, int bytes0, int bytes1, int lane, int wave) {
+  c.rg.src = reinterpret_cast<const char*>(wpk);
+  c.rg.voff = lane * 16;
+  c.rg.lds0 = lds_byte_addr(lds);
+  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0;
+  c.ll = lds + lane * 16; c.wave = wave;
+  bf_ring_copy(c.rg, 0, bytes0, wave);
+  bf_ring_copy(c.rg, 1, bytes1, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < BF_DF; ++i) c.fr[i] = *reinterpret_cast<const bf16x8*>(c.ll + i * BF_KB);
+}
 
 }  // namespace
 
-// NG sample groups of 32 per wave, NW waves per workgroup (NG * NW = 8): <2, 4> = one wave per SIMD with every weight fragment
-// feeding two MFMAs; <1, 8> = two waves per SIMD (latencies overlap) at twice the LDS reads per MFMA.
-template <int NG, int NW, bool STASH = false>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4, NW / 4))) void nerf_mlp_fwd_bf16_kernel(const ChainFwdArgs A) {
-  static_assert(!STASH || NG == 1, "the training stash is laid out for one 32-sample group per wave");
+// One workgroup (8 waves) per CU, 256 samples per workgroup iteration, one 32-sample group per wave.
+template <bool STASH>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_fwd_bf16_kernel(const ChainFwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int n = lane & 31, h = lane >> 5;
-  const int niter = (A.rows + 255) / 256;   // 256 samples per workgroup iteration (4 waves x 2 groups x 32)
+  const int niter = (A.rows + 255) / 256;
+  const bf16x8 bias_op = as_bf16x8(0x3F803F80u, 0u, 0u, 0u);   // B = 1 in k-slots 0, 1 (bias hi + lo)
 
-  BfStream st;
-  st.src = reinterpret_cast<const char*>(A.wpk) + lane * 16;
-  st.soff = 0;
-  st.cur = 0;
-  bf_dma<T0, NW>(st.src, 0, bf_lds, 0, wave);        // layer 0's only chunk
-  bf_dma<T0, NW>(st.src, T0, bf_lds, 1, wave);       // layer 1, chunk 0
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  ChainCtx c;
+  chain_start(c, bf_lds, A.wpk, FW_TOTAL, FW_L0, FW_L0, lane0, wave);
 
 #pragma unroll 1
   for (int it = blockIdx.x; it < niter; it += gridDim.x) {
-    int row[NG];
-    float x[NG][3];
+    int lo = lane0;
+    asm volatile("" : "+v"(lo));   // per-iteration opaque lane: nothing derived from it is hoisted out of the loop (and spilled)
+    const int lane = lo, n = lane & 31, h = lane >> 5;
+    const int lane16 = lane * 16;
+    const int row = it * 256 + wave * 32 + n;
+    const int rc = row < A.rows ? row : A.rows - 1;
+    float x[3];
+    if (A.points) {
+      x[0] = A.points[3 * rc]; x[1] = A.points[3 * rc + 1]; x[2] = A.points[3 * rc + 2];
+    } else {
+      const int ray = rc / A.S;
+      const float z = A.zvals[rc];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      row[g] = it * 256 + wave * 32 * NG + g * 32 + n;
-      const int r = row[g] < A.rows ? row[g] : A.rows - 1;
-      if (A.points) {
-        x[g][0] = A.points[3 * r]; x[g][1] = A.points[3 * r + 1]; x[g][2] = A.points[3 * r + 2];
-      } else {
-        const int ray = r / A.S;
-        const float z = A.zvals[r];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) x[g][c] = __fadd_rn(A.origins[3 * ray + c], __fmul_rn(z, A.directions[3 * ray + c]));
-      }
+      for (int k = 0; k < 3; ++k) x[k] = __fadd_rn(A.origins[3 * ray + k], __fmul_rn(z, A.directions[3 * ray + k]));
     }
-    const float half_pi = 1.57079632679489661923f;
+    const size_t gidx = (size_t)it * 8 + wave;   // this wave's group
     // SinusoidalEncoder (modules.py:213-228) in fp32, packed straight into B-operand registers
-    auto posenc = [&](unsigned (&pe)[NG][2][8]) {
+    unsigned pe[2][8];
+    {
+      const float half_pi = 1.57079632679489661923f;
 #pragma unroll
-      for (int g = 0; g < NG; ++g)
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float v[2];
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const int r16 = 2 * q + t;                                  // accumulator-style register index 4j + i
+            const int e = 32 * b + 8 * (r16 >> 2) + 4 * h + (r16 & 3);   // posenc feature
+            float val = 0.f;
+            if (e < 3) {
+              val = e == 0 ? x[0] : e == 1 ? x[1] : x[2];
+            } else if (e < A.P) {
+              const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, cc = rem >= 3 ? rem - 3 : rem;
+              const float a = __fmul_rn(cc == 0 ? x[0] : cc == 1 ? x[1] : x[2], (float)(1 << f));
+              val = __sinf(rem >= 3 ? __fadd_rn(a, half_pi) : a);   // v_sin_f32: ~1e-6 abs, far below the bf16 rounding that follows
+            }
+            v[t] = val;
+          }
+          pe[b][q] = pack_bf16(v[0], v[1]);
+        }
+      if constexpr (STASH) {
+        const __amdgpu_buffer_rsrc_t rp = panel_rsrc(A.bst.pe + gidx * 2 * BF_BLOCK_DW, 0);
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            float v[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const int r16 = 2 * q + t;                                  // accumulator-style register index 4j + i
-              const int e = 32 * b + 8 * (r16 >> 2) + 4 * h + (r16 & 3);   // posenc feature
-              float val = 0.f;
-              if (e < 3) {
-                val = e == 0 ? x[g][0] : e == 1 ? x[g][1] : x[g][2];
-              } else if (e < A.P) {
-                const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, c = rem >= 3 ? rem - 3 : rem;
-                const float a = __fmul_rn(c == 0 ? x[g][0] : c == 1 ? x[g][1] : x[g][2], (float)(1 << f));
-#ifdef BF_NOSIN
-                val = rem >= 3 ? __fadd_rn(a, half_pi) : a;
-#else
-                val = __sinf(rem >= 3 ? __fadd_rn(a, half_pi) : a);   // v_sin_f32: ~1e-6 abs, far below the bf16 rounding that follows
-#endif
-              }
-              v[t] = val;
-            }
-            pe[g][b][q] = pack_bf16(v[0], v[1]);
-          }
-    };
+          for (int jp = 0; jp < 2; ++jp)
+            bf_store16(rp, lane16 + (b * 2 + jp) * BF_KB, pe[b][4 * jp], pe[b][4 * jp + 1], pe[b][4 * jp + 2], pe[b][4 * jp + 3]);
+      }
+    }
 
-    // training stash: this wave's group
-    const size_t gidx = (size_t)it * 8 + wave;
-    auto stash_layer = [&](int l, const f32x16 (&acc)[NG][8], const unsigned (&packed)[NG][8][8]) {
+    unsigned ua[8][8], ub[8][8];
+    unsigned m0[4] = {0u, 0u, 0u, 0u}, m1[4] = {0u, 0u, 0u, 0u};
+    f32x16 acc0[2], acc1[2];
+    auto hst = [&](int l) __attribute__((always_inline)) { return A.bst.h + ((size_t)l * A.bst.ngroups + gidx) * 8 * BF_BLOCK_DW; };
+    auto store_bits = [&](int l, unsigned (&mb)[4]) __attribute__((always_inline)) {
       if constexpr (STASH) {
-        unsigned mb[4] = {0u, 0u, 0u, 0u};
-        bf_signbits<8>(mb, acc[0]);
         const u32x4v q = {mb[0], mb[1], mb[2], mb[3]};
         __builtin_nontemporal_store(q, reinterpret_cast<u32x4v*>(A.bst.bits) + ((size_t)l * A.bst.ngroups + gidx) * 64 + lane);
-        bf_store_blocks<8>(A.bst.h + ((size_t)l * A.bst.ngroups + gidx) * 8 * BF_BLOCK_DW, packed[0], lane);
+        mb[0] = mb[1] = mb[2] = mb[3] = 0u;
       }
     };
-
-    // ---- trunk ----
-    unsigned act[NG][8][8];
+    // ---- trunk: the packed activations alternate between ua and ub ----
+    layer256<5, false, true, true, STASH>(c, acc0, acc1, ua, ua, m1, m0, hst(0), hst(0), FW_L0, FW_T, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(pe, 1); });                           // L0: pe -> ua
+    layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(0), hst(1), FW_T, FW_T, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
+    store_bits(0, m0);
+    layer256<17, true, true, true, STASH>(c, acc0, acc1, ub, ua, m1, m0, hst(1), hst(2), FW_T, FW_T, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); });
+    store_bits(1, m1);
+    layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(2), hst(3), FW_T, FW_S, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
+    store_bits(2, m0);
+    layer256<21, true, true, true, STASH>(c, acc0, acc1, ub, ua, m1, m0, hst(3), hst(4), FW_S, FW_T, lane16,                      // skip: [h, posenc]
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : r <= 16 ? BF_ROWS(ub, 1) : BF_ROWS(pe, 17); });
+    store_bits(3, m1);
+    layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(4), hst(5), FW_T, FW_T, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
+    store_bits(4, m0);
+    layer256<17, true, true, true, STASH>(c, acc0, acc1, ub, ua, m1, m0, hst(5), hst(6), FW_T, FW_T, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); });
+    store_bits(5, m1);
+    layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(6), hst(7), FW_T, FW_T, lane16,
+        [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
+    store_bits(6, m0);
+    // ---- bottleneck (linear): h8 = ub -> ua; its chunks 2, 3 prefetch the alpha chunk and the rgb branch ----
+    const uint32_t* bnb = A.bst.bn + gidx * 8 * BF_BLOCK_DW;
+    unsigned mdummy = 0u;
     {
-      unsigned pe[NG][2][8];
-      posenc(pe);
-      if constexpr (STASH) bf_store_blocks<2>(A.bst.pe + gidx * 2 * BF_BLOCK_DW, pe[0], lane);
-      f32x16 acc[NG][8];
-      bf_gemm<NG, NW, 2, 8, true, T0, T1>(acc, pe, st, bf_lds, lane, wave);
-      bf_pack<NG, 8, true>(act, acc);
-      stash_layer(0, acc, act);
+      constexpr int NF = 34;
+      const __amdgpu_buffer_rsrc_t r73 = panel_rsrc(hst(7), 3), rb0 = panel_rsrc(bnb, 0), rb1 = panel_rsrc(bnb, 1), rb2 = panel_rsrc(bnb, 2);
+      auto bs = [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); };
+      bf_chunk<2, 17, true, 24, epi_ops(true, STASH), STASH>(acc0, c.fr, c.rg, c.ll, wave, FW_T, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi<24, 6, true, STASH>(k, acc1, ub, m1[3], r73, lane16); });
+      store_bits(7, m1);
+      bf_chunk<2, 17, true, NF - 1, 1, STASH>(acc1, c.fr, c.rg, c.ll, wave, FW_T, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 0, false, STASH>(k, acc0, ua, mdummy, rb0, lane16); });
+      bf_chunk<2, 17, true, NF - 1, 1, STASH>(acc0, c.fr, c.rg, c.ll, wave, FW_AL, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 2, false, STASH>(k, acc1, ua, mdummy, rb1, lane16); });
+      bf_chunk<2, 17, true, NF - 1, 1, STASH>(acc1, c.fr, c.rg, c.ll, wave, FW_RG, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 4, false, STASH>(k, acc0, ua, mdummy, rb2, lane16); });
     }
-#pragma unroll 1
-    for (int l = 1; l < TRUNK_DEPTH; ++l) {
-      f32x16 acc[NG][8];
-      if (l == SKIP_LAYER) {
-        unsigned pe[NG][2][8];
-        posenc(pe);   // before the accumulators come alive: the sin() temporaries would not fit next to 256 of them
-        bf_gemm<NG, NW, 8, 8, true, T1, T0>(acc, act, st, bf_lds, lane, wave);     // then the skip rows (one 32 KiB chunk), then layer 5
-        bf_gemm<NG, NW, 2, 8, false, T0, T1, false, false>(acc, pe, st, bf_lds, lane, wave);   // accumulates onto the h part
-      } else if (l == TRUNK_DEPTH - 1) {
-        bf_gemm<NG, NW, 8, 8, true, BN0, BN1>(acc, act, st, bf_lds, lane, wave);
-      } else {
-        bf_gemm<NG, NW, 8, 8, true, T0, T1>(acc, act, st, bf_lds, lane, wave);
-      }
-      bf_pack<NG, 8, true>(act, acc);
-      stash_layer(l, acc, act);
-    }
-
-    // ---- bottleneck (linear) + alpha head as the ninth output block ----
-    unsigned bn[NG][8][8];
-    float alpha_raw[NG];
+    // ---- alpha head: one block on h8 (row 0 = its bias; feature 0 = the raw density) ----
+    float alpha_raw;
     {
-      f32x16 acc9[NG][9];
-      bf_gemm<NG, NW, 8, 9, true, RG, RG>(acc9, act, st, bf_lds, lane, wave);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        alpha_raw[g] = acc9[g][8][0];
-#pragma unroll
-        for (int o = 0; o < 8; ++o)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) bn[g][o][q] = pack_bf16(acc9[g][o][2 * q], acc9[g][o][2 * q + 1]);
-      }
-      if constexpr (STASH) bf_store_blocks<8>(A.bst.bn + gidx * 8 * BF_BLOCK_DW, bn[0], lane);
+      f32x16 aa[1];
+      const __amdgpu_buffer_rsrc_t rb3 = panel_rsrc(bnb, 3);
+      bf_chunk<1, 17, true, 16, 1, STASH>(aa, c.fr, c.rg, c.ll, wave, FW_RG,
+          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); },
+          [&](int k) __attribute__((always_inline)) { panel_epi<16, 6, false, STASH>(k, acc1, ua, mdummy, rb3, lane16); });
+      alpha_raw = aa[0][0];
     }
-
-    // ---- rgb branch ----
-    unsigned rgbh[NG][4][8];
+    // ---- rgb branch: hidden 256 -> 128 (+ the fp32 per-ray condition term incl. bias), ReLU ----
+    unsigned rh[4][8];
+    const float* ct = A.condterm + (size_t)min(rc / A.S, A.B - 1) * RGB_W + 4 * h;
+    const uint32_t* rgb_ = A.bst.rgbh + gidx * 4 * BF_BLOCK_DW;
+    auto add_ct = [&](f32x16 (&acc)[2], int o0) __attribute__((always_inline)) {
+#pragma unroll
+      for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float4 c4 = *reinterpret_cast<const float4*>(ct + 32 * (o0 + o) + 8 * j);
+          acc[o][4 * j] += c4.x; acc[o][4 * j + 1] += c4.y; acc[o][4 * j + 2] += c4.z; acc[o][4 * j + 3] += c4.w;
+        }
+    };
     {
-      f32x16 acc4[NG][4];
-      bf_gemm<NG, NW, 8, 4, false, LG0, LG1>(acc4, bn, st, bf_lds, lane, wave);
-#pragma unroll
-      for (int g = 0; g < NG; ++g) {
-        const int r = row[g] < A.rows ? row[g] : A.rows - 1;
-        const float* ct = A.condterm + (size_t)min(r / A.S, A.B - 1) * RGB_W;   // fp32 per-ray term incl. bias
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 c4 = *reinterpret_cast<const float4*>(ct + 32 * o + 8 * j + 4 * h);
-            acc4[g][o][4 * j] += c4.x; acc4[g][o][4 * j + 1] += c4.y; acc4[g][o][4 * j + 2] += c4.z; acc4[g][o][4 * j + 3] += c4.w;
-          }
-      }
-      bf_pack<NG, 4, true>(rgbh, acc4);
+      const __amdgpu_buffer_rsrc_t rg0 = panel_rsrc(rgb_, 0);
+      auto bs = [&](int r) __attribute__((always_inline)) { return BF_ROWS(ua, 0); };
+      bf_chunk<2, 16, true, 0, 0, false>(acc0, c.fr, c.rg, c.ll, wave, FW_LG, bs, [&](int) __attribute__((always_inline)) {});
+      add_ct(acc0, 0);
+      bf_chunk<2, 16, true, 31, epi_ops(true, STASH), STASH>(acc1, c.fr, c.rg, c.ll, wave, FW_L0, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi<31, 0, true, STASH>(k, acc0, rh, m0[0], rg0, lane16); });
+      add_ct(acc1, 2);
+    }
+    // ---- rgb logits: 128 -> 3 (one block), sigmoid; the chain restarts (layer 0 of the next iteration is being copied);
+    //      the pending panel (rgb hidden blocks 2, 3) is this chunk's k-steps 4..7: its 16 units ride in slots 1..4 ----
+    {
+      f32x16 lg[1];
+      const __amdgpu_buffer_rsrc_t rg1 = panel_rsrc(rgb_, 1);
+      bf_chunk<1, 9, true, 4, epi_ops(true, STASH), STASH>(lg, c.fr, c.rg, c.ll, wave, FW_L0,
+          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(rh, 1); },
+          [&](int k) __attribute__((always_inline)) { panel_epi<4, 2, true, STASH>(k, acc1, rh, m0[1], rg1, lane16); });
       if constexpr (STASH) {
-        unsigned mb[2] = {0u, 0u};
-        bf_signbits<4>(mb, acc4[0]);
-        const u32x4v q = {mb[0], mb[1], 0u, 0u};
+        const u32x4v q = {m0[0], m0[1], 0u, 0u};
         __builtin_nontemporal_store(q, reinterpret_cast<u32x4v*>(A.bst.bits) + ((size_t)8 * A.bst.ngroups + gidx) * 64 + lane);
-        bf_store_blocks<4>(A.bst.rgbh + gidx * 4 * BF_BLOCK_DW, rgbh[0], lane);
+      }
+      if (h == 0 && row < A.rows) {
+        float4 o;
+        o.x = 1.f / (1.f + expf(-lg[0][0]));
+        o.y = 1.f / (1.f + expf(-lg[0][1]));
+        o.z = 1.f / (1.f + expf(-lg[0][2]));
+        float araw = alpha_raw;
+        if (A.noise_std > 0.f)   // model_utils.noise_regularize (model_utils.py:266-282)
+          araw += A.noise_std * (A.noise ? A.noise[row]
+                                         : philox_normal(A.dyn ? A.dyn->rng_seed : A.noise_seed, A.dyn ? A.dyn->rng_offset : A.noise_offset, A.noise_stream, (uint32_t)row));
+        o.w = bf_sigma(araw, A.sigma_act);
+        A.out4[row] = o;
       }
     }
-    f32x16 acc1[NG][4];   // blocks 1..3 are padding (zero weights)
-    bf_gemm<NG, NW, 4, 4, true, T0, T0, true>(acc1, rgbh, st, bf_lds, lane, wave);   // then the chain restarts: layer 0, layer 1
-#pragma unroll
-    for (int g = 0; g < NG; ++g)
-      if (h == 0 && row[g] < A.rows) {
-        float4 o;
-        o.x = 1.f / (1.f + expf(-acc1[g][0][0]));
-        o.y = 1.f / (1.f + expf(-acc1[g][0][1]));
-        o.z = 1.f / (1.f + expf(-acc1[g][0][2]));
-        float araw = alpha_raw[g];
-        if (A.noise_std > 0.f)   // model_utils.noise_regularize (model_utils.py:266-282)
-          araw += A.noise_std * (A.noise ? A.noise[row[g]]
-                                         : philox_normal(A.dyn ? A.dyn->rng_seed : A.noise_seed, A.dyn ? A.dyn->rng_offset : A.noise_offset, A.noise_stream, (uint32_t)row[g]));
-        o.w = bf_sigma(araw, A.sigma_act);
-        A.out4[row[g]] = o;
-      }
   }
 }
 
@@ -430,17 +302,57 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 4,
 // data-gradient chain (training): d raw (rgb, sigma) -> dpre of every layer, stored for wgrad_bf16.hip
 // ---------------------------------------------------------------------------------------------
 namespace {
-// chunk byte counts of the dgrad weight stream (GEMMs in execution order, one chunk = 4 k-steps x NOUT KiB):
-//   G1  logit^T   K = 32 (3 valid) padded to one 4-k-step chunk -> 128:   DG1
-//   G2  rgbh^T    K = 128 -> 256:                                          2 x DG
-//   G3  bn^T      K = 256 -> 256, first chunk carries the alpha row:      DG3, 3 x DG
-//   L7..L1        K = 256 -> 256:                                          4 x DG each
-//   warp on, after L1:  P0  W0^T   K = 256 -> 64 (d posenc through layer 0),  P4  W4[256:]^T  K = 256 -> 64 (skip rows):  4 x DP each
-constexpr int DG1 = 16 * KB, DG = 32 * KB, DG3 = 40 * KB, DP = 8 * KB;
+// dgrad weight stream, chunks in execution order (panel = 2 output blocks unless noted):
+//   G1  logit^T   K = 3 of one k-step (+ a zero k-step), all 4 blocks of the rgb hidden layer in one panel      8 KiB
+//   G2  rgbh^T    K = 128 (8 k-steps) -> 256                                                                     4 x 16
+//   G3  bn^T      K = 256 -> 256, row 0 = the alpha row (B = d sigma)                                             4 x 34
+//   L7..L1        K = 256 -> 256                                                                                  7 x 4 x 32
+//   warp on:  P0  W0^T  256 -> 64 (d posenc through layer 0),  P4  W4[256:]^T  256 -> 64 (skip rows, accumulates)  2 x 32
+constexpr int DG1 = 8 * BF_KB, DG2 = 16 * BF_KB, DG3 = 34 * BF_KB, DGL = 32 * BF_KB, DGP = 32 * BF_KB;
+constexpr int BW_TOTAL = DG1 + 4 * DG2 + 4 * DG3 + 28 * DGL;
+static_assert(BW_TOTAL == BF_BWD_STREAM_KB * BF_KB && BW_TOTAL + 2 * DGP == BF_BWD_STREAM_DPTS_KB * BF_KB, "dgrad stream length (nrf_internal.h)");
+
+// Backward units: accumulators -> bf16 pairs -> (MASK: zero where the stashed ReLU bit is clear) -> out, 1 KiB store per half block
+template <int SPAN, int O0, bool MASK, int PO = 0, int NBLK, int NP>
+__device__ __forceinline__ void panel_epi_bwd(int k, const f32x16 (&pend)[NP], unsigned (&out)[NBLK][8], unsigned mb,
+                                              __amdgpu_buffer_rsrc_t rs, int lane16) {
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    if (epi_slot(u, 16, SPAN) != k) continue;
+    const int o = u >> 3, q = u & 7;
+    unsigned pk = pack_bf16(pend[PO + o][2 * q], pend[PO + o][2 * q + 1]);
+    if (MASK) pk = bits_mask(pk, mb, u);
+    out[O0 + o][q] = pk;
+    if ((q & 3) == 3) {
+      const int jp = q >> 2;
+      bf_store16(rs, lane16 + (o * 2 + jp) * BF_KB, out[O0 + o][4 * jp], out[O0 + o][4 * jp + 1], out[O0 + o][4 * jp + 2],
+                 out[O0 + o][4 * jp + 3]);
+    }
+  }
+}
+constexpr int BW_OPS_MASK = 4, BW_OPS_LIN = 1;   // VALU per unit: pack (+ shift, shift, and)
+
+// One 256 -> 256 layer of the dgrad chain: in = dpre_l (blocks 6, 7 from acc1 during chunk 0), out = masked d h_{l-1} = dpre_{l-1}
+// blocks 0..5, blocks 6, 7 pending in acc1.  PMASK / mbp3 / st_prev: the previous GEMM's epilogue (its last panel); mb / st: this one's.
+template <int R, bool PMASK, class BSel>
+__device__ __forceinline__ void layer256_bwd(ChainCtx& c, f32x16 (&acc0)[2], f32x16 (&acc1)[2], unsigned (&in)[8][8], unsigned (&out)[8][8],
+                                             unsigned mbp3, const u32x4v& mb, const uint32_t* st_prev, const uint32_t* st,
+                                             int b2_01, int b2_2, int b2_3, int lane16, BSel bsel) {
+  const __amdgpu_buffer_rsrc_t rp3 = panel_rsrc(st_prev, 3), rn0 = panel_rsrc(st, 0), rn1 = panel_rsrc(st, 1), rn2 = panel_rsrc(st, 2);
+  constexpr int NF = 2 * R;
+  constexpr int SP0 = 22;   // chunk 0: the pending blocks are this chunk's k-steps 12..15 (slots >= 24 without a bias row)
+  bf_chunk<2, R, true, SP0, PMASK ? BW_OPS_MASK : BW_OPS_LIN, true>(acc0, c.fr, c.rg, c.ll, c.wave, b2_01, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi_bwd<SP0, 6, PMASK>(k, acc1, in, mbp3, rp3, lane16); });
+  bf_chunk<2, R, true, NF - 1, BW_OPS_MASK, true>(acc1, c.fr, c.rg, c.ll, c.wave, b2_01, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi_bwd<NF - 1, 0, true>(k, acc0, out, mb.x, rn0, lane16); });
+  bf_chunk<2, R, true, NF - 1, BW_OPS_MASK, true>(acc0, c.fr, c.rg, c.ll, c.wave, b2_2, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi_bwd<NF - 1, 2, true>(k, acc1, out, mb.y, rn1, lane16); });
+  bf_chunk<2, R, true, NF - 1, BW_OPS_MASK, true>(acc1, c.fr, c.rg, c.ll, c.wave, b2_3, bsel,
+      [&](int k) __attribute__((always_inline)) { panel_epi_bwd<NF - 1, 4, true>(k, acc0, out, mb.z, rn2, lane16); });
+}
 }  // namespace
 
-// Both levels in ONE launch (round 2: two launches of 256 and 768 iterations on 256 workgroups -- one iteration per workgroup for
-// the coarse level, i.e. pure ramp): workgroups [0, n0) walk level 0, the rest level 1, split in proportion to the levels'
+// Both levels in ONE launch: workgroups [0, n0) walk level 0, the rest level 1, split in proportion to the levels'
 // iteration counts, so every workgroup runs the same number of iterations of ONE level (its weight stream never switches).
 // The level's arguments are indexed in the kernarg segment (scalar loads).
 struct ChainBwdBf16Args2 { ChainBwdBf16Args a[2]; int n0; };
@@ -451,102 +363,132 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wg0 = lvl ? (int)blockIdx.x - P.n0 : (int)blockIdx.x;        // this workgroup's index inside its level
   const int wgn = lvl ? (int)gridDim.x - P.n0 : P.n0;                    // workgroups of its level
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
-  constexpr int NW = 8;
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int niter = (A.rows + 255) / 256;
   const BfStash& S = A.st;
 
-  BfStream st;
-  st.src = reinterpret_cast<const char*>(A.wpk) + lane0 * 16;
-  st.soff = 0;
-  st.cur = 0;
-  bf_dma<DG1, NW>(st.src, 0, bf_lds, 0, wave);      // G1
-  bf_dma<DG, NW>(st.src, DG1, bf_lds, 1, wave);     // G2, chunk 0
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  ChainCtx c;
+  chain_start(c, bf_lds, A.wpk, BW_TOTAL + (DPTS ? 2 * DGP : 0), DG1, DG2, lane0, wave);
 
 #pragma unroll 1
   for (int it = wg0; it < niter; it += wgn) {
     int lo = lane0;
-    asm volatile("" : "+v"(lo));   // per-iteration opaque lane: see mlp_chain.hip's backward tile
+    asm volatile("" : "+v"(lo));   // per-iteration opaque lane (see the forward kernel)
     const int lane = lo, n = lane & 31, h = lane >> 5;
+    const int lane16 = lane * 16;
     const size_t gidx = (size_t)it * 8 + wave;
     const int row = it * 256 + wave * 32 + n;
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < A.rows) d = A.d_raw4[row];
-    auto bits_of = [&](int l) {   // nrf_internal.h BfStash::bits
+    auto bits_of = [&](int l) __attribute__((always_inline)) {   // nrf_internal.h BfStash::bits
       return __builtin_nontemporal_load(reinterpret_cast<const u32x4v*>(S.bits) + ((size_t)l * S.ngroups + gidx) * 64 + lane);
     };
+    auto dyst = [&](int l) __attribute__((always_inline)) { return S.dy + ((size_t)l * S.ngroups + gidx) * 8 * BF_BLOCK_DW; };
 
     // ---- d raw -> the "small" dY block (features 0..3 = d rgb logits, d raw sigma) ----
-    unsigned dsm[1][2][8];
+    unsigned dsm[4];
+    dsm[0] = h == 0 ? pack_bf16(d.x, d.y) : 0u;
+    dsm[1] = h == 0 ? pack_bf16(d.z, d.w) : 0u;
+    dsm[2] = dsm[3] = 0u;
+    {
+      const __amdgpu_buffer_rsrc_t rsm = panel_rsrc(S.dsmall + gidx * 2 * BF_BLOCK_DW, 0);
+      bf_store16(rsm, lane16, dsm[0], dsm[1], 0u, 0u);
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) dsm[0][b][q] = 0u;
-    if (h == 0) { dsm[0][0][0] = pack_bf16(d.x, d.y); dsm[0][0][1] = pack_bf16(d.z, d.w); }
-    bf_store_blocks<2>(S.dsmall + gidx * 2 * BF_BLOCK_DW, dsm[0], lane);
+      for (int i = 1; i < 4; ++i) bf_store16(rsm, lane16 + i * BF_KB, 0u, 0u, 0u, 0u);
+    }
     const unsigned dsig2 = pack_bf16(d.w, d.w);
+    const u32x4v mq8 = bits_of(8);
 
-    // ---- G1: d rgb hidden = W_logit . d logits (K index 3 = d sigma meets a zero weight row), ReLU mask ----
-    unsigned drg[1][4][8];
+    unsigned ua[8][8], ub[8][8];
+    f32x16 acc0[2], acc1[2];
+    // ---- G1: d rgb hidden = W_logit . d logits (K index 3 = d sigma meets a zero weight row), ReLU mask of the rgb hidden layer;
+    //      one panel of 4 blocks; its epilogue runs behind it (G2's first k-step already needs block 0) ----
+    unsigned drg[4][8];
     {
-      f32x16 acc4[1][4];
-      bf_gemm<1, NW, 2, 4, false, DG, DG>(acc4, dsm, st, bf_lds, lane, wave);
-      const u32x4v mq = bits_of(8);
-      const unsigned mb[2] = {mq.x, mq.y};
-      bf_mask<4>(acc4[0], mb);
-      bf_pack<1, 4, false>(drg, acc4);
-      bf_store_blocks<4>(S.drgbh + gidx * 4 * BF_BLOCK_DW, drg[0], lane);
+      f32x16 g1[4];
+      bf_chunk<4, 2, true, 0, 0, false>(g1, c.fr, c.rg, c.ll, wave, DG2,
+          [&](int r) __attribute__((always_inline)) { return as_bf16x8(dsm[0], dsm[1], dsm[2], dsm[3]); },
+          [&](int) __attribute__((always_inline)) {});
+      const uint32_t* gb = S.drgbh + gidx * 4 * BF_BLOCK_DW;
+      const __amdgpu_buffer_rsrc_t r0 = panel_rsrc(gb, 0), r1 = panel_rsrc(gb, 1);
+#pragma unroll
+      for (int k = 1; k <= 16; ++k) panel_epi_bwd<16, 0, true, 0>(k, g1, drg, mq8.x, r0, lane16);
+#pragma unroll
+      for (int k = 1; k <= 16; ++k) panel_epi_bwd<16, 2, true, 2>(k, g1, drg, mq8.y, r1, lane16);
     }
-    // ---- G2: d bottleneck = W_rgbh[0:256] . d rgb hidden (linear) ----
-    unsigned dy[1][8][8];
+    // ---- G2: d bottleneck = W_rgbh[0:256] . d rgb hidden (linear): -> ub blocks 0..5, blocks 6, 7 pending ----
+    const uint32_t* dbn = S.dbn + gidx * 8 * BF_BLOCK_DW;
     {
-      f32x16 acc[1][8];
-      bf_gemm<1, NW, 4, 8, false, DG3, DG>(acc, drg, st, bf_lds, lane, wave);
-      bf_pack<1, 8, false>(dy, acc);
-      bf_store_blocks<8>(S.dbn + gidx * 8 * BF_BLOCK_DW, dy[0], lane);
+      const __amdgpu_buffer_rsrc_t rn0 = panel_rsrc(dbn, 0), rn1 = panel_rsrc(dbn, 1), rn2 = panel_rsrc(dbn, 2);
+      auto bs = [&](int r) __attribute__((always_inline)) { return BF_ROWS(drg, 0); };
+      bf_chunk<2, 8, true, 0, 0, false>(acc0, c.fr, c.rg, c.ll, wave, DG2, bs, [&](int) __attribute__((always_inline)) {});
+      bf_chunk<2, 8, true, 15, BW_OPS_LIN, true>(acc1, c.fr, c.rg, c.ll, wave, DG2, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<15, 0, false>(k, acc0, ub, 0u, rn0, lane16); });
+      bf_chunk<2, 8, true, 15, BW_OPS_LIN, true>(acc0, c.fr, c.rg, c.ll, wave, DG3, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<15, 2, false>(k, acc1, ub, 0u, rn1, lane16); });
+      bf_chunk<2, 8, true, 15, BW_OPS_LIN, true>(acc1, c.fr, c.rg, c.ll, wave, DG3, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<15, 4, false>(k, acc0, ub, 0u, rn2, lane16); });
     }
-    // ---- G3: d h8 = W_bn . d bottleneck + w_alpha d sigma (the extra k-step), mask of layer 7 -> dpre_7 ----
+    // ---- G3: d h8 = W_bn . d bottleneck + w_alpha d sigma (row 0), mask of layer 7 -> dpre_7: ub -> ua ----
+    u32x4v mq = bits_of(7);
     {
-      f32x16 acc[1][8];
-      bf_gemm<1, NW, 8, 8, true, DG, DG>(acc, dy, st, bf_lds, lane, wave, dsig2);
-      const u32x4v mq = bits_of(7);
-      const unsigned mb[4] = {mq.x, mq.y, mq.z, mq.w};
-      bf_mask<8>(acc[0], mb);
-      bf_pack<1, 8, false>(dy, acc);
-      bf_store_blocks<8>(S.dy + ((size_t)7 * S.ngroups + gidx) * 8 * BF_BLOCK_DW, dy[0], lane);
+      constexpr int NF = 34;
+      const __amdgpu_buffer_rsrc_t rp3 = panel_rsrc(dbn, 3);
+      const uint32_t* st = dyst(7);
+      const __amdgpu_buffer_rsrc_t rn0 = panel_rsrc(st, 0), rn1 = panel_rsrc(st, 1), rn2 = panel_rsrc(st, 2);
+      auto bs = [&](int r) __attribute__((always_inline)) { return r == 0 ? as_bf16x8(dsig2, 0u, 0u, 0u) : BF_ROWS(ub, 1); };
+      bf_chunk<2, 17, true, 24, BW_OPS_LIN, true>(acc0, c.fr, c.rg, c.ll, wave, DG3, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<24, 6, false>(k, acc1, ub, 0u, rp3, lane16); });
+      bf_chunk<2, 17, true, NF - 1, BW_OPS_MASK, true>(acc1, c.fr, c.rg, c.ll, wave, DG3, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<NF - 1, 0, true>(k, acc0, ua, mq.x, rn0, lane16); });
+      bf_chunk<2, 17, true, NF - 1, BW_OPS_MASK, true>(acc0, c.fr, c.rg, c.ll, wave, DGL, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<NF - 1, 2, true>(k, acc1, ua, mq.y, rn1, lane16); });
+      bf_chunk<2, 17, true, NF - 1, BW_OPS_MASK, true>(acc1, c.fr, c.rg, c.ll, wave, DGL, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<NF - 1, 4, true>(k, acc0, ua, mq.z, rn2, lane16); });
     }
-    // ---- l = 7..1: d h_l = W_l[0:256] . dpre_l, mask of layer l-1 -> dpre_{l-1} ----
-#pragma unroll 1
-    for (int l = TRUNK_DEPTH - 1; l >= 1; --l) {
-      f32x16 acc[1][8];
-      if (l > 1)      bf_gemm<1, NW, 8, 8, false, DG, DG>(acc, dy, st, bf_lds, lane, wave);
-      else if (DPTS)  bf_gemm<1, NW, 8, 8, false, DP, DP>(acc, dy, st, bf_lds, lane, wave);          // then the d posenc GEMMs
-      else            bf_gemm<1, NW, 8, 8, false, DG1, DG, true>(acc, dy, st, bf_lds, lane, wave);   // then the stream restarts: G1, G2
-      const u32x4v mq = bits_of(l - 1);
-      const unsigned mb[4] = {mq.x, mq.y, mq.z, mq.w};
-      bf_mask<8>(acc[0], mb);
-      bf_pack<1, 8, false>(dy, acc);
-      bf_store_blocks<8>(S.dy + ((size_t)(l - 1) * S.ngroups + gidx) * 8 * BF_BLOCK_DW, dy[0], lane);
+    // ---- l = 7..1: d h_l = W_l[0:256] . dpre_l, mask of layer l-1 -> dpre_{l-1}; the arrays alternate ----
+    // after L1 the stream continues with the d posenc GEMMs (DPTS) or restarts with G1, G2
+    constexpr int AFTER_A = DPTS ? DGP : DG1, AFTER_B = DPTS ? DGP : DG2;
+#define BW_LAYER(L, IN, OUT, B2, B3)                                                                                        \
+    {                                                                                                                        \
+      const unsigned mbp3 = mq.w;                                                                                            \
+      mq = bits_of((L) - 1);                                                                                                 \
+      layer256_bwd<16, true>(c, acc0, acc1, IN, OUT, mbp3, mq, dyst(L), dyst((L) - 1), DGL, B2, B3, lane16,                  \
+          [&](int r) __attribute__((always_inline)) { return BF_ROWS(IN, 0); });                                            \
     }
-    // ---- warp on: d posenc = W0 . dpre_0 + W4[256:] . dpre_4 (two 256 -> 64 GEMMs), chain rule through SinusoidalEncoder
-    //      (modules.py:213-228) -> d points, float32, for the warp field's backward ----
-    if constexpr (DPTS) {
-      f32x16 ape[1][2];
-      bf_gemm<1, NW, 8, 2, false, DP, DP>(ape, dy, st, bf_lds, lane, wave);   // dy = dpre_0
-      {   // dpre_4 back from its stash (stored four GEMMs ago by this wave; every vmcnt wait since has retired it)
-        const u32x4v* src = reinterpret_cast<const u32x4v*>(S.dy + ((size_t)SKIP_LAYER * S.ngroups + gidx) * 8 * BF_BLOCK_DW) + lane;
+    BW_LAYER(7, ua, ub, DGL, DGL)
+    BW_LAYER(6, ub, ua, DGL, DGL)
+    BW_LAYER(5, ua, ub, DGL, DGL)
+    BW_LAYER(4, ub, ua, DGL, DGL)
+    BW_LAYER(3, ua, ub, DGL, DGL)
+    BW_LAYER(2, ub, ua, DGL, DGL)
+    BW_LAYER(1, ua, ub, AFTER_A, AFTER_B)
+#undef BW_LAYER
+    // dpre_0 = ub: blocks 0..5 stored, blocks 6, 7 pending in acc1 (mask word mq.w, stash dyst(0) panel 3)
+    if constexpr (!DPTS) {
+      const __amdgpu_buffer_rsrc_t rp3 = panel_rsrc(dyst(0), 3);
+#pragma unroll
+      for (int k = 1; k <= 16; ++k) panel_epi_bwd<16, 6, true>(k, acc1, ub, mq.w, rp3, lane16);
+    } else {
+      // ---- warp on: d posenc = W0 . dpre_0 + W4[256:] . dpre_4 (two 256 -> 64 GEMMs into one accumulator panel), chain rule
+      //      through SinusoidalEncoder (modules.py:213-228) -> d points, float32, for the warp field's backward ----
+      const __amdgpu_buffer_rsrc_t rp3 = panel_rsrc(dyst(0), 3);
+      {   // dpre_4 back from its stash (stored four layers ago by this wave; the waits since have retired it); ua is free: the loads fly under P0
+        const u32x4v* src = reinterpret_cast<const u32x4v*>(dyst(SKIP_LAYER)) + lane;
 #pragma unroll
         for (int b = 0; b < 8; ++b)
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
             const u32x4v q = src[(b * 2 + jp) * 64];
-            dy[0][b][4 * jp] = q.x; dy[0][b][4 * jp + 1] = q.y; dy[0][b][4 * jp + 2] = q.z; dy[0][b][4 * jp + 3] = q.w;
+            ua[b][4 * jp] = q.x; ua[b][4 * jp + 1] = q.y; ua[b][4 * jp + 2] = q.z; ua[b][4 * jp + 3] = q.w;
           }
       }
-      bf_gemm<1, NW, 8, 2, false, DG1, DG, true, false>(ape, dy, st, bf_lds, lane, wave);   // += ; then the stream restarts
+      bf_chunk<2, 16, true, 22, BW_OPS_MASK, true>(acc0, c.fr, c.rg, c.ll, wave, DG1,
+          [&](int r) __attribute__((always_inline)) { return BF_ROWS(ub, 0); },
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<22, 6, true>(k, acc1, ub, mq.w, rp3, lane16); });
+      bf_chunk<2, 16, false, 0, 0, false>(acc0, c.fr, c.rg, c.ll, wave, DG2,
+          [&](int r) __attribute__((always_inline)) { return BF_ROWS(ua, 0); }, [&](int) __attribute__((always_inline)) {});
       const int r = row < A.rows ? row : A.rows - 1;
       const float x[3] = {A.points[3 * r], A.points[3 * r + 1], A.points[3 * r + 2]};
       const float half_pi = 1.57079632679489661923f;
@@ -556,20 +498,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
           const int e = 32 * o + 8 * (rr >> 2) + 4 * h + (rr & 3);   // posenc feature of this accumulator register
-          const float g = ape[0][o][rr];
+          const float g = acc0[o][rr];
           if (e < 3) {
             dx[0] += e == 0 ? g : 0.f; dx[1] += e == 1 ? g : 0.f; dx[2] += e == 2 ? g : 0.f;
           } else if (e < A.P) {
-            const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, c = rem >= 3 ? rem - 3 : rem;
+            const int idx = e - 3, f = idx / 6, rem = idx - 6 * f, cc = rem >= 3 ? rem - 3 : rem;
             const float fr = (float)(1 << f);
-            const float a = __fmul_rn(c == 0 ? x[0] : c == 1 ? x[1] : x[2], fr);
+            const float a = __fmul_rn(cc == 0 ? x[0] : cc == 1 ? x[1] : x[2], fr);
             // d sin(a) = fr cos(a) = fr sin(a + pi/2);  d sin(a + pi/2) = fr sin(a + pi)
             const float dv = fr * __sinf(rem >= 3 ? __fadd_rn(a, 2.f * half_pi) : __fadd_rn(a, half_pi)) * g;
-            dx[0] += c == 0 ? dv : 0.f; dx[1] += c == 1 ? dv : 0.f; dx[2] += c == 2 ? dv : 0.f;
+            dx[0] += cc == 0 ? dv : 0.f; dx[1] += cc == 1 ? dv : 0.f; dx[2] += cc == 2 ? dv : 0.f;
           }
         }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) dx[c] += __shfl_xor(dx[c], 32);   // the two lane halves hold different features of the sample
+      for (int k = 0; k < 3; ++k) dx[k] += __shfl_xor(dx[k], 32);   // the two lane halves hold different features of the sample
       if (h == 0 && row < A.rows_pad) {
         float* o = A.d_points + (size_t)row * 3;
         o[0] = dx[0]; o[1] = dx[1]; o[2] = dx[2];
@@ -579,7 +521,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 void launch_chain_bwd_bf16(const ChainBwdBf16Args& a0, const ChainBwdBf16Args* a1, int max_grid, hipStream_t stream) {
-  const size_t lds = 3 * BF_BUF_BYTES;
+  const size_t lds = BF_LDS_BYTES;
   const int it0 = (a0.rows + 255) / 256, it1 = a1 ? (a1->rows + 255) / 256 : 0;
   int grid = it0 + it1 < max_grid ? it0 + it1 : max_grid;
   int n0 = grid;
@@ -632,9 +574,11 @@ void launch_dray_bf16(const uint32_t* drgbh, int B, int S, float* dray, hipStrea
 }
 
 namespace {
-// One descriptor fills rows of the weight stream.  kind 0: `nrows` k-step rows of a GEMM (row = 2b + s), out blocks
-// o0 .. o0 + nout of a GEMM that is nout_panel blocks wide; lane (m, h) gets 8 bf16: slot e <-> K index
-// 32b + 8(2s + e/4) + 4h + e%4.  kind 1: the bias row: slots 0/1 of the h = 0 lanes = bf16 hi / lo parts of bias[32o + m].
+// One descriptor fills rows of ONE chunk (panel) of a weight stream: [row][block of the panel][lane] x 16 B.
+//   kind 0: `ngroups` k-step rows (row = 2b + s) of output blocks oblk0 .. oblk0 + nout of the GEMM; lane (m, h) gets 8 bf16:
+//           slot e <-> K index 32b + 8(2s + e/4) + 4h + e%4, column 32 (oblk0 + o) + m.
+//   kind 1: the bias row: slots 0/1 of the h = 0 lanes = bf16 hi / lo parts of bias[column].
+// dst_off = first row written; nout_panel = blocks per row of the chunk.
 __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __restrict__ descs, const float* __restrict__ params,
                                                         float* __restrict__ ws) {
   const RcPackDesc d = descs[blockIdx.y];
@@ -643,7 +587,7 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63, o = (idx >> 6) % d.nout, rowi = (idx >> 6) / d.nout;
     const int m = lane & 31, h = lane >> 5, b = rowi >> 1, s = rowi & 1;
-    const int col = 32 * o + m;
+    const int col = 32 * (d.oblk0 + o) + m;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (d.kind == 1) {
       if (h == 0 && col < d.ncols) {
@@ -668,24 +612,17 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
 }  // namespace
 
 void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream) {
-  if (ndesc > 0) bf16_pack_kernel<<<dim3(32, ndesc), 256, 0, stream>>>(descs, params, ws);
+  if (ndesc > 0) bf16_pack_kernel<<<dim3(8, ndesc), 256, 0, stream>>>(descs, params, ws);
 }
 
 void launch_chain_fwd_bf16(const ChainFwdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = 3 * BF_BUF_BYTES;
+  const size_t lds = BF_LDS_BYTES;
   if (a.bst.h) {   // training: stash every layer's packed output + sign bits
-    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<1, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<1, 8, true>), dim3(grid), dim3(512), lds, stream, a);
-    return;
-  }
-  // measured (8192 rays x 256 samples): <1, 8> 3.44 ms, <2, 4> 4.30 ms for the fine level -> two waves per SIMD by default
-  static const bool w8 = getenv("NRF_BF16_W4") == nullptr;
-  if (w8) {
-    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<1, 8>), dim3(grid), dim3(512), lds, stream, a);
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<true>), dim3(grid), dim3(512), lds, stream, a);
   } else {
-    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<2, 4>), dim3(grid), dim3(256), lds, stream, a);
+    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<false>), dim3(grid), dim3(512), lds, stream, a);
   }
 }
 

@@ -55,6 +55,7 @@ struct WsPlan {
   size_t pack_off_b, groups_off_b, reduce_off_b, segs_off_b, segbegin_off_b, emb_off_b;
   size_t bf_desc = 0;
   std::vector<RcPackDesc> bfpack;
+  bool bf_stream_ok = true;   // the chunk tables emitted by build_plan add up to the stream lengths the kernels walk
   size_t iparams = 0, igrad = 0;   // zero-padded parameter image / its gradient (models narrower than the kernels)
   std::vector<WgradSegment> segs;
   std::vector<int> seg_begin;
@@ -574,52 +575,57 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     if (train) p.igrad = take((size_t)h->nparams);
   }
   p.bfpack.clear();
-  if (!train || bft) {   // weight stream of the bf16 forward (mlp_bf16.hip), GEMMs in execution order, rows of nout KiB
+  if (!train || bft) {   // weight streams of the bf16 chains (mlp_bf16.hip): chunks (panels) in execution order
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
-      const size_t stream_floats = (size_t)(40 + 7 * 136 + 32 + 153 + 64 + 36 + 64) * 256;   // KiB -> floats, + slack
-      p.L[lv].bf_wpk = take(stream_floats);
+      p.L[lv].bf_wpk = take((size_t)BF_FWD_STREAM_KB * 256);   // KiB -> floats
       size_t at = 0;   // floats from the level's stream base
       size_t base = p.L[lv].bf_wpk;
       int tr = 0;
-      auto emit = [&](int kind, int64_t src, int ld, int row0, int krows, int ncols, int nrows, int nout, int npanel, int o0) {
-        RcPackDesc e;
-        memset(&e, 0, sizeof(e));
-        e.src_off = src; e.dst_off = (long long)(base + at); e.kind = kind; e.src_ld = ld; e.row0 = row0; e.krows = krows;
-        e.ncols = ncols; e.ngroups = nrows; e.nout = nout; e.nout_panel = npanel; e.o0 = o0; e.transposed = tr;
-        p.bfpack.push_back(e);
+      // One GEMM = nblocks / pb panels; a panel (chunk) = [row][block of the panel][lane] x 16 B, rows = [bias row,] then the
+      // k-step rows of each input part (leaf, ld, row0, valid K, input blocks)
+      struct Part { int64_t leaf; int ld, row0, krows, nin; };
+      auto gemm = [&](int pb, int nblocks, int ncols, int64_t bias, std::initializer_list<Part> parts) {
+        for (int pn = 0; pn < nblocks / pb; ++pn) {
+          int row = 0;
+          auto emit = [&](int kind, int64_t src, int ld, int row0, int krows, int nrows) {
+            RcPackDesc e;
+            memset(&e, 0, sizeof(e));
+            e.src_off = src; e.dst_off = (long long)(base + at + (size_t)row * pb * 256); e.kind = kind; e.src_ld = ld; e.row0 = row0;
+            e.krows = krows; e.ncols = ncols; e.ngroups = nrows; e.nout = pb; e.nout_panel = pb; e.o0 = 0; e.transposed = tr;
+            e.oblk0 = pn * pb;
+            p.bfpack.push_back(e);
+            row += nrows;
+          };
+          if (bias >= 0) emit(1, bias, 0, 0, 0, 1);
+          for (const Part& q : parts) emit(0, q.leaf, q.ld, q.row0, q.krows, 2 * q.nin);
+          at += (size_t)row * pb * 256;
+        }
       };
-      auto gemm = [&](int64_t wk, int ld, int row0, int krows, int ncols, int nin, int nout, int64_t bias) {
-        if (bias >= 0) { emit(1, bias, 0, 0, 0, ncols, 1, nout, nout, 0); at += (size_t)nout * 256; }
-        emit(0, wk, ld, row0, krows, ncols, nin * 2, nout, nout, 0);
-        at += (size_t)nin * 2 * nout * 256;
-      };
-      gemm(po.trunk_k[0], TRUNK_W, 0, h->P, TRUNK_W, 2, 8, po.trunk_b[0]);
+      gemm(2, 8, TRUNK_W, po.trunk_b[0], {{po.trunk_k[0], TRUNK_W, 0, h->P, 2}});
       for (int l = 1; l < TRUNK_DEPTH; ++l) {
-        gemm(po.trunk_k[l], TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, po.trunk_b[l]);
-        if (l == SKIP_LAYER) gemm(po.trunk_k[l], TRUNK_W, TRUNK_W, h->P, TRUNK_W, 2, 8, -1);
+        if (l == SKIP_LAYER) gemm(2, 8, TRUNK_W, po.trunk_b[l], {{po.trunk_k[l], TRUNK_W, 0, TRUNK_W, 8}, {po.trunk_k[l], TRUNK_W, TRUNK_W, h->P, 2}});
+        else gemm(2, 8, TRUNK_W, po.trunk_b[l], {{po.trunk_k[l], TRUNK_W, 0, TRUNK_W, 8}});
       }
-      emit(1, po.bn_b, 0, 0, 0, TRUNK_W, 1, 8, 9, 0);          // bottleneck (8 blocks) + alpha head (block 8)
-      emit(1, po.alpha_b, 0, 0, 0, 1, 1, 1, 9, 8);
-      at += 9 * 256;
-      emit(0, po.bn_k, TRUNK_W, 0, TRUNK_W, TRUNK_W, 16, 8, 9, 0);
-      emit(0, po.alpha_k, 1, 0, TRUNK_W, 1, 16, 1, 9, 8);
-      at += (size_t)16 * 9 * 256;
-      gemm(po.rgbh_k, RGB_W, 0, TRUNK_W, RGB_W, 8, 4, -1);
-      gemm(po.logit_k, 3, 0, RGB_W, 3, 4, 4, po.logit_b);   // padded to 4 output blocks (whole 4-KiB chunk groups)
+      gemm(2, 8, TRUNK_W, po.bn_b, {{po.bn_k, TRUNK_W, 0, TRUNK_W, 8}});        // bottleneck
+      gemm(1, 1, 1, po.alpha_b, {{po.alpha_k, 1, 0, TRUNK_W, 8}});               // alpha head: one block, column 0
+      gemm(2, 4, RGB_W, -1, {{po.rgbh_k, RGB_W, 0, TRUNK_W, 8}});                // rgb hidden (bias: the fp32 per-ray term)
+      gemm(1, 1, 3, po.logit_b, {{po.logit_k, 3, 0, RGB_W, 4}});                 // rgb logits: one block, columns 0..2
+      p.bf_stream_ok = at == (size_t)BF_FWD_STREAM_KB * 256;
       if (bft) {
         // dgrad stream (nerf_mlp_bwd_bf16_kernel): A = W as stored, [m = the layer's input feature][k = its output feature];
-        // gemm(leaf, ld, row0, valid K, valid M, K blocks, M blocks, bias leaf)
-        p.L[lv].bf_wpkT = take((size_t)(16 + 64 + 8 + 128 + 7 * 128 + 2 * 32 + 64) * 256);
+        // ncols = valid M, Part.krows = valid K
+        p.L[lv].bf_wpkT = take((size_t)(h->warp ? BF_BWD_STREAM_DPTS_KB : BF_BWD_STREAM_KB) * 256);
         base = p.L[lv].bf_wpkT; at = 0; tr = 1;
-        gemm(po.logit_k, 3, 0, 3, RGB_W, 2, 4, -1);                        // G1: K padded to one 4-k-step chunk (3 valid)
-        gemm(po.rgbh_k, RGB_W, 0, RGB_W, TRUNK_W, 4, 8, -1);               // G2: rows 0..255 of [256+R, 128]
-        gemm(po.bn_k, TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, po.alpha_k);     // G3: + the alpha row (w_alpha as the "bias")
-        for (int l = TRUNK_DEPTH - 1; l >= 1; --l) gemm(po.trunk_k[l], TRUNK_W, 0, TRUNK_W, TRUNK_W, 8, 8, -1);
+        gemm(4, 4, RGB_W, -1, {{po.logit_k, 3, 0, 3, 1}});                       // G1: one k-step (3 valid) + a zero one, 4 blocks
+        gemm(2, 8, TRUNK_W, -1, {{po.rgbh_k, RGB_W, 0, RGB_W, 4}});              // G2: rows 0..255 of [256+R, 128]
+        gemm(2, 8, TRUNK_W, po.alpha_k, {{po.bn_k, TRUNK_W, 0, TRUNK_W, 8}});    // G3: row 0 = the alpha row (w_alpha as the "bias")
+        for (int l = TRUNK_DEPTH - 1; l >= 1; --l) gemm(2, 8, TRUNK_W, -1, {{po.trunk_k[l], TRUNK_W, 0, TRUNK_W, 8}});
         if (h->warp) {   // d posenc: W0 and the skip layer's posenc rows as A [m = posenc feature (P valid)][k = output feature]
-          gemm(po.trunk_k[0], TRUNK_W, 0, TRUNK_W, h->P, 8, 2, -1);
-          gemm(po.trunk_k[d.nerf_skip_layer], TRUNK_W, TRUNK_W, TRUNK_W, h->P, 8, 2, -1);
+          gemm(2, 2, h->P, -1, {{po.trunk_k[0], TRUNK_W, 0, TRUNK_W, 8}});
+          gemm(2, 2, h->P, -1, {{po.trunk_k[d.nerf_skip_layer], TRUNK_W, TRUNK_W, TRUNK_W, 8}});
         }
+        p.bf_stream_ok = p.bf_stream_ok && at == (size_t)(h->warp ? BF_BWD_STREAM_DPTS_KB : BF_BWD_STREAM_KB) * 256;
       }
     }
     p.bf_desc = take(p.bfpack.size() * sizeof(RcPackDesc) / 4 + 16);
@@ -1100,6 +1106,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   build_plan(h, B, flags, bgN, elastic);
   WsPlan& p = h->plan;
   if (ws_bytes < p.total_floats * sizeof(float)) return fail(NRF_E_WORKSPACE, "workspace too small (see nrf_workspace_bytes)");
+  if (!p.bf_stream_ok) return fail(NRF_E_STATE, "bf16 weight stream tables do not match the kernels' chunk sequence");
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
   const bool warp_on = h->warp && !(flags & NRF_FLAG_NO_WARP);   // models.py:296 use_warp argument

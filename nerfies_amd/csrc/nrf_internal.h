@@ -95,13 +95,17 @@ void launch_time_encoder_bwd(const TimeEncArgs& a, hipStream_t stream);
 void launch_time_encoder_wgrad(const TimeEncArgs& a, float* grad, hipStream_t stream);
 
 // bf16 chains (mlp_bf16.hip): one descriptor fills rows of a weight stream
+// stream lengths in KiB (mlp_bf16.hip: chunk tables FW_* / DG*; nrf_api.hip build_plan emits the chunks)
+constexpr int BF_FWD_STREAM_KB = 4 * 10 + 28 * 34 + 4 * 42 + 17 + 2 * 32 + 9;
+constexpr int BF_BWD_STREAM_KB = 8 + 4 * 16 + 4 * 34 + 28 * 32;
+constexpr int BF_BWD_STREAM_DPTS_KB = BF_BWD_STREAM_KB + 2 * 32;
 struct RcPackDesc {
   long long src_off, dst_off;   // params leaf / first row written, in floats from the workspace base
   int kind;                     // 0: k-step rows of weights, 1: the bias row
   int src_ld, row0, krows, ncols;   // leaf column count, first row, valid K and valid M (output index of the GEMM)
-  int ngroups, nout, nout_panel, o0;   // rows written, output blocks written, GEMM width in blocks, first output block
+  int ngroups, nout, nout_panel, o0;   // rows written, output blocks written, blocks per row of the chunk, first block position in the row
   int transposed;               // 0: A[m][k] = leaf[row0 + k][m] (forward); 1: A[m][k] = leaf[row0 + m][k] (dgrad: W as is)
-  int pad_;
+  int oblk0;                    // first output block of the GEMM this descriptor covers (column 32 (oblk0 + o) + m)
 };
 void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 
@@ -118,8 +122,8 @@ struct BfStash {
   uint32_t* bn;      // [ngroups][8]   bottleneck output (linear)
   uint32_t* rgbh;    // [ngroups][4]   rgb hidden (post-ReLU)
   uint32_t* bits;    // [9][ngroups][64 lanes][4 dwords]: ReLU derivative bits of trunk layers 0..7 and (index 8, two dwords
-                     // used) the rgb hidden layer; element (block o, accumulator register r) of a lane is bit
-                     // 31 - (16 (o & 1) + r) of dword o >> 1; 1 = pre-activation > 0
+                     // used) the rgb hidden layer; dword w = blocks (2w, 2w + 1); accumulator registers (2q, 2q + 1) of block o
+                     // are bit 15 - (8 (o & 1) + q) of the low / high half (bf16_chain.h bits_push); 1 = pre-activation > 0
   uint32_t* dy;      // [8][ngroups][8]  dpre_0..dpre_7
   uint32_t* dbn;     // [ngroups][8]
   uint32_t* drgbh;   // [ngroups][4]

@@ -20,7 +20,7 @@ def main():
 
   def cc(src):
     obj = os.path.join(obj_dir, os.path.splitext(src)[0] + '.o')
-    r = subprocess.run([hipcc] + B.FLAGS + extra + ['-c', os.path.join(B.CSRC, src), '-o', obj], capture_output=True, text=True)
+    r = subprocess.run([hipcc] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + extra + ['-c', os.path.join(B.CSRC, src), '-o', obj], capture_output=True, text=True)
     if r.returncode:
       raise RuntimeError(r.stderr[-3000:])
     return obj

@@ -156,13 +156,62 @@ def test_model_config_defaults_match_reference_dataclass():
 
 
 REF_CONFIGS = '/root/reference/configs'
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIPPED = os.path.join(REPO, 'configs')
+RUNNABLE = ('gpu_fullhd.gin', 'gpu_quarterhd.gin', 'gpu_quarterhd_4gpu.gin', 'gpu_vrig_paper.gin', 'test_local.gin', 'test_vrig.gin')
+
+
+def _effective(path, cwd):
+  """Every config dataclass as a dict after parsing `path` from `cwd` (the reference's presets include relative paths)."""
+  import dataclasses
+  old = os.getcwd()
+  os.chdir(cwd)
+  try:
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([path], None, skip_unknown=True)
+    return {c.__name__: dataclasses.asdict(c()) for c in (configs.ExperimentConfig, configs.ModelConfig, configs.TrainConfig, configs.EvalConfig)}
+  finally:
+    os.chdir(old)
+
+
+def _check_preset(f, m, t):
+  expect = {'gpu_vrig_paper.gin': (128, 128, 6144, 6), 'gpu_quarterhd.gin': (128, 128, 6144, 8),
+            'gpu_fullhd.gin': (256, 256, 4096, 8), 'test_vrig.gin': (64, 64, 1024, 8), 'test_local.gin': (64, 64, 1024, 8),
+            'gpu_quarterhd_4gpu.gin': (128, 128, 3072, 8)}
+  assert m.sigma_activation == 'softplus' and m.use_warp and m.warp_field_type == 'se3'
+  for name in ('lr_schedule', 'warp_alpha_schedule', 'elastic_loss_weight_schedule'):
+    assert schedules.from_config(getattr(t, name))(1000) >= 0
+  assert (m.num_coarse_samples, m.num_fine_samples, t.batch_size, m.num_warp_freqs) == expect[f], f
+  # every preset's model is accepted by the HIP library (nrf_create is host-only) and reports its own leaf shapes
+  from nerfies_amd import models
+  model, fp = models.construct_nerf(0, m, t.batch_size, [0, 1, 2], [0, 1], [0, 1, 2], 0.1, 1.0, device='cpu')
+  k = fp['nerf_mlps_fine']['MLP_0']['hidden_4']['kernel']
+  assert k.shape == (m.nerf_trunk_width + 3 + 6 * m.num_nerf_point_freqs, m.nerf_trunk_width), f
+
+
+def test_every_shipped_preset_parses():
+  """configs/*.gin of THIS repo (scripts/make_presets.py): the presets a user passes to train.py / eval.py; runs anywhere."""
+  assert sorted(os.listdir(SHIPPED)) == sorted(RUNNABLE)
+  for f in RUNNABLE:
+    gin.clear_config()
+    gin.parse_config_files_and_bindings([os.path.join(SHIPPED, f)], None, skip_unknown=True)
+    m, t = configs.ModelConfig(), configs.TrainConfig()
+    configs.EvalConfig(), configs.ExperimentConfig()
+    _check_preset(f, m, t)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason='reference tree only exists in the build container')
+def test_shipped_presets_equal_the_reference_presets():
+  """Each shipped (flattened) preset resolves to EXACTLY the configuration the reference's include chain resolves to."""
+  for f in RUNNABLE:
+    ours = _effective(os.path.join(SHIPPED, f), REPO)
+    ref = _effective(os.path.join('configs', f), '/root/reference')
+    assert ours == ref, (f, {c: {k: (ours[c][k], ref[c][k]) for k in ours[c] if ours[c][k] != ref[c][k]} for c in ours})
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_CONFIGS), reason='reference tree only exists in the build container')
 def test_every_reference_preset_parses(monkeypatch):
   monkeypatch.chdir('/root/reference')        # presets include both 'warp_defaults.gin' and 'configs/warp_defaults.gin'
-  expect = {'gpu_vrig_paper.gin': (128, 128, 6144, 6), 'gpu_quarterhd.gin': (128, 128, 6144, 8),
-            'gpu_fullhd.gin': (256, 256, 4096, 8), 'test_vrig.gin': (64, 64, 1024, 8)}
   for f in sorted(os.listdir(REF_CONFIGS)):
     if f in ('defaults.gin', 'warp_defaults.gin'):      # "Do not run this directly": macros left for the includer
       continue
@@ -170,13 +219,4 @@ def test_every_reference_preset_parses(monkeypatch):
     gin.parse_config_files_and_bindings([os.path.join('configs', f)], None, skip_unknown=True)
     m, t = configs.ModelConfig(), configs.TrainConfig()
     configs.EvalConfig(), configs.ExperimentConfig()
-    assert m.sigma_activation == 'softplus' and m.use_warp and m.warp_field_type == 'se3'
-    for name in ('lr_schedule', 'warp_alpha_schedule', 'elastic_loss_weight_schedule'):
-      assert schedules.from_config(getattr(t, name))(1000) >= 0
-    if f in expect:
-      assert (m.num_coarse_samples, m.num_fine_samples, t.batch_size, m.num_warp_freqs) == expect[f], f
-    # every preset's model is accepted by the HIP library (nrf_create is host-only) and reports its own leaf shapes
-    from nerfies_amd import models
-    model, fp = models.construct_nerf(0, m, t.batch_size, [0, 1, 2], [0, 1], [0, 1, 2], 0.1, 1.0, device='cpu')
-    k = fp['nerf_mlps_fine']['MLP_0']['hidden_4']['kernel']
-    assert k.shape == (m.nerf_trunk_width + 3 + 6 * m.num_nerf_point_freqs, m.nerf_trunk_width), f
+    _check_preset(f, m, t)

@@ -129,3 +129,49 @@ def test_train_and_eval_drivers_end_to_end(tmp_path, capsys, extra):
   assert Image.open(os.path.join(rdir, 'rgb_000003.png')).size == (24, 16)
   assert Image.open(os.path.join(rdir, 'depth_median_000003.png')).mode in ('I;16', 'I')
   gin.clear_config()
+
+
+def test_configs0_test_local_preset_end_to_end(tmp_path, capsys):
+  """BASELINE configs[0]: `configs/test_local.gin on a 4-frame synthetic scene, 64 rays/batch` -- the SHIPPED preset (64+64 samples,
+  F_p = 10, SE3 warp with a 3-wide GLO code, appearance ids, stratified sampling, elastic loss, 8 x 256 trunk) driven through
+  train.py / eval.py exactly as a user would (/root/reference/configs/test_local.gin:20-66, train.py:100-141): only the batch
+  size, the step count and the logging / checkpoint intervals are overridden on the command line."""
+  sys.path.insert(0, ROOT)
+  import eval as eval_driver
+  import train as train_driver
+  from nerfies_amd import gin_lite as gin
+  cap, exp = str(tmp_path / 'cap'), str(tmp_path / 'exp')
+  datasets.write_synthetic_scene(cap, num_frames=4, size=(24, 16), image_scale=4)   # the preset reads rgb/4x
+  preset = os.path.join(ROOT, 'configs', 'test_local.gin')
+  binds = ['TrainConfig.batch_size = 64', 'TrainConfig.print_every = 5', 'TrainConfig.log_every = 5', 'TrainConfig.save_every = 15',
+           'EvalConfig.eval_once = True', 'EvalConfig.num_val_eval = 1', 'EvalConfig.num_train_eval = 1', 'EvalConfig.chunk = 128']
+  args = ['--base_folder', exp, '--data_dir', cap, '--gin_configs', preset]
+  for b in binds:
+    args += ['--gin_bindings', b]
+  gin.clear_config()
+  state = train_driver.main(args + ['--max_steps', '15'])
+  assert state.optimizer.step == 15 and os.path.exists(os.path.join(exp, 'checkpoints', 'checkpoint_15'))
+  cfg = open(os.path.join(exp, 'config.gin')).read()
+  assert 'ModelConfig.num_warp_features = 3' in cfg and 'TrainConfig.batch_size = 64' in cfg
+  gin.clear_config()
+  state = train_driver.main(args + ['--max_steps', '30'])             # resumes from the checkpoint
+  assert state.optimizer.step == 30
+  out = capsys.readouterr().out
+  assert 'Starting training at step 16' in out
+  scal = [json.loads(l) for l in open(os.path.join(exp, 'summaries', 'train', 'scalars.jsonl'))]
+  loss = {r['step']: r['value'] for r in scal if r.get('tag') == 'loss/rgb/fine'}
+  assert sorted(loss) == [5, 10, 15, 20, 25, 30] and loss[30] < loss[5]
+  assert any(r.get('tag') == 'loss/elastic/coarse' for r in scal) and not any(r.get('tag') == 'loss/background' for r in scal)
+  # the model the preset names: 64 + 64 samples, F_p = 10 (dataclass default), 8 x 256, G = 3
+  params = state.optimizer.target          # FlatParams: flax-shaped views of the flat buffer
+  k4 = params['nerf_mlps_fine']['MLP_0']['hidden_4']['kernel']
+  assert tuple(k4.shape) == (256 + 63, 256)
+  assert tuple(params['warp_field']['metadata_encoder']['embed']['embedding'].shape)[1] == 3
+  gin.clear_config()
+  res = eval_driver.main(args)
+  assert set(res) == {'val', 'train'} and np.isfinite(res['val']['psnr']) and np.isfinite(res['train']['mse'])
+  rdir = os.path.join(exp, 'renders', '00000030', 'val')
+  assert 'rgb_000003.png' in os.listdir(rdir)
+  from PIL import Image
+  assert Image.open(os.path.join(rdir, 'rgb_000003.png')).size == (24, 16)
+  gin.clear_config()

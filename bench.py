@@ -46,7 +46,8 @@ def kernel_source_sha():
   h = hashlib.sha256()
   csrc = os.path.join(ROOT, 'nerfies_amd', 'csrc')
   for f in sorted(os.listdir(csrc)):
-    h.update(open(os.path.join(csrc, f), 'rb').read())
+    if f.endswith(('.hip', '.h')):
+      h.update(open(os.path.join(csrc, f), 'rb').read())
   return h.hexdigest()[:16]
 
 
@@ -177,6 +178,10 @@ class CfgEval(Cfg):
   num_coarse_samples, num_fine_samples, use_stratified_sampling = 128, 128, False
 
 
+class CfgEvalWarp(CfgEval):   # BASELINE.md config E as nerfies renders it (eval.py:330-339): SE3 warp F_w=8, G=8, forward only
+  use_warp, num_warp_freqs, num_warp_features, warp_field_type = True, 8, 8, 'se3'
+
+
 # training workloads: rays per GPU, model config, regularisers, warp alpha, the gin shape they stand for
 NUM_FRAMES = int(os.environ.get('BENCH_FRAMES', 256))   # frames of the synthetic capture: warp / appearance ids per frame
 
@@ -303,14 +308,22 @@ def rccl_version():
 
 
 def eval_mode(args, world, rank, dev, bf16):
-  """BASELINE configs[4]: the video-render forward, 8192-ray chunks x (128+128), hipGraph replay."""
-  from nerfies_amd import evaluation, models
+  """BASELINE configs[4]: the video-render forward, 8192-ray chunks x (128+128), hipGraph replay.  --warp: with the SE3 field
+  (the path eval.py actually renders, models.py:251-267: 526.1 MFLOP/ray); --frame: additionally times evaluation.render_image
+  on a whole 960x540 frame (chunk scheduling, tail padding, the copy of every chunk into the frame buffer included)."""
+  from nerfies_amd import evaluation, models, training
   n = 8192
-  model, fp = models.construct_nerf(0, CfgEval, n, [0, 1, 2, 3], [0, 1], [0, 1, 2, 3], 0.0206, 0.826, device=dev)
+  cfg = CfgEvalWarp if args.warp else CfgEval
+  model, fp = models.construct_nerf(0, cfg, n, list(range(NUM_FRAMES)), [0, 1], list(range(NUM_FRAMES)), 0.0206, 0.826, device=dev)
   rays = {k: v for k, v in synthetic_batch(n, 100 + rank, dev).items() if k != 'rgb'}
+  extra = {}
+  if args.warp:
+    # a rendered frame is ONE camera at one time stamp: every ray of a chunk carries the same warp id
+    rays['metadata'] = {'warp': torch.full((n, 1), 3 + rank, dtype=torch.int32, device=dev)}
+    extra = {'alpha': 8.0}
   fn = evaluation.GraphedChunkRenderer(model, bf16=bf16)
-  step = lambda: fn(0, 1, fp, rays, {})
-  prof_step = lambda: model.apply({'params': fp}, rays, {}, bf16=bf16)   # HIP events cannot be recorded inside a graph replay
+  step = lambda: fn.call_static(0, 1, fp, rays, extra)
+  prof_step = lambda: model.apply({'params': fp}, rays, extra, bf16=bf16)   # HIP events cannot be recorded inside a graph replay
 
   def barrier():
     if world > 1:
@@ -330,6 +343,29 @@ def eval_mode(args, world, rank, dev, bf16):
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
+  frame = None
+  if args.frame:
+    # one 960 x 540 frame (the quarter-HD capture of the README) through render_image: 64 chunks of 8192 rays, the last one
+    # edge-padded (518400 = 63 x 8192 + 2304); each rank renders its slice of every chunk, one packed all_gather per chunk
+    h, w = 540, 960
+    fr = {k: v for k, v in synthetic_batch(h * w, 7, dev).items() if k != 'rgb'}
+    fr = {k: v.reshape(h, w, 3) for k, v in fr.items() if k != 'metadata'}
+    if args.warp:
+      fr['metadata'] = {'warp': torch.full((h, w, 1), 3, dtype=torch.int32, device=dev)}
+    state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=extra.get('alpha', 0.0))
+    render = lambda: evaluation.render_image(state, fr, fn, chunk=n)
+    render()
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(3):
+      render()
+    barrier()
+    frame_ms = 1e3 * (time.perf_counter() - t1) / 3
+    nchunks = -(-h * w // n)
+    chunk_ms = 1e3 * elapsed / args.steps * (1.0 / world if world > 1 else 1.0)
+    frame = {'size': [w, h], 'chunks': nchunks, 'frame_ms': frame_ms, 'sum_of_chunk_replays_ms': nchunks * chunk_ms,
+             'overhead_frac': frame_ms / (nchunks * chunk_ms) - 1.0 if world == 1 else None,
+             'frames_per_s': 1e3 / frame_ms}
   model.profile_enable(True)
   for _ in range(5):
     prof_step()
@@ -337,18 +373,20 @@ def eval_mode(args, world, rank, dev, bf16):
   prof = model.profile_read()
   model.profile_enable(False)
   if rank == 0:
-    roofline, peak = roofline_of(prof, bf16, 'eval_bf16' if bf16 else 'eval', n, CfgEval)
+    roofline, peak = roofline_of(prof, bf16, ('eval_warp' if args.warp else 'eval') + ('_bf16' if bf16 else ''), n, cfg)
     step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / 5
     ms = 1e3 * elapsed / args.steps
+    warp_txt = 'SE3 warp F_w=8 G=8 (one warp id per chunk)' if args.warp else 'warp off'
     print(json.dumps({
-        'metric': 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [bf16 MLP operands]' if bf16 else ''),
+        'metric': 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [SE3 warp on]' if args.warp else '') +
+                  (' [bf16 MLP operands]' if bf16 else ''),
         'value': world * n * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16' if bf16 else 'f32',
-        'data': 'synthetic',
-        'config': {'workload': 'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, warp off, deterministic, forward only',
+        'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': ('bf16 NeRF MLPs + f32 warp field' if args.warp else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
+        'config': {'workload': f'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, {warp_txt}, deterministic, forward only',
                    'rays_per_gpu': n, 'parallelism': f'ray-shard dp{world}'},
         'roofline': roofline, 'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernel_table(prof, 5),
-        'csrc_sha16': kernel_source_sha()}))
+        'frame': frame, 'csrc_sha16': kernel_source_sha()}))
 
 
 def main():
@@ -371,6 +409,8 @@ def main():
                   help='rays per GPU of the training modes (default: the mode\'s own, 1024 for the headline); 128 = one GPU\'s share '
                        'of a 1024-ray global batch on 8 GPUs (the north star\'s strong-scaling point)')
   ap.add_argument('--graph', action='store_true', help='replay the whole train step (loss+grad, all-reduce, Adam) from one hipGraph')
+  ap.add_argument('--warp', action='store_true', help='eval mode: render with the SE3 warp field (the path eval.py takes)')
+  ap.add_argument('--frame', action='store_true', help='eval mode: also time evaluation.render_image on a whole 960x540 frame')
   args = ap.parse_args()
 
   world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -472,6 +512,19 @@ def main():
     elapsed = t.item()
   state, stats, key = box['state'], box['stats'], box['key']
   loss = stats['fine']['loss/rgb'].item()
+  # every rank applied the same all-reduced gradient to the same initial parameters: the replicas must be BIT-identical.
+  # Checked on a checksum of the parameter bits (and the per-rank losses are reported: they differ, every rank has its own rays)
+  per_rank_loss, replicas_agree = [loss], True
+  if dist_on:
+    flat = state.optimizer.target.flat
+    mine = torch.stack([flat.view(torch.int32).to(torch.int64).sum(), (flat.view(torch.int32).to(torch.int64) * 31 % 1000003).sum()])
+    both = torch.cat([mine.to(torch.float64), torch.tensor([loss], device=dev, dtype=torch.float64)])
+    allr = [torch.empty_like(both) for _ in range(dist.get_world_size())]
+    dist.all_gather(allr, both)
+    per_rank_loss = [float(a[2]) for a in allr]
+    replicas_agree = all(bool((a[:2] == allr[0][:2]).all()) for a in allr)
+    if not replicas_agree:
+      raise SystemExit(f'rank {rank}: parameter replicas diverged across ranks: checksums {[a[:2].tolist() for a in allr]}')
 
   # ---- the gradient all-reduce on its own (outside the timed region): the fused [grad | stats] buffer, 20 calls ----
   allreduce_us = None
@@ -523,7 +576,7 @@ def main():
         ('step_frac_of_bf16_mfma_peak' if step_peak == PEAK_BF16_MFMA_TFLOPS else 'step_frac_of_fp32_mfma_peak'):
             None if mixed else step_flops / (ms_per_step * 1e-3) / 1e12 / (step_peak * world),
         'kernels': kernels, 'sum_of_kernels_ms': ksum_ms, 'step_over_sum_of_kernels': ms_per_step / ksum_ms if ksum_ms else None,
-        'final_loss_fine': loss,
+        'final_loss_fine': loss, 'per_rank_final_loss_fine': per_rank_loss, 'replica_param_checksums_agree': replicas_agree,
         'steady_state': {'burn_in_steps': burn_steps, 'burn_in_s': args.burn_in_s, 'timed_window_s': elapsed,
                          'during_timed_window': clocks},
         'graph_replay': bool(args.graph),

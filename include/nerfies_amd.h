@@ -17,8 +17,14 @@
  *   - every entry returns 0 on success or a negative NRF_E_* code; nothing
  *     throws or aborts.  nrf_last_error() returns the message of the last failing
  *     call MADE BY THE CALLING THREAD (thread-local storage; valid until that thread's
- *     next failing call).  Handles carry no error state, so one handle may be driven
- *     from several threads (on distinct workspaces) without their errors mixing.
+ *     next failing call).  Handles carry no error state, so the errors of several threads never mix.
+ *   - a handle caches ONE workspace plan -- the layout for the (num_rays, flags, regularisers) of its most recent call -- and
+ *     the descriptor tables it uploads into a workspace belong to that plan.  Calls on one handle must therefore be SERIALISED
+ *     by the caller (one host thread at a time, launches of different (num_rays, flags) on different streams ordered by the
+ *     caller); changing the batch size or the flags between calls is fine (the plan is rebuilt, the tables re-uploaded), and
+ *     nrf_backward refuses a workspace whose forward was stashed under another plan (NRF_E_STATE).  For concurrent streams
+ *     or threads create one handle per stream: nrf_create is host-only and cheap.
+ *   - grad_params must be 16-byte aligned (it is cleared and accumulated into with 128-bit accesses; NRF_E_SHAPE otherwise).
  *   - fp32 everywhere (the reference computes in fp32); ids are int32.
  */
 #ifndef NERFIES_AMD_H_
@@ -247,7 +253,7 @@ typedef struct nrf_background {
   const float* points;      /* (N,3) points: already noised when warp_ids is given, raw when the library draws */
   const int32_t* warp_ids;  /* (N,) or NULL: the library draws id = id_choices[floor(U * num_choices)] (random.choice over
                                model.warp_ids, training.py:121-123) and adds noise_std * N(0,1) to the points (:124-126) with
-                               its Philox streams 4..7 of (nrf_rand.seed, offset) -- nothing left for the host to launch */
+                               its Philox streams 4 and 5 of (nrf_rand.seed, offset) -- nothing left for the host to launch */
   float loss_weight;        /* scalar_params.background_loss_weight */
   float loss_alpha;         /* -2 (training.py:119) */
   float loss_scale;         /* 0.001 */

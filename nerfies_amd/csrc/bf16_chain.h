@@ -32,7 +32,10 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int BF_KB = 1024;
-constexpr int BF_DF = 8;                   // A fragments in flight: the LDS read of fragment f + BF_DF goes out behind MFMA f
+#ifndef NRF_BF_DF
+#define NRF_BF_DF 8
+#endif
+constexpr int BF_DF = NRF_BF_DF;           // A fragments in flight: the LDS read of fragment f + BF_DF goes out behind MFMA f
 constexpr int BF_SLOT = 42 * BF_KB;        // ring slot = the largest chunk (skip layer: 2 blocks x (1 + 16 + 4) rows)
 constexpr int BF_LDS_BYTES = 3 * BF_SLOT;
 

@@ -99,8 +99,10 @@ __device__ __forceinline__ void layer256(ChainCtx& c, f32x16 (&acc0)[2], f32x16 
       [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 4, RELU, STASH>(k, acc0, out, mbn[2], rn2, lane16); });
 }
 
+// sigma activation (models.py:276-277): softplus or relu.  Fast exp / log: log(1 + e) loses e below 6e-8 -- an ABSOLUTE error of
+// that size on a density, far inside the mode's tolerance -- and drops the long log1pf sequence from the per-iteration tail
 __device__ __forceinline__ float bf_sigma(float x, int kind) {
-  return kind == 1 ? fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))) : fmaxf(x, 0.f);
+  return kind == 1 ? fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x))) : fmaxf(x, 0.f);
 }
 
 // the ring's first two chunks, the first fragments
@@ -474,19 +476,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       // ---- warp on: d posenc = W0 . dpre_0 + W4[256:] . dpre_4 (two 256 -> 64 GEMMs into one accumulator panel), chain rule
       //      through SinusoidalEncoder (modules.py:213-228) -> d points, float32, for the warp field's backward ----
       const __amdgpu_buffer_rsrc_t rp3 = panel_rsrc(dyst(0), 3);
-      {   // dpre_4 back from its stash (stored four layers ago by this wave; the waits since have retired it); ua is free: the loads fly under P0
-        const u32x4v* src = reinterpret_cast<const u32x4v*>(dyst(SKIP_LAYER)) + lane;
+      // dpre_4 back from its stash (stored four layers ago by this wave; the waits since have retired it).  ua is free: the first
+      // half of the loads flies under P0, the second under the first half of P4 (all 64 registers at once next to ub, both
+      // accumulator panels and the fragment ring is what made this variant spill)
+      const u32x4v* d4src = reinterpret_cast<const u32x4v*>(dyst(SKIP_LAYER)) + lane;
+      auto load_d4 = [&](int b0) __attribute__((always_inline)) {
 #pragma unroll
-        for (int b = 0; b < 8; ++b)
+        for (int b = b0; b < b0 + 4; ++b)
 #pragma unroll
           for (int jp = 0; jp < 2; ++jp) {
-            const u32x4v q = src[(b * 2 + jp) * 64];
+            const u32x4v q = d4src[(b * 2 + jp) * 64];
             ua[b][4 * jp] = q.x; ua[b][4 * jp + 1] = q.y; ua[b][4 * jp + 2] = q.z; ua[b][4 * jp + 3] = q.w;
           }
-      }
+      };
+      load_d4(0);
       bf_chunk<2, 16, true, 22, BW_OPS_MASK, true>(acc0, c.fr, c.rg, c.ll, wave, DG1,
           [&](int r) __attribute__((always_inline)) { return BF_ROWS(ub, 0); },
           [&](int k) __attribute__((always_inline)) { panel_epi_bwd<22, 6, true>(k, acc1, ub, mq.w, rp3, lane16); });
+      load_d4(4);
       bf_chunk<2, 16, false, 0, 0, false>(acc0, c.fr, c.rg, c.ll, wave, DG2,
           [&](int r) __attribute__((always_inline)) { return BF_ROWS(ua, 0); }, [&](int) __attribute__((always_inline)) {});
       const int r = row < A.rows ? row : A.rows - 1;

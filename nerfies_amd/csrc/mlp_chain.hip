@@ -293,7 +293,7 @@ void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t s
   const size_t lds = (size_t)(ACT_FLOATS + a.PK * TILE_ROWS) * sizeof(float);
   ChainFwdArgs1 p;
   p.a[0] = a;
-  if (getenv("NRF_DEBUG_OCC")) {
+  if (knobs().debug_occ) {
     int nb = -1;
     (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)nerf_mlp_fwd_kernel<true>, 256, lds);

@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,26 @@ int fail_hip(hipError_t e, const char* where) {
   return NRF_E_HIP;
 }
 
+}  // namespace (reopened below)
+
+const Knobs& nrf::knobs() {
+  static const Knobs k = [] {
+    Knobs v;
+    v.trace_regions = getenv("NRF_TRACE_REGIONS") != nullptr;
+#ifdef NRF_EXPERIMENT
+    v.debug_occ = getenv("NRF_DEBUG_OCC") != nullptr;
+    v.timeline = getenv("NRF_TIMELINE") != nullptr;
+    v.dynamic_tiles = getenv("NRF_DYNAMIC_TILES") != nullptr;
+    if (const char* e = getenv("NRF_GRID_MUL")) v.grid_mul = atoi(e) < 1 ? 1 : atoi(e);
+    if (const char* e = getenv("NRF_WARP_GRID_MUL")) v.warp_grid_mul = atoi(e);
+    if (const char* e = getenv("NRF_OLD_SHARE")) v.old_share = atof(e);
+#endif
+    return v;
+  }();
+  return k;
+}
+
+namespace {
 constexpr size_t ALIGN_F = 64;   // workspace sub-buffers are aligned to 64 floats (256 B)
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -103,20 +124,35 @@ struct Prof {
   std::vector<ProfAcc> acc;
   // NRF_TRACE_REGIONS=1 (debugging aid): name every region on stderr and synchronise the stream behind it, so that a device
   // fault is attributed to the kernel group that raised it
-  static bool trace() { static const bool t = getenv("NRF_TRACE_REGIONS") != nullptr; return t; }
+  static bool trace() { return knobs().trace_regions; }
+  // Neither the trace's stream synchronise nor the profiler's event records are legal inside a stream capture (a
+  // GraphedTrainStep / GraphedChunkRenderer capture with either switched on would be invalidated and surface as an unrelated
+  // HIP error): both are skipped while `st` is capturing.
+  static bool capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  }
+  bool open = false;   // begin() recorded an event that end() must close
   void begin(const char* name, double flops, hipStream_t st) {
+    open = false;
+    if (!trace() && !on) return;
+    if (capturing(st)) return;
     if (trace()) { fprintf(stderr, "[nrf] %s ...", name); fflush(stderr); }
     if (!on) return;
     if (next == slots.size()) { slots.emplace_back(); (void)hipEventCreate(&slots.back().a); (void)hipEventCreate(&slots.back().b); }
     ProfSlot& s = slots[next];
     s.name = name; s.flops = flops; s.used = true;
     (void)hipEventRecord(s.a, st);
+    open = true;
   }
   void end(hipStream_t st) {
+    if (!trace() && !on) return;
+    if (capturing(st)) return;
     if (trace()) { const hipError_t e = hipStreamSynchronize(st); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr); }
-    if (!on) return;
+    if (!on || !open) return;
     (void)hipEventRecord(slots[next].b, st);
     ++next;
+    open = false;
   }
   void drain() {
     for (size_t i = 0; i < next; ++i) {
@@ -316,8 +352,7 @@ int k_old_for(int ntiles, int grid, int num_cus, double dflt_share) {
   if (grid != 2 * num_cus) return 0;
   const int K = (ntiles + num_cus - 1) / num_cus;
   if (K < 4) return 0;
-  static const char* e = getenv("NRF_OLD_SHARE");
-  const double share = e ? atof(e) : dflt_share;
+  const double share = knobs().old_share >= 0.0 ? knobs().old_share : dflt_share;
   if (share <= 0.0) return 0;
   int k = (int)floor(K * share + 0.5);
   return k < 1 ? 1 : (k > K - 1 ? K - 1 : k);
@@ -325,13 +360,12 @@ int k_old_for(int ntiles, int grid, int num_cus, double dflt_share) {
 
 // workgroups per CU of the SE3 chain kernels' launches
 int warp_grid_mul() {
-  static const int m = getenv("NRF_WARP_GRID_MUL") ? atoi(getenv("NRF_WARP_GRID_MUL")) : NRF_WARP_WAVES;
+  const int m = knobs().warp_grid_mul;
   return m < 1 ? 1 : (m > 4 ? 4 : m);
 }
 
 int* tile_counter_or_null(float* base, int idx) {
-  static const bool dynamic = getenv("NRF_DYNAMIC_TILES") != nullptr;
-  return dynamic ? reinterpret_cast<int*>(base) + idx : nullptr;
+  return knobs().dynamic_tiles ? reinterpret_cast<int*>(base) + idx : nullptr;
 }
 constexpr int BG = 2;   // level index of the background-point batch
 constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coarse tiles)
@@ -352,7 +386,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
   const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) && h->warp;   // tangent pass in an inference plan
   const bool wstash = train || jac;                                // the warp kernels keep their input / sign-bit stash
-  static uint64_t next_serial = 1;
+  static std::atomic<uint64_t> next_serial{1};   // handles may be planned from several host threads
   p = WsPlan();
   p.serial = next_serial++;
   p.B = B;
@@ -481,9 +515,12 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   // ---- stream-K partition of the wgrad work: equal cost per workgroup, one workgroup per CU ----
   // cost of one 64-row tile of a group, in units of a full 256x256 layer tile; the narrow groups
   // are staging/latency bound, so they are charged more than their MFMA share.
-  auto env_cost = [](const char* name, double dflt) {
-    const char* e = getenv(name);
-    return e ? atof(e) : dflt;
+  auto env_cost = [](const char* name, double dflt) {   // calibration overrides (scripts/wgrad_calib.py): experiment builds only
+#ifdef NRF_EXPERIMENT
+    if (const char* e = getenv(name)) return atof(e);
+#endif
+    (void)name;
+    return dflt;
   };
   // measured with scripts/wgrad_calib.py / wgrad_calib_vrig.py (per-segment wall clocks, least squares), relative to a
   // 256x256 tile; round 3 (asm LDS-DMA + 160 KiB ring: the narrow groups are no longer latency-bound): 8x8 = 14.8 us
@@ -1006,7 +1043,7 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
   a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation;
   a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_FWD + lv);
-  a.timeline = getenv("NRF_TIMELINE") ? reinterpret_cast<unsigned long long*>(ws + p.timeline) + lv * (256 + 512 + 4 * 2048) : nullptr;
+  a.timeline = knobs().timeline ? reinterpret_cast<unsigned long long*>(ws + p.timeline) + lv * (256 + 512 + 4 * 2048) : nullptr;
   a.alpha_ct = h->A > 0 ? ws + L.alpha_ct : nullptr;
   if (h->d.noise_std > 0.f && h->d.use_stratified_sampling) {   // model_utils.noise_regularize (model_utils.py:266-282)
     a.noise_std = h->d.noise_std;
@@ -1176,7 +1213,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       pf.end(stream);
     }
     ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train, rnd, dyn);
-    const int gmul = getenv("NRF_GRID_MUL") ? atoi(getenv("NRF_GRID_MUL")) : 2;
+    const int gmul = knobs().grid_mul;
     const int grid = p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus;   // two workgroups per CU
     if (warp_on) {
       // the background-point batch of the fused train step rides in the coarse launch (its 256 tiles under-fill the chip)
@@ -1289,6 +1326,8 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   // narrower model: the stashed forward left the padded parameter image in the workspace; gradients are formed
   // in the padded layout and copied out at the end
   const float* params = h->embed ? ws + p.iparams : params_x;
+  // the gradient buffer is zero-filled and accumulated into with 16-byte accesses (zero_ranges_kernel, reduce passes)
+  if ((reinterpret_cast<uintptr_t>(grad_x) & 15u) != 0) return fail(NRF_E_SHAPE, "grad_params must be 16-byte aligned");
   float* grad = h->embed ? ws + p.igrad : grad_x;
   const bool wr_on = wr && warp_on;
   const bool bg_on = bg && p.bgN > 0;
@@ -1303,6 +1342,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     if (el_on) z.add(ws + p.el_sums, 64);
     if (bg_on) z.add(ws + p.bg_loss, 64);
     for (int lv = 0; lv < h->nlevels; ++lv) z.add(ws + p.L[lv].dray, (long long)B * RGB_W);
+    if (z.overflow) return fail(NRF_E_STATE, "zero_ranges table full: an accumulator would stay unzeroed");
     launch_zero_ranges(z, stream);
   }
   const int G2 = 2 * h->num_cus;   // chain kernels: two workgroups per CU
@@ -1399,13 +1439,9 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   //      (already noised) background points with one warp id per point; general loss of |x' - x|^2 ----
   if (bg_on) {
     const LevelWs& L = p.L[BG];
-    if (!bg_forward_done) {   // nrf_forward + nrf_backward path: the fused train step ran it inside the coarse warp launch
-      const int grid = p.ntiles[BG] < G2 ? p.ntiles[BG] : G2;
-      draw_background(h, bg, nullptr, scalars, ws, stream);
-      h->prof.begin("warp_fwd_bg", warp_fwd_flops_row(h) * p.bgN, stream);
-      launch_warp_fwd(bg_fwd_args(h, params, bg, scalars, ws), nullptr, true, grid, stream);
-      h->prof.end(stream);
-    }
+    // the background batch's warp forward ran inside the coarse warp launch of the fused train step (the only caller that
+    // passes `bg`: nrf_backward has no background argument)
+    if (!bg_forward_done) return fail(NRF_E_STATE, "background regulariser without its forward pass");
     launch_background_loss(bg_points_of(p, bg, ws), ws + L.wpoints, p.bgN, p.ntiles[BG] * TILE_ROWS, bg->loss_alpha, bg->loss_scale,
                            bg->loss_weight, ws + L.d_points, ws + p.bg_loss, stream);
   }

@@ -339,6 +339,20 @@ struct PackDesc {
   int nvalid;         // valid n (columns beyond are zero)
 };
 
+// Environment knobs, read ONCE per process (first use), never on a launch path.  The product build honours only the debugging
+// aid NRF_TRACE_REGIONS; the experiment knobs of scripts/exp_*.sh (tile hand-out, grid multipliers, timelines, occupancy print)
+// exist only in builds compiled with -DNRF_EXPERIMENT (scripts/build_variant.py NAME -DNRF_EXPERIMENT ...).
+struct Knobs {
+  bool trace_regions = false;   // NRF_TRACE_REGIONS: name every kernel group on stderr and synchronise behind it
+  bool debug_occ = false;       // NRF_DEBUG_OCC: print the forward kernel's occupancy once per launch
+  bool timeline = false;        // NRF_TIMELINE: shader-clock stamps of workgroup 0 (needs -DNRF_TIMELINE_BUILD as well)
+  bool dynamic_tiles = false;   // NRF_DYNAMIC_TILES: tiles from a global counter instead of the static split
+  int grid_mul = 2;             // NRF_GRID_MUL: workgroups per CU of the fp32 NeRF chain launches
+  int warp_grid_mul = NRF_WARP_WAVES;   // NRF_WARP_GRID_MUL: workgroups per CU of the SE3 chain launches
+  double old_share = -1.0;      // NRF_OLD_SHARE: uneven static split (chain_common.h tile_iter); < 0: the caller's default
+};
+const Knobs& knobs();
+
 // ---- launchers (all asynchronous on `stream`) ----
 void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
@@ -427,7 +441,12 @@ struct ZeroArgs {
   float* p[8];
   long long n[8];
   int count;
-  void add(float* ptr, long long nfloats) { if (nfloats > 0 && count < 8) { p[count] = ptr; n[count] = nfloats; ++count; } }
+  bool overflow;   // a ninth range was offered: the caller must fail (an accumulator would stay unzeroed)
+  void add(float* ptr, long long nfloats) {
+    if (nfloats <= 0) return;
+    if (count >= 8) { overflow = true; return; }
+    p[count] = ptr; n[count] = nfloats; ++count;
+  }
 };
 void launch_zero_ranges(const ZeroArgs& a, hipStream_t stream);
 void launch_adam(float* p, float* m, float* v, const float* g, int64_t n, double lr, double b1,

@@ -50,6 +50,12 @@ class GraphedChunkRenderer:
     return graph, ins, outs
 
   def __call__(self, key_0, key_1, params, rays, warp_extra):
+    # the static buffers are overwritten by the next replay: a plain model_fn caller gets copies
+    return _tree_map(lambda x: x.clone(), self.call_static(key_0, key_1, params, rays, warp_extra))
+
+  def call_static(self, key_0, key_1, params, rays, warp_extra):
+    """As __call__, but returns the graph's own output buffers (valid until the next replay): render_image copies each chunk
+    straight into the frame at its offset, so a chunk's outputs are moved once instead of cloned and then concatenated."""
     del key_0, key_1               # eval is deterministic (eval.py:239 forces use_stratified_sampling off)
     n = rays['origins'].shape[0]
     # every scalar of lib.StepScalars is part of the key: a replay would otherwise render with the captured value
@@ -65,12 +71,12 @@ class GraphedChunkRenderer:
       def cp(dst, src):
         if isinstance(dst, dict):
           for k in dst:
-            cp(dst[k], src[k])
+            cp(dst[k], (src or {}).get(k) if isinstance(dst[k], dict) else src[k])
         else:
           dst.copy_(src)
       cp(slot[1], rays)
     slot[0].replay()
-    return _tree_map(lambda x: x.clone(), slot[2])   # the static buffers are overwritten by the next replay
+    return slot[2]
 
 
 def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_count: int = 1, rng=0,
@@ -89,7 +95,8 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
   world = dist.get_world_size() if dist_on else 1
   rank = dist.get_rank() if world > 1 else 0
   del device_count
-  ret_maps = []
+  frame = None          # output key -> (num_rays, ...) buffer, filled chunk by chunk at the chunk's offset
+  call = getattr(model_fn, 'call_static', model_fn)   # a graph renderer hands out its static output buffers (no per-chunk clone)
   num_chunks = int(math.ceil(num_rays / chunk))
   # a graph-replaying renderer wants ONE chunk size per frame: the tail is edge-padded to the full chunk (rendered and
   # dropped) instead of being a second shape; otherwise it is padded to a multiple of the world size only
@@ -104,7 +111,7 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
       chunk_rays = _tree_map(lambda x: torch.cat([x, x[-1:].expand(pad, *x.shape[1:])], 0), chunk_rays)
     per = (n + pad) // world
     mine = _tree_map(lambda x: x[rank * per:(rank + 1) * per], chunk_rays) if world > 1 else chunk_rays
-    out = model_fn(rng, rng + 1, state.optimizer.target, mine, state.warp_extra)
+    out = call(rng, rng + 1, state.optimizer.target, mine, state.warp_extra)
     ret_key = default_ret_key or ('fine' if 'fine' in out else 'coarse')
     ret = out[ret_key]
     if dist_on:   # ONE all_gather per chunk: every output key packed side by side into a (per, sum of widths) buffer
@@ -115,10 +122,11 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
       dist.all_gather_into_tensor(gathered, packed)
       split = torch.split(gathered, [c.shape[1] for c in cols], 1)
       ret = {k: split[i].reshape(world * per, *ret[k].shape[1:]).to(ret[k].dtype) for i, k in enumerate(keys)}
-    if pad:
-      ret = {k: v[:-pad] for k, v in ret.items()}
-    ret_maps.append(ret)
-  return {k: torch.cat([r[k] for r in ret_maps], 0).reshape(h, w, *ret_maps[0][k].shape[1:]) for k in ret_maps[0]}
+    if frame is None:
+      frame = {k: torch.empty(num_rays, *v.shape[1:], dtype=v.dtype, device=v.device) for k, v in ret.items()}
+    for k, v in ret.items():
+      frame[k][i0:i0 + n].copy_(v[:n])     # drops the padding; the only copy a chunk's outputs see
+  return {k: v.reshape(h, w, *v.shape[1:]) for k, v in frame.items()}
 
 
 def rays_from_camera(camera, metadata: Optional[Dict[str, int]] = None, device='cuda'):

@@ -1,4 +1,5 @@
 mkdir -p gpurun_out
+# needs an experiment build: python scripts/build_variant.py exp -DNRF_EXPERIMENT && export NRF_LIB_PATH=nerfies_amd/_lib/variants/libnerfies_amd_exp.so
 for cfg in "NRF_GRID_MUL=2" "NRF_GRID_MUL=1"; do
   env $cfg python bench.py --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/b.json 2> gpurun_out/b.err
   python - "$cfg" <<'PY'

@@ -1,4 +1,5 @@
 #!/bin/bash
+# needs an experiment build: python scripts/build_variant.py exp -DNRF_EXPERIMENT && export NRF_LIB_PATH=nerfies_amd/_lib/variants/libnerfies_amd_exp.so
 # uneven static tile split of the fp32 chain kernels: share of a CU's tiles given to its older workgroup
 for s in 0 0.5 0.55 0.58 0.62 0.67; do
   NRF_OLD_SHARE=$s python bench.py --no-cpu-baseline --burn-in-s 0.5 --steps 40 > gpurun_out/old_share.json 2>/dev/null

@@ -200,8 +200,10 @@ TRAIN_MODES = {
                             'points per GPU (w=1), stratified'),
 }
 TRAIN_MODES['train_bf16'] = dict(TRAIN_MODES['train'], force_bf16=True)
-BF16_NOTE = (' [opt-in bf16 mode: bfloat16 NeRF-MLP operands and activation / dY stash; fp32 master weights, posenc, SE3 warp '
-             'field and its regularisers, compositing, loss, all-reduce, Adam]')
+BF16_NOTE_MLP = (' [opt-in bf16 mode, NeRF MLPs only: bfloat16 NeRF-MLP operands and activation / dY stash; fp32 master weights, posenc, '
+                 'SE3 warp field and its regularisers, compositing, loss, all-reduce, Adam]')
+BF16_NOTE_ALL = (' [opt-in bf16 mode: bfloat16 operands and activation / dY stash of the NeRF MLPs and of the SE3 trunk; fp32 master '
+                 'weights, posenc, exp_se3 / Jacobian algebra / regularisers, GLO tables, compositing, loss, all-reduce, Adam]')
 
 
 def synthetic_batch(n, seed, device):
@@ -283,8 +285,9 @@ def roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg):
   dom_ms = dom['ms'] / dom['launches']
   achieved = dom['flops_per_launch'] / (dom_ms * 1e-3) / 1e12
   traffic, traffic_src = hbm_traffic(dom['name'], mode_key)
-  # the NeRF-MLP kernels run on bf16 MFMA in the bf16 modes; the SE3 field and the fp32 wgrad kernel never do
-  on_bf16 = bf16 and dom['name'].startswith('mlp_')
+  # the NeRF-MLP kernels run on bf16 MFMA in the bf16 modes, and so does the SE3 trunk unless --warp-f32 keeps it in float32
+  # (bf16 == 'mlp'); the fp32 wgrad kernel never does
+  on_bf16 = bool(bf16) and (dom['name'].startswith('mlp_') or (bf16 != 'mlp' and dom['name'].startswith('warp_')))
   peak_tf = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
   r = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': achieved / peak_tf,
        'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']}
@@ -382,7 +385,7 @@ def eval_mode(args, world, rank, dev, bf16):
                   (' [bf16 MLP operands]' if bf16 else ''),
         'value': world * n * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': ('bf16 NeRF MLPs + f32 warp field' if args.warp else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
+        'dtype': ('bf16 NeRF MLPs + f32 warp field' if (args.warp and bf16 == 'mlp') else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': f'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, {warp_txt}, deterministic, forward only',
                    'rays_per_gpu': n, 'parallelism': f'ray-shard dp{world}'},
         'roofline': roofline, 'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernel_table(prof, 5),
@@ -410,6 +413,7 @@ def main():
                        'of a 1024-ray global batch on 8 GPUs (the north star\'s strong-scaling point)')
   ap.add_argument('--graph', action='store_true', help='replay the whole train step (loss+grad, all-reduce, Adam) from one hipGraph')
   ap.add_argument('--warp', action='store_true', help='eval mode: render with the SE3 warp field (the path eval.py takes)')
+  ap.add_argument('--warp-f32', action='store_true', help='bf16 modes: keep the SE3 trunk in float32 (NRF_FLAG_WARP_F32; the round-3 behaviour)')
   ap.add_argument('--frame', action='store_true', help='eval mode: also time evaluation.render_image on a whole 960x540 frame')
   args = ap.parse_args()
 
@@ -440,6 +444,8 @@ def main():
   dist_on = world > 1 or force_dist
 
   bf16 = args.bf16 or bool(os.environ.get('BENCH_BF16'))
+  if bf16 and args.warp_f32:
+    bf16 = 'mlp'
   if args.mode == 'eval':
     eval_mode(args, world, rank, dev, bf16)
     if dist_on:
@@ -449,6 +455,7 @@ def main():
   from nerfies_amd import models, training
   M = TRAIN_MODES[args.mode]
   bf16 = bf16 or bool(M.get('force_bf16'))
+  BF16_NOTE = BF16_NOTE_MLP if bf16 == 'mlp' else BF16_NOTE_ALL
   cfg = M['cfg']
   rays_per_gpu = args.rays_per_gpu or M['rays']
   # metadata ids as a capture has them: one warp / appearance id per FRAME (a vrig capture has a few hundred frames and a batch
@@ -559,7 +566,7 @@ def main():
     roofline, peak_tf = roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg)
     kernels = kernel_table(prof, prof_steps)
     ksum_ms = sum(v['ms'] * v['launches_per_step'] for v in kernels.values())
-    mixed = bf16 and getattr(cfg, 'use_warp', False)
+    mixed = bf16 == 'mlp' and getattr(cfg, 'use_warp', False)   # bf16 NeRF MLPs next to a float32 SE3 trunk
     # the step's flops are priced against the bf16 peak only when every MFMA kernel of it runs in bf16 (warp off)
     step_peak = PEAK_BF16_MFMA_TFLOPS if (bf16 and not mixed) else PEAK_FP32_MFMA_TFLOPS
     out = {

@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 300 /* 0.3.0: device-resident per-step scalars (a whole train step replays from one hipGraph), background ids /
+#define NRF_VERSION 400 /* 0.4.0: NRF_FLAG_BF16 also runs the SE3 trunk in bfloat16 (NRF_FLAG_WARP_F32 opts out).
+                           0.3.0: device-resident per-step scalars (a whole train step replays from one hipGraph), background ids /
                            noise drawn by the library, `points` output without the warp field.
                            0.2.0: alpha condition, pre-encoded metadata, warp Jacobian output, noise_std, warp_reg loss,
                            elastic loss types, time metadata encoder, stats[16], bf16 training */
@@ -202,6 +203,9 @@ typedef struct nrf_outputs {
                                loss / Adam); an opt-in mode with no reference counterpart (BASELINE config D) -- ~1e-2 on
                                rendered colour */
 #define NRF_FLAG_WARP_JACOBIAN 8u /* return_warp_jacobian (models.py:297): forward-mode tangent pass of the warp per level */
+#define NRF_FLAG_WARP_F32 16u     /* with NRF_FLAG_BF16: keep SE3Field's 6 x 128 trunk on float32 operands (since 0.4.0 NRF_FLAG_BF16
+                                     runs it on bfloat16 operands as well: annealed posenc, exp_se3, (w, v), the Jacobian algebra and
+                                     the GLO table stay float32); a call that returns the warp Jacobian uses the float32 trunk anyway */
 
 int nrf_version(void);
 const char* nrf_last_error(void);

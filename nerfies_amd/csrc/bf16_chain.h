@@ -200,4 +200,40 @@ __device__ __forceinline__ void bf_store16(__amdgpu_buffer_rsrc_t r, int voff, u
   __builtin_amdgcn_raw_buffer_store_b128(q, r, voff, 0, 2);
 }
 
+// the 4 KiB of a stash group that panel `panel` (2 blocks) of a layer writes: one descriptor, immediates reach all of it
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const uint32_t* group_base, int panel) {
+  return make_rsrc(group_base + panel * 2 * BF_BLOCK_DW, 2 * BF_BLOCK_DW * 4);
+}
+
+
+struct ChainCtx {
+  BfRing rg;
+  bf16x8 fr[BF_DF];
+  const char* ll;   // LDS ring + lane * 16
+  int wave;
+};
+
+
+// B operand of row r of a layer whose rows are [bias,] 2 k-steps per input block: registers 4s .. 4s+3 of block b
+#define BF_ROWS(arr, r0) as_bf16x8(arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1)], arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 1], \
+                                   arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 2], arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 3])
+
+
+// the ring's first two chunks, the first fragments
+__device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* wpk, int total, int bytes0, int bytes1, int lane, int wave) {
+  c.rg.src = reinterpret_cast<const char*>(wpk);
+  c.rg.voff = lane * 16;
+  c.rg.lds0 = lds_byte_addr(lds);
+  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0;
+  c.ll = lds + lane * 16; c.wave = wave;
+  bf_ring_copy(c.rg, 0, bytes0, wave);
+  bf_ring_copy(c.rg, 1, bytes1, wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int i = 0; i < BF_DF; ++i) c.fr[i] = *reinterpret_cast<const bf16x8*>(c.ll + i * BF_KB);
+}
+
+
 }  // namespace nrf

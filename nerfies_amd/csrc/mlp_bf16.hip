@@ -59,21 +59,6 @@ __device__ __forceinline__ void panel_epi(int k, const f32x16 (&pend)[2], unsign
   }
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t panel_rsrc(const uint32_t* group_base, int panel) {
-  return make_rsrc(group_base + panel * 2 * BF_BLOCK_DW, 2 * BF_BLOCK_DW * 4);
-}
-
-struct ChainCtx {
-  BfRing rg;
-  bf16x8 fr[BF_DF];
-  const char* ll;   // LDS ring + lane * 16
-  int wave;
-};
-
-// B operand of row r of a layer whose rows are [bias,] 2 k-steps per input block: registers 4s .. 4s+3 of block b
-#define BF_ROWS(arr, r0) as_bf16x8(arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1)], arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 1], \
-                                   arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 2], arr[((r) - (r0)) >> 1][4 * (((r) - (r0)) & 1) + 3])
-
 // One 256-wide layer of the forward chain, 4 panels of 2 blocks.  `in` = packed input (its blocks 6, 7 arrive from acc1 = the
 // previous layer's last panel during chunk 0 when PEND), out = packed output blocks 0..5; blocks 6, 7 stay pending in acc1.
 //   R: rows per panel (bias + k-steps); bsel(r): B operand of row r; PRELU / RELU: activation of the previous / this layer;
@@ -99,26 +84,14 @@ __device__ __forceinline__ void layer256(ChainCtx& c, f32x16 (&acc0)[2], f32x16 
       [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 4, RELU, STASH>(k, acc0, out, mbn[2], rn2, lane16); });
 }
 
-// sigma activation (models.py:276-277): softplus or relu.  Fast exp / log: log(1 + e) loses e below 6e-8 -- an ABSOLUTE error of
-// that size on a density, far inside the mode's tolerance -- and drops the long log1pf sequence from the per-iteration tail
+// sigma activation (models.py:276-277): softplus or relu.  log1p(e), e = exp(-|x|) in (0, 1], as log(u) e / (u - 1) with u = 1 + e:
+// the rounding of u cancels in the quotient (relative error ~1e-7 down to e ~ 1e-38), where log(1 + e) alone loses e below
+// 6e-8 and 20 % of it at x = -15 -- and it is 6 VALU instead of libm's log1pf sequence (which cost the inference kernel its
+// only scratch slot)
 __device__ __forceinline__ float bf_sigma(float x, int kind) {
-  return kind == 1 ? fmaxf(x, 0.f) + __logf(1.f + __expf(-fabsf(x))) : fmaxf(x, 0.f);
-}
-
-// the ring's first two chunks, the first fragments
-__device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* wpk, int total, int bytes0, int bytes1, int lane, int wave) {
-  c.rg.src = reinterpret_cast<const char*>(wpk);
-  c.rg.voff = lane * 16;
-  c.rg.lds0 = lds_byte_addr(lds);
-  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0;
-  c.ll = lds + lane * 16; c.wave = wave;
-  bf_ring_copy(c.rg, 0, bytes0, wave);
-  bf_ring_copy(c.rg, 1, bytes1, wave);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < BF_DF; ++i) c.fr[i] = *reinterpret_cast<const bf16x8*>(c.ll + i * BF_KB);
+  if (kind != 1) return fmaxf(x, 0.f);
+  const float e = __expf(-fabsf(x)), u = 1.f + e, d = u - 1.f;
+  return fmaxf(x, 0.f) + (d == 0.f ? e : __logf(u) * __fdividef(e, d));
 }
 
 }  // namespace
@@ -595,10 +568,14 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
     const int lane = idx & 63, o = (idx >> 6) % d.nout, rowi = (idx >> 6) / d.nout;
     const int m = lane & 31, h = lane >> 5, b = rowi >> 1, s = rowi & 1;
     const int col = 32 * (d.oblk0 + o) + m;
+    // two leaves side by side (SE3 heads): output columns (forward, bias) / K indices (transposed) >= split come from src_off2
+    const bool col2 = !d.transposed && d.split > 0 && col >= d.split;
+    const long long leaf = col2 ? d.src_off2 : d.src_off;
+    const int lcol = col2 ? col - d.split : col;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (d.kind == 1) {
       if (h == 0 && col < d.ncols) {
-        const float bias = params[d.src_off + col];
+        const float bias = params[leaf + lcol];
         const float hi = __uint_as_float(pack_bf16(bias, 0.f) << 16);
         v[0] = hi; v[1] = bias - hi;
       }
@@ -606,9 +583,14 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const int k = 32 * b + 8 * (2 * s + (e >> 2)) + 4 * h + (e & 3);
-        if (k < d.krows && col < d.ncols)
-          v[e] = d.transposed ? params[d.src_off + (int64_t)(d.row0 + col) * d.src_ld + k]
-                              : params[d.src_off + (int64_t)(d.row0 + k) * d.src_ld + col];
+        if (k < d.krows && col < d.ncols) {
+          if (d.transposed) {
+            const bool k2 = d.split > 0 && k >= d.split;
+            v[e] = params[(k2 ? d.src_off2 : d.src_off) + (int64_t)(d.row0 + col) * d.src_ld + (k2 ? k - d.split : k)];
+          } else {
+            v[e] = params[leaf + (int64_t)(d.row0 + k) * d.src_ld + lcol];
+          }
+        }
       }
     }
     uint4 out;

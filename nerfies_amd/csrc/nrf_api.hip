@@ -59,6 +59,9 @@ struct LevelWs {   // float offsets from the workspace base, per level (0 = coar
   // bf16 training (NRF_FLAG_TRAIN | NRF_FLAG_BF16): dgrad weight stream, the two bf16 stashes (nrf_internal.h BfStash), bias slabs
   size_t bf_wpkT = 0, b_pe = 0, b_h = 0, b_bn = 0, b_rgbh = 0, b_bits = 0, b_dy = 0, b_dbn = 0, b_drgbh = 0, b_dsmall = 0;
   int b_ngroups = 0;
+  // bf16 SE3 trunk (nrf_internal.h BfWarpStash) of this level's pass through the field
+  size_t bw_in = 0, bw_h = 0, bw_bits = 0, bw_dy = 0, bw_dhead = 0;
+  int bw_ngroups = 0;
   size_t st_pe, st_h, st_bn, st_rgbh, bits_trunk, bits_rgbh;
   size_t d_raw4, dy_trunk, dy_bn, dy_rgbh, dray, small_part, cond_grad;
   // SE3 warp field (per level: the field is evaluated on the coarse and on the fine samples)
@@ -77,6 +80,8 @@ struct WsPlan {
   size_t bf_desc = 0;
   std::vector<RcPackDesc> bfpack;
   bool bf_stream_ok = true;   // the chunk tables emitted by build_plan add up to the stream lengths the kernels walk
+  bool bfw = false;           // training plan: the SE3 trunk stashes / differentiates in bfloat16 (warp_bf16.hip)
+  size_t bfw_wpk = 0, bfw_wpkT = 0;   // bf16 SE3 weight streams (forward: also in inference plans)
   size_t iparams = 0, igrad = 0;   // zero-padded parameter image / its gradient (models narrower than the kernels)
   std::vector<WgradSegment> segs;
   std::vector<int> seg_begin;
@@ -373,7 +378,7 @@ constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coa
 // the flags a workspace layout depends on: TRAIN, WARP_JACOBIAN, and BF16 together with TRAIN (bf16 stash instead of fp32)
 uint32_t plan_flags(uint32_t flags) {
   uint32_t f = flags & (NRF_FLAG_TRAIN | NRF_FLAG_WARP_JACOBIAN);
-  if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_BF16)) f |= NRF_FLAG_BF16;
+  if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_BF16)) f |= NRF_FLAG_BF16 | (flags & NRF_FLAG_WARP_F32);
   return f;
 }
 
@@ -385,13 +390,15 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   const bool train = flags & NRF_FLAG_TRAIN;
   const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
   const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) && h->warp;   // tangent pass in an inference plan
-  const bool wstash = train || jac;                                // the warp kernels keep their input / sign-bit stash
+  const bool bfw = bft && h->warp && !(flags & NRF_FLAG_WARP_F32);   // ... and so does the SE3 trunk (warp_bf16.hip)
+  const bool wstash = (train && !bfw) || jac;                      // the fp32 warp kernels keep their input / sign-bit stash
   static std::atomic<uint64_t> next_serial{1};   // handles may be planned from several host threads
   p = WsPlan();
   p.serial = next_serial++;
   p.B = B;
   p.flags = flags;
   p.bgN = bgN;
+  p.bfw = bfw;
   p.elastic = elastic;
   p.S[0] = d.num_coarse_samples;
   p.S[1] = d.num_coarse_samples + d.num_fine_samples;
@@ -444,7 +451,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   struct BSpec { int lv; size_t* xoff; size_t xadd; int Kb; size_t* yoff; size_t yadd; int Nb;
                  int64_t dst; int dst_ld, rows, cols, col0;          // weight leaf <- slab[0:rows][col0:col0+cols]
                  int64_t bias_dst; int bias_cols;                     // bias leaf <- column sums [0:bias_cols], or -1
-                 int64_t bias2_dst; int bias2_col0; };                // a second 1-wide bias leaf (alpha: column 3), or -1
+                 int64_t bias2_dst; int bias2_col0;                   // a second bias leaf (alpha: column 3; SE3 v head: columns 3..5), or -1
+                 int bias2_cols = 1; int accu = 0; int ngroups = 0;   // reduce pass the leaf is added in; groups (0: the MLP level's)
+                 int64_t dst2 = -1; int col20 = 0; };                 // a second weight leaf from the same slab (SE3 v head), or -1
   std::vector<BSpec> bspecs;
   if (bft) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -471,6 +480,40 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       bpush(&L.b_rgbh, 0, 4, &L.b_dsmall, 0, 2, po.logit_k, 3, 128, 3, 0, po.logit_b, 3, po.alpha_b, 3);
       bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);
     }
+  }
+  // bf16 SE3 trunk: every pass through the field (coarse / fine samples, background points, the 3 tangents per coarse sample)
+  // leaves its own X / dY stash; all of them add into the same leaves (reduce passes 0..3).  The tangent pass carries no bias.
+  if (bfw) {
+    const WarpParamOffsets& w = h->wpo;
+    auto add_bf_warp = [&](int lv, int accu, bool tangent) {
+      LevelWs& L = p.L[lv];
+      const int rows = tangent ? p.rows[0] : p.rows[lv];
+      L.bw_ngroups = (tangent ? 3 : 1) * ((rows + 255) / 256 * 8);
+      const size_t layer = (size_t)L.bw_ngroups * 4 * BF_BLOCK_DW;
+      auto wpush = [&](size_t* xoff, size_t xadd, int Kb, size_t* yoff, size_t yadd, int Nb, int64_t dst, int dst_ld, int rws, int cols,
+                       int64_t bias_dst, int bias_cols) {
+        BSpec b = {lv, xoff, xadd, Kb, yoff, yadd, Nb, dst, dst_ld, rws, cols, 0, tangent ? -1 : bias_dst, bias_cols, -1, 0};
+        b.accu = accu; b.ngroups = L.bw_ngroups;
+        bspecs.push_back(b);
+      };
+      for (int l = 0; l < WARP_DEPTH; ++l) {
+        if (l == 0) {
+          wpush(&L.bw_in, 0, 2, &L.bw_dy, 0, 4, w.trunk_k[0], WARP_W, h->Win, WARP_W, w.trunk_b[0], WARP_W);
+        } else {
+          wpush(&L.bw_h, (size_t)(l - 1) * layer, 4, &L.bw_dy, (size_t)l * layer, 4, w.trunk_k[l], WARP_W, WARP_W, WARP_W, w.trunk_b[l], WARP_W);
+          if (l == WARP_SKIP)
+            wpush(&L.bw_in, 0, 2, &L.bw_dy, (size_t)l * layer, 4, w.trunk_k[l] + (int64_t)WARP_W * WARP_W, WARP_W, h->Win, WARP_W, -1, 0);
+        }
+      }
+      // both heads read h6 against the "small" dY block: columns 0..2 = dL/dw, 3..5 = dL/dv
+      BSpec hd = {lv, &L.bw_h, (size_t)(WARP_DEPTH - 1) * layer, 4, &L.bw_dhead, 0, 2, w.w_k, 3, WARP_W, 3, 0,
+                  tangent ? -1 : w.w_b, 3, tangent ? -1 : w.v_b, 3};
+      hd.bias2_cols = 3; hd.accu = accu; hd.ngroups = L.bw_ngroups; hd.dst2 = w.v_k; hd.col20 = 3;
+      bspecs.push_back(hd);
+    };
+    for (int lv = 0; lv < h->nlevels; ++lv) add_bf_warp(lv, lv > 0 ? 1 : 0, false);
+    if (bgN > 0) add_bf_warp(BG, 2, false);
+    if (elastic) add_bf_warp(TG, 3, true);
   }
   if (train) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -503,10 +546,10 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       specs.push_back({lv, SRC_FRAG128, &L.st_rgbh, FRAG_TILE_128, 128, 4, 0, nullptr, 0, 0, 3,
                        po.logit_k, 3, 128, 3, 6, 0, 0});
       }
-      if (h->warp) add_warp_groups(lv, lv > 0 ? 1 : 0);   // the field is shared by both passes: level 1 accumulates
+      if (h->warp && !bfw) add_warp_groups(lv, lv > 0 ? 1 : 0);   // the field is shared by both passes: level 1 accumulates
     }
-    if (h->warp && bgN > 0) add_warp_groups(BG, 2);
-    if (h->warp && elastic) add_warp_groups(TG, 3);   // tangent activations x tangent adjoints, same leaves
+    if (h->warp && !bfw && bgN > 0) add_warp_groups(BG, 2);
+    if (h->warp && !bfw && elastic) add_warp_groups(TG, 3);   // tangent activations x tangent adjoints, same leaves
   }
 
   // ---- float layout ----
@@ -578,7 +621,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     const double bc_chunk = env_cost("NRF_BCOST_CHUNK", 12.0);   // per-chunk fixed cost (barrier + issue), in block units
     auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb) + bc_chunk; };
     double total = 0;
-    for (auto& sp : bspecs) total += bcost(sp) * p.L[sp.lv].b_ngroups;
+    auto bng = [&](const BSpec& sp) { return sp.ngroups ? sp.ngroups : p.L[sp.lv].b_ngroups; };
+    for (auto& sp : bspecs) total += bcost(sp) * bng(sp);
     const int nwg = G;
     total += bc_seg * (nwg + (double)bspecs.size());
     const double quota = total / nwg;
@@ -588,7 +632,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     for (size_t gi = 0; gi < bspecs.size(); ++gi) {
       const double c = bcost(bspecs[gi]);
       int t0 = 0;
-      const int nt = p.L[bspecs[gi].lv].b_ngroups;
+      const int nt = bng(bspecs[gi]);
       while (t0 < nt) {
         int take_n = (int)floor((room - bc_seg) / c + 1e-9);
         if (take_n <= 0 && w < nwg - 1) {
@@ -665,6 +709,49 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         p.bf_stream_ok = p.bf_stream_ok && at == (size_t)(h->warp ? BF_BWD_STREAM_DPTS_KB : BF_BWD_STREAM_KB) * 256;
       }
     }
+    if (h->warp) {   // bf16 SE3 trunk (warp_bf16.hip): forward stream (also for bf16 inference), reverse stream (training)
+      const WarpParamOffsets& w = h->wpo;
+      size_t at = 0, base = 0;
+      int tr = 0;
+      struct Part { int64_t leaf; int ld, row0, krows, nin; int64_t leaf2 = -1; int split = 0; };
+      // as the NeRF gemm() above; bias2 / Part.leaf2: the second of two leaves side by side (heads w | v)
+      auto gemm = [&](int pb, int nblocks, int ncols, int64_t bias, int64_t bias2, int bsplit, std::initializer_list<Part> parts) {
+        for (int pn = 0; pn < nblocks / pb; ++pn) {
+          int row = 0;
+          auto emit = [&](int kind, int64_t src, int64_t src2, int split, int ld, int row0, int krows, int nrows) {
+            RcPackDesc e;
+            memset(&e, 0, sizeof(e));
+            e.src_off = src; e.dst_off = (long long)(base + at + (size_t)row * pb * 256); e.kind = kind; e.src_ld = ld; e.row0 = row0;
+            e.krows = krows; e.ncols = ncols; e.ngroups = nrows; e.nout = pb; e.nout_panel = pb; e.o0 = 0; e.transposed = tr;
+            e.oblk0 = pn * pb; e.src_off2 = src2 >= 0 ? src2 : 0; e.split = src2 >= 0 ? split : 0;
+            p.bfpack.push_back(e);
+            row += nrows;
+          };
+          if (bias >= 0) emit(1, bias, bias2, bsplit, 0, 0, 0, 1);
+          for (const Part& q : parts) emit(0, q.leaf, q.leaf2, q.split, q.ld, q.row0, q.krows, 2 * q.nin);
+          at += (size_t)row * pb * 256;
+        }
+      };
+      p.bfw_wpk = take((size_t)BFW_FWD_STREAM_KB * 256);
+      base = p.bfw_wpk;
+      gemm(2, 4, WARP_W, w.trunk_b[0], -1, 0, {{w.trunk_k[0], WARP_W, 0, h->Win, 2}});
+      for (int l = 1; l < WARP_DEPTH; ++l) {
+        if (l == WARP_SKIP) gemm(2, 4, WARP_W, w.trunk_b[l], -1, 0, {{w.trunk_k[l], WARP_W, 0, WARP_W, 4}, {w.trunk_k[l], WARP_W, WARP_W, h->Win, 2}});
+        else gemm(2, 4, WARP_W, w.trunk_b[l], -1, 0, {{w.trunk_k[l], WARP_W, 0, WARP_W, 4}});
+      }
+      gemm(1, 1, 6, w.w_b, w.v_b, 3, {{w.w_k, 3, 0, WARP_W, 4, w.v_k, 3}});     // heads: columns 0..2 = w, 3..5 = v
+      p.bf_stream_ok = p.bf_stream_ok && at == (size_t)BFW_FWD_STREAM_KB * 256;
+      if (bfw) {
+        // reverse stream: A = W as stored, [m = the layer's input feature][k = its output feature]
+        p.bfw_wpkT = take((size_t)BFW_BWD_STREAM_KB * 256);
+        base = p.bfw_wpkT; at = 0; tr = 1;
+        gemm(4, 4, WARP_W, -1, -1, 0, {{w.w_k, 3, 0, 6, 1, w.v_k, 3}});         // heads^T: K = (w0..2, v0..2) of one k-step + a zero one
+        for (int l = WARP_DEPTH - 1; l >= 1; --l) gemm(2, 4, WARP_W, -1, -1, 0, {{w.trunk_k[l], WARP_W, 0, WARP_W, 4}});
+        gemm(2, 2, h->Win, -1, -1, 0, {{w.trunk_k[0], WARP_W, 0, WARP_W, 4}});                  // C0: d input through layer 0
+        gemm(2, 2, h->Win, -1, -1, 0, {{w.trunk_k[WARP_SKIP], WARP_W, WARP_W, WARP_W, 4}});     // C4: ... through the skip rows
+        p.bf_stream_ok = p.bf_stream_ok && at == (size_t)BFW_BWD_STREAM_KB * 256;
+      }
+    }
     p.bf_desc = take(p.bfpack.size() * sizeof(RcPackDesc) / 4 + 16);
   }
 
@@ -677,12 +764,24 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       L.w_st_wv = take(nt * TILE_ROWS * 8);
       L.w_bits = take(nt * 4 * 64 * WARP_DEPTH);
     }
-    if (train) {
+    if (train && !bfw) {
       L.d_points = take(nt * TILE_ROWS * 3);
       L.w_dy = take(nt * FRAG_TILE_128 * WARP_DEPTH);
       L.w_dw4 = take(nt * TILE_ROWS * 4);
       L.w_dv4 = take(nt * TILE_ROWS * 4);
       L.w_small_part = take((size_t)4 * G * WARP_SMALL_PART);
+    }
+    if (bfw) {   // bf16 trunk: fp32 rows only for what exp_se3 / the elastic kernel read and write; the rest is the bf16 stash
+      const size_t ng = L.bw_ngroups;
+      L.w_st_wv = take(nt * TILE_ROWS * 8);
+      L.d_points = take(nt * TILE_ROWS * 3);
+      L.w_dw4 = take(nt * TILE_ROWS * 4);
+      L.w_dv4 = take(nt * TILE_ROWS * 4);
+      L.bw_in = take(ng * 2 * BF_BLOCK_DW);
+      L.bw_h = take(ng * 4 * BF_BLOCK_DW * WARP_DEPTH);
+      L.bw_bits = take(ng * 64 * 2 * WARP_DEPTH);
+      L.bw_dy = take(ng * 4 * BF_BLOCK_DW * WARP_DEPTH);
+      L.bw_dhead = take(ng * 2 * BF_BLOCK_DW);
     }
   };
   p.cond = take((size_t)B * (h->R > 0 ? h->R : 1));
@@ -788,7 +887,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       add(po.trunk_k[d.nerf_skip_layer], pk.bwd_L4bT, 256, 256, 256, 256, 2, 1, 1, h->P);
     }
   }
-  if (h->warp) {
+  if (h->warp && !bfw) {   // fp32 fragment images of the SE3 trunk (a bf16-trunk training plan reads only its bf16 streams)
     const WarpParamOffsets& w = h->wpo;
     const WarpPackOffsets& wk = h->wpk;
     const int64_t base = (int64_t)p.warp_wpk;
@@ -867,7 +966,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       memset(&g, 0, sizeof(g));
       g.x_off = (int64_t)(*sp.xoff + sp.xadd); g.x_tile_stride = sp.Kb * BF_BLOCK_DW; g.Kb = sp.Kb; g.x_kvalid = sp.rows;
       g.dy_off = (int64_t)(*sp.yoff + sp.yadd); g.dy_tile_stride = sp.Nb * BF_BLOCK_DW; g.Nb = sp.Nb;
-      g.ntiles = p.L[sp.lv].b_ngroups; g.nsplit = bnsplit[i]; g.vec_off = -1; g.vec2_off = -1;
+      g.ntiles = sp.ngroups ? sp.ngroups : p.L[sp.lv].b_ngroups; g.nsplit = bnsplit[i]; g.vec_off = -1; g.vec2_off = -1;
       g.slab_off = (int64_t)take((size_t)g.nsplit * sp.Kb * 32 * sp.Nb * 32);
       g.vslab_off = sp.bias_dst >= 0 ? (int64_t)take((size_t)g.nsplit * sp.Nb * 32) : -1;
       p.bgroups.push_back(g);
@@ -875,16 +974,25 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       memset(&r, 0, sizeof(r));
       r.dst_off = sp.dst; r.dst_ld = sp.dst_ld; r.rows = sp.rows; r.cols = sp.cols;
       r.src_off = g.slab_off + sp.col0; r.src_ld = sp.Nb * 32; r.part_stride = (int64_t)sp.Kb * 32 * sp.Nb * 32; r.nparts = g.nsplit;
-      p.reduce.push_back(r);
+      r.accumulate = sp.accu;
+      auto rpush = [&](const ReduceDesc& q) {
+        (q.accumulate == 0 ? p.reduce : q.accumulate == 1 ? reduce2 : q.accumulate == 2 ? reduce3 : reduce4).push_back(q);
+      };
+      rpush(r);
+      if (sp.dst2 >= 0) {   // a second leaf out of the same slab (column window col20)
+        ReduceDesc r2 = r;
+        r2.dst_off = sp.dst2; r2.src_off = g.slab_off + sp.col20;
+        rpush(r2);
+      }
       auto bias = [&](int64_t dst, int cols, int col0) {
         ReduceDesc b;
         memset(&b, 0, sizeof(b));
-        b.dst_off = dst; b.dst_ld = cols; b.rows = 1; b.cols = cols;
+        b.dst_off = dst; b.dst_ld = cols; b.rows = 1; b.cols = cols; b.accumulate = sp.accu;
         b.src_off = g.vslab_off + col0; b.src_ld = sp.Nb * 32; b.part_stride = sp.Nb * 32; b.nparts = g.nsplit;
-        p.reduce.push_back(b);
+        rpush(b);
       };
       if (sp.bias_dst >= 0) bias(sp.bias_dst, sp.bias_cols, 0);
-      if (sp.bias2_dst >= 0) bias(sp.bias2_dst, 1, sp.bias2_col0);
+      if (sp.bias2_dst >= 0) bias(sp.bias2_dst, sp.bias2_cols, sp.bias2_col0);
     }
     // bias gradients and per-ray condition rows
     for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -913,7 +1021,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         r.src_off = (int64_t)L.cond_grad; r.src_ld = 128; r.part_stride = 0; r.nparts = 1;
         p.reduce.push_back(r);
       }
-      if (h->warp && lv == 0) {   // ONE SE3 dgrad launch (coarse + fine + background tiles), one set of bias partials
+      if (h->warp && !bfw && lv == 0) {   // ONE SE3 dgrad launch (coarse + fine + background tiles), one set of bias partials
         const int nt_w = nt_mlp + (bgN > 0 ? p.ntiles[BG] : 0);
         warp_bias_descs(0, nt_w < warp_grid_mul() * G ? nt_w : warp_grid_mul() * G, 0);
       }
@@ -1031,6 +1139,15 @@ BfStash bf_stash(const WsPlan& p, int lv, float* ws) {
   return b;
 }
 
+BfWarpStash bfw_stash(const WsPlan& p, int lv, float* ws) {
+  const LevelWs& L = p.L[lv];
+  BfWarpStash b;
+  auto u = [&](size_t off) { return reinterpret_cast<uint32_t*>(ws + off); };
+  b.win = u(L.bw_in); b.h = u(L.bw_h); b.bits = u(L.bw_bits); b.dy = u(L.bw_dy); b.dhead = u(L.bw_dhead);
+  b.ngroups = L.bw_ngroups;
+  return b;
+}
+
 ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays* rays, float* ws, bool train, const nrf_rand* rnd,
                       const nrf_dynamic_scalars* dyn = nullptr) {
   const WsPlan& p = h->plan;
@@ -1126,7 +1243,14 @@ void launch_tangent_fwd(nrf_handle h, int lv, const float* params, const nrf_ray
   (void)gmul;
   const int tgrid = ta.ntiles < warp_grid_mul() * h->num_cus ? ta.ntiles : warp_grid_mul() * h->num_cus;
   h->prof.begin("warp_tangent_fwd", 3.0 * warp_fwd_flops_row(h) * p.rows[lv], stream);
-  launch_warp_fwd(ta, nullptr, true, tgrid, stream);
+  if (p.bfw) {   // bf16 trunk: tangent groups = 3 x the primal groups, masks = the primal pass's bits
+    ta.rows = p.rows[lv]; ta.rows_pad = p.ntiles[lv] * TILE_ROWS;
+    ta.bwpk = ws + p.bfw_wpk; ta.bst = bfw_stash(p, TG, ws);
+    ta.bprim_bits = reinterpret_cast<const uint32_t*>(ws + L.bw_bits); ta.bng_prim = L.bw_ngroups;
+    launch_warp_fwd_bf16(ta, nullptr, true, h->num_cus, stream);
+  } else {
+    launch_warp_fwd(ta, nullptr, true, tgrid, stream);
+  }
   h->prof.end(stream);
 }
 
@@ -1171,6 +1295,9 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   pf.begin("pack_prep_sample", 0, stream);
   if (!p.pack.empty()) launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
   const bool bf16 = flags & NRF_FLAG_BF16;
+  // the SE3 trunk follows the MLPs into bf16 unless the caller opts out (NRF_FLAG_WARP_F32) or asks for the Jacobian output
+  // (inference tangent pass: fp32 kernels); a training plan has decided already (its stash layout depends on it)
+  const bool bfw_on = warp_on && bf16 && (train ? p.bfw : !(flags & NRF_FLAG_WARP_F32) && !jac);
   if (bf16) launch_bf16_pack(reinterpret_cast<const RcPackDesc*>(ws + p.bf_desc), (int)p.bfpack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
   {
@@ -1223,8 +1350,16 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       const int wnt = p.ntiles[lv] + (with_bg ? p.ntiles[BG] : 0);
       const int wgrid = wnt < warp_grid_mul() * h->num_cus ? wnt : warp_grid_mul() * h->num_cus;
       pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * (p.rows[lv] + (with_bg ? p.bgN : 0)), stream);
-      launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars, ws, train || jac), with_bg ? &bga : nullptr,
-                      train || jac, wgrid, stream);
+      if (bfw_on) {   // SE3 trunk on bf16 operands (warp_bf16.hip); one workgroup per CU, 256 rows per iteration
+        WarpFwdArgs wa = warp_fwd_args(h, lv, params, rays, scalars, ws, train);
+        wa.bwpk = ws + p.bfw_wpk; wa.rows_pad = p.ntiles[lv] * TILE_ROWS;
+        if (train) wa.bst = bfw_stash(p, lv, ws);
+        if (with_bg) { bga.bwpk = wa.bwpk; bga.rows_pad = p.ntiles[BG] * TILE_ROWS; bga.bst = bfw_stash(p, BG, ws); }
+        launch_warp_fwd_bf16(wa, with_bg ? &bga : nullptr, train, h->num_cus, stream);
+      } else {
+        launch_warp_fwd(warp_fwd_args(h, lv, params, rays, scalars, ws, train || jac), with_bg ? &bga : nullptr,
+                        train || jac, wgrid, stream);
+      }
       pf.end(stream);
       a.points = ws + L.wpoints;
       // forward-mode Jacobian of the warp: on the coarse samples for the elastic regulariser (models.py:345), per level
@@ -1413,6 +1548,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     ElasticArgs ea;
     memset(&ea, 0, sizeof(ea));
     ea.prim_win = ws + L.w_st_win; ea.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
+    if (p.bfw) ea.x_rows = ws + L.points_raw;   // bf16 trunk: no fp32 input stash
     ea.tan_wv = reinterpret_cast<const float4*>(ws + T.w_st_wv); ea.coef = ws + L.weights;
     if (el->reduce_method == NRF_ELASTIC_MEDIAN) {   // training.py:182-188
       launch_median_coef(ws + L.weights, B, p.S[0], ws + p.el_coef, stream);
@@ -1479,8 +1615,20 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       w.grad_embed = grad + h->wpo.embed;
     }
     const int GW = warp_grid_mul() * h->num_cus;
+    if (p.bfw) {   // bf16 trunk: the reverse stream, this level's stash, the points as fp32 rows
+      int q = 0;
+      for (int lv = 0; lv < h->nlevels; ++lv, ++q) {
+        wa[q].bwpk = ws + p.bfw_wpkT; wa[q].bst = bfw_stash(p, lv, ws); wa[q].x_rows = ws + p.L[lv].points_raw;
+        wa[q].rows_pad = p.ntiles[lv] * TILE_ROWS;
+      }
+      if (bg_on) {
+        wa[q].bwpk = ws + p.bfw_wpkT; wa[q].bst = bfw_stash(p, BG, ws); wa[q].x_rows = bg_points_of(p, bg, ws);
+        wa[q].rows_pad = p.ntiles[BG] * TILE_ROWS;
+      }
+    }
     h->prof.begin("warp_dgrad", warp_dgrad_flops_row(h) * rows_all, stream);
-    launch_warp_bwd(wa[0], nlev > 1 ? &wa[1] : nullptr, nlev > 2 ? &wa[2] : nullptr, nt_all < GW ? nt_all : GW, stream);
+    if (p.bfw) launch_warp_bwd_bf16(wa[0], nlev > 1 ? &wa[1] : nullptr, nlev > 2 ? &wa[2] : nullptr, h->num_cus, stream);
+    else launch_warp_bwd(wa[0], nlev > 1 ? &wa[1] : nullptr, nlev > 2 ? &wa[2] : nullptr, nt_all < GW ? nt_all : GW, stream);
     h->prof.end(stream);
     if (el_on) {   // reverse of the tangent pass
       const LevelWs& T = p.L[TG];
@@ -1492,7 +1640,14 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       ta.small_part = nullptr;
       const int tgrid = p.ntiles[TG] < GW ? p.ntiles[TG] : GW;
       h->prof.begin("warp_tangent_dgrad", 3.0 * warp_dgrad_flops_row(h) * p.rows[0], stream);
-      launch_warp_bwd(ta, nullptr, nullptr, tgrid, stream);
+      if (p.bfw) {
+        ta.rows = p.rows[0]; ta.rows_pad = p.ntiles[0] * TILE_ROWS;
+        ta.bst = bfw_stash(p, TG, ws); ta.bprim_bits = reinterpret_cast<const uint32_t*>(ws + p.L[0].bw_bits);
+        ta.bng_prim = p.L[0].bw_ngroups;
+        launch_warp_bwd_bf16(ta, nullptr, nullptr, h->num_cus, stream);
+      } else {
+        launch_warp_bwd(ta, nullptr, nullptr, tgrid, stream);
+      }
       h->prof.end(stream);
     }
   }
@@ -1531,7 +1686,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     h->prof.end(stream);
   }
   if (!p.bsegs.empty()) {
-    h->prof.begin("wgrad_bf16", wgrad_flops_row(h) * wg_rows, stream);
+    h->prof.begin("wgrad_bf16", wgrad_flops_row(h) * wg_rows + (p.bfw ? warp_fwd_flops_row_or0(h) * warp_wg_rows : 0.0), stream);
     launch_wgrad_bf16(reinterpret_cast<const WgradGroup*>(tables + p.bgroups_off_b),
                       reinterpret_cast<const WgradSegment*>(tables + p.bsegs_off_b),
                       reinterpret_cast<const int*>(tables + p.bsegbegin_off_b), p.bwgrad_nwg, ws, stream);
@@ -1697,7 +1852,7 @@ int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_ray
                                 const nrf_elastic* el, const nrf_warp_reg* wr, uint32_t flags, float* grad_params, float* stats,
                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
-  if (flags & ~(uint32_t)NRF_FLAG_BF16) return fail(NRF_E_UNSUPPORTED, "nrf_train_step_loss_grad_ex flags: 0 or NRF_FLAG_BF16");
+  if (flags & ~(uint32_t)(NRF_FLAG_BF16 | NRF_FLAG_WARP_F32)) return fail(NRF_E_UNSUPPORTED, "nrf_train_step_loss_grad_ex flags: 0, NRF_FLAG_BF16 [| NRF_FLAG_WARP_F32]");
   int bgN = 0;
   if (el) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the elastic regulariser needs the warp field");
@@ -1862,6 +2017,8 @@ int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* 
       {"w_bits", L.w_bits}, {"bits_trunk", L.bits_trunk}, {"bits_rgbh", L.bits_rgbh},
       {"b_pe", L.b_pe}, {"b_h", L.b_h}, {"b_bn", L.b_bn}, {"b_rgbh", L.b_rgbh}, {"b_bits", L.b_bits}, {"b_dy", L.b_dy},
       {"b_dbn", L.b_dbn}, {"b_drgbh", L.b_drgbh}, {"b_dsmall", L.b_dsmall},
+      {"bw_in", L.bw_in}, {"bw_h", L.bw_h}, {"bw_bits", L.bw_bits}, {"bw_dy", L.bw_dy}, {"bw_dhead", L.bw_dhead},
+      {"points_raw", L.points_raw},
       {"bg_points", h->plan.bg_points}, {"bg_ids", h->plan.bg_ids},
       {"timeline", h->plan.timeline + (size_t)(level & 1) * 2 * (256 + 512 + 4 * 2048)}};
   for (const auto& t : tab)

@@ -106,6 +106,10 @@ struct RcPackDesc {
   int ngroups, nout, nout_panel, o0;   // rows written, output blocks written, blocks per row of the chunk, first block position in the row
   int transposed;               // 0: A[m][k] = leaf[row0 + k][m] (forward); 1: A[m][k] = leaf[row0 + m][k] (dgrad: W as is)
   int oblk0;                    // first output block of the GEMM this descriptor covers (column 32 (oblk0 + o) + m)
+  // two leaves side by side (the SE3 heads w | v, [128, 3] each): split > 0 -> indices >= split of the OUTPUT columns (forward,
+  // bias) or of K (transposed) read leaf src_off2 at index - split
+  long long src_off2;
+  int split, pad_;
 };
 void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 
@@ -129,6 +133,23 @@ struct BfStash {
   uint32_t* drgbh;   // [ngroups][4]
   uint32_t* dsmall;  // [ngroups][2]   block 0 features 0..3 = d raw (r, g, b, sigma), everything else 0
   int ngroups;       // whole workgroup iterations: 8 * ceil(rows / 256)
+};
+
+// ---- bf16 SE3 trunk (warp_bf16.hip; NRF_FLAG_BF16 with the warp field) ----
+// Weight streams in KiB (chunk tables WF_* / WB_* in warp_bf16.hip; build_plan emits the chunks):
+//   forward:  L0 2 x 10, L1..L3 + L5 2 x 18 each, L4 (skip) 2 x 26, heads 9
+//   reverse:  heads^T 8, L5..L1 2 x 16 each, code-gradient GEMMs C0 / C4 16 each (the tangent reverse stops before them)
+constexpr int BFW_FWD_STREAM_KB = 2 * 10 + 8 * 18 + 2 * 26 + 9;
+constexpr int BFW_BWD_TAN_STREAM_KB = 8 + 10 * 16;
+constexpr int BFW_BWD_STREAM_KB = BFW_BWD_TAN_STREAM_KB + 2 * 16;
+// Stash of one pass over one level, units as BfStash (32-row group x 32-feature block = 2 KiB)
+struct BfWarpStash {
+  uint32_t* win;     // [ngroups][2]       trunk input: annealed posenc (or its tangent), code
+  uint32_t* h;       // [6][ngroups][4]    h1..h6, post-ReLU (tangent pass: masked tangents)
+  uint32_t* bits;    // [6][ngroups][64 lanes][2 dwords]: ReLU derivative bits (bf16_chain.h bits_push), dword = panel
+  uint32_t* dy;      // [6][ngroups][4]    dpre_0..5
+  uint32_t* dhead;   // [ngroups][2]       block 0 features 0..5 = (dL/dw, dL/dv), everything else 0
+  int ngroups;       // 8 * ceil(rows / 256)
 };
 
 struct ChainBwdBf16Args {
@@ -234,6 +255,12 @@ struct WarpFwdArgs {
   const float* prim_win;
   const uint32_t* prim_bits;
   int* tile_counter;         // zeroed before the launch
+  // bf16 trunk (warp_bf16.hip): this pass's stash (null pointers: inference), the stream, the primal pass's bits (tangent)
+  const float* bwpk;
+  BfWarpStash bst;
+  const uint32_t* bprim_bits;
+  int bng_prim;              // groups of the primal level (tangent pass: group = c * bng_prim + primal group)
+  int rows_pad;              // rows of the per-row fp32 outputs (points_out, st_wv): ntiles * 64; tangent: per coordinate
 };
 
 struct WarpBwdArgs {
@@ -259,10 +286,17 @@ struct WarpBwdArgs {
   int* tile_counter;         // zeroed before the launch
   int tangent;               // reverse of the tangent pass: d_w4 / d_v4 are INPUTS, masks of primal tile tt % nt_prim
   int nt_prim;               // tiles of the primal level (== ntiles for the primal pass)
+  // bf16 trunk (warp_bf16.hip)
+  const float* bwpk;         // reverse stream
+  BfWarpStash bst;           // dy / dhead written, bits read (tangent: the PRIMAL level's bits in bprim_bits)
+  const uint32_t* bprim_bits;
+  int bng_prim, rows_pad;
+  const float* x_rows;       // [rows][3] the points the field was evaluated at (fp32)
 };
 
 // training.compute_elastic_loss on the coarse samples (see warp_chain.hip elastic_kernel)
 struct ElasticArgs {
+  const float* x_rows;       // [rows][3] sample points (bf16 trunk: there is no fp32 input stash), or nullptr -> prim_win
   const float* prim_win;     // primal trunk-input stash (x = features 0..2)
   const float4* prim_wv;     // primal raw head outputs (w, v) per row
   const float4* tan_wv;      // [3][rows_pad] x 2: (dw/dx_c, dv/dx_c)
@@ -283,6 +317,7 @@ struct ElasticArgs {
 
 // warp Jacobian as an output (return_warp_jacobian, models.py:264-265): J = I + d/dx [exp_se3(w, v) x - x]
 struct JacobianArgs {
+  const float* x_rows;       // as ElasticArgs
   const float* prim_win;
   const float4* prim_wv;
   const float4* tan_wv;
@@ -464,6 +499,10 @@ struct EmbedDesc {
   int rows, ext_cols, int_cols, split, shift, pad_;
 };
 void launch_chain_fwd_bf16(const struct ChainFwdArgs& a, int grid, hipStream_t stream);
+// bf16 SE3 trunk: forward of one or two levels (a1: e.g. the background batch) or the tangent pass (a.prim_... set);
+// reverse of up to three levels, or of the tangent pass
+void launch_warp_fwd_bf16(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int max_grid, hipStream_t stream);
+void launch_warp_bwd_bf16(const WarpBwdArgs& a, const WarpBwdArgs* a1, const WarpBwdArgs* a2, int max_grid, hipStream_t stream);
 void launch_embed(const EmbedDesc* descs, int ndesc, const float* src, float* dst, bool to_internal, hipStream_t stream);
 
 // camera.hip -- Camera.pixels_to_rays / pixels_to_points / project (nerfies/camera.py)

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const WgradGroup* __res
     if (nrb == 4)                  wgrad_bf16_body<4, 4, 4>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 8 blocks: 32 KiB chunks
     else if (nrb == 2)             wgrad_bf16_body<2, 3, 5>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 4: 24 KiB
     else if (cpw == 3)             wgrad_bf16_body<1, 3, 6>(G, sg, ws, wb_lds, kb0, nb0, active);    // 2 x 8, 8 x 2: 20 KiB
-    else                           wgrad_bf16_body<1, 2, 10>(G, sg, ws, wb_lds, kb0, nb0, active);   // 4 x 2: 12 KiB
+    else if (G.Kb + G.Nb > 6)      wgrad_bf16_body<1, 2, 8>(G, sg, ws, wb_lds, kb0, nb0, active);    // 4 x 4 (SE3 trunk): 16 KiB
+    else                           wgrad_bf16_body<1, 2, 10>(G, sg, ws, wb_lds, kb0, nb0, active);   // 4 x 2, 2 x 4: 12 KiB
     __syncthreads();   // the next segment restages LDS
   }
 }

@@ -203,14 +203,24 @@ class NerfModel:
       self._layout = P.layout_from_infos(infos, total.value)
     return self._layout
 
+  @staticmethod
+  def bf16_flags(bf16) -> int:
+    """bf16=True: NRF_FLAG_BF16 (NeRF MLPs AND the SE3 trunk on bfloat16 operands); bf16='mlp': the NeRF MLPs only
+    (NRF_FLAG_WARP_F32: the round-3 behaviour); False: float32."""
+    if not bf16:
+      return 0
+    if bf16 == 'mlp':
+      return L.NRF_FLAG_BF16 | L.NRF_FLAG_WARP_F32
+    return L.NRF_FLAG_BF16
+
   def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0, elastic: bool = False,
-                jacobian: bool = False, bf16: bool = False) -> torch.Tensor:
-    bf16 = bool(bf16 and train)   # only the TRAINING layout depends on it (bf16 stash instead of the fp32 one)
+                jacobian: bool = False, bf16=False) -> torch.Tensor:
+    bf16 = bf16 if train else False   # only the TRAINING layout depends on it (bf16 stashes instead of the fp32 ones)
     key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic), bool(jacobian), bf16)
     ws = self._ws.get(key)
     if ws is None:
       nbytes = C.c_size_t(0)
-      flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jacobian else 0) | (L.NRF_FLAG_BF16 if bf16 else 0)
+      flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jacobian else 0) | self.bf16_flags(bf16)
       L.check(self.lib.nrf_workspace_bytes_ex(self.handle, num_rays, flags,
                                               int(num_background_points), int(bool(elastic)), C.byref(nbytes)), self.lib)
       ws = torch.empty((nbytes.value + 3) // 4, dtype=torch.float32, device=device)
@@ -340,7 +350,7 @@ class NerfModel:
       self._train_ws = (B, ws)   # the stash `backward` differentiates (fp32 or bf16 layout), and the batch size it is for
     stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     flags = (L.NRF_FLAG_TRAIN if train else 0) | (L.NRF_FLAG_NO_WARP if self.use_warp and not warp_on else 0) | \
-        (L.NRF_FLAG_BF16 if bf16 else 0) | (L.NRF_FLAG_WARP_JACOBIAN if jac_levels else 0)
+        self.bf16_flags(bf16) | (L.NRF_FLAG_WARP_JACOBIAN if jac_levels else 0)
     L.check(self.lib.nrf_forward(self.handle, _ptr(fp.flat), C.byref(rays), C.byref(scal), C.byref(rnd), C.byref(out),
                                  flags, _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2
@@ -420,7 +430,7 @@ class NerfModel:
     L.check(self.lib.nrf_train_step_loss_grad_ex(self.handle, _ptr(fp.flat), C.byref(rays), _ptr(target), C.byref(scal),
                                                  C.byref(rnd), C.byref(bg) if bg is not None else None,
                                                  C.byref(el) if el is not None else None,
-                                                 C.byref(wr) if wr is not None else None, L.NRF_FLAG_BF16 if bf16 else 0,
+                                                 C.byref(wr) if wr is not None else None, self.bf16_flags(bf16),
                                                  _ptr(grad), _ptr(stats), _ptr(ws), ws.numel() * 4, stream), self.lib)
     del keep, keep2, keep3
     return grad, stats

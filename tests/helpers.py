@@ -265,11 +265,11 @@ def assert_forward(r, spec, atol=1e-4):
 # ---------------------------------------------------------------------------------------------
 # bf16 training stash (csrc/nrf_internal.h BfStash) decoded to [rows, features] float64 matrices
 # ---------------------------------------------------------------------------------------------
-def bf16_stash(model, ws, name, level, nlayers, nblocks, rows, as_float32=False):
+def bf16_stash(model, ws, name, level, nlayers, nblocks, rows, as_float32=False, ngroups=None):
   """Buffer `name` ("b_pe", "b_h", "b_bn", "b_rgbh", "b_dy", "b_dbn", "b_drgbh", "b_dsmall") of `level`: [nlayers] matrices
   (rows, 32 * nblocks).  Layout per 32-sample group: [block b][jp][lane = n + 32 h][8 bf16], the 8 = features
   32 b + 8 (2 jp + jj) + 4 h + i in (jj, i) order."""
-  ng = (rows + 255) // 256 * 8
+  ng = ngroups if ngroups is not None else (rows + 255) // 256 * 8
   words = _ws_words(model, ws, name, level, nlayers * ng * nblocks * 512)
   a = words.view('uint16').reshape(nlayers, ng, nblocks, 2, 2, 32, 2, 4)        # [L][g][b][jp][h][n][jj][i]
   a = a.transpose(0, 1, 5, 2, 3, 6, 4, 7).reshape(nlayers, ng * 32, nblocks * 32)  # [L][g, n][b, jp, jj, h, i]

@@ -24,6 +24,10 @@ import helpers as H  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+# the step-1 checks below pin the NeRF-MLP chain against an oracle that rounds exactly what that chain rounds: they run the mode
+# that keeps the SE3 trunk in float32 (bf16='mlp' = NRF_FLAG_BF16 | NRF_FLAG_WARP_F32); the bfloat16 trunk has its own checks
+# in tests/test_gpu_bf16_warp.py, and the end-to-end gates (gradient direction, PSNR) run the full bf16 mode
+MLP = 'mlp'
 
 
 class _RoundFwd(torch.autograd.Function):
@@ -96,9 +100,9 @@ def check_forward_and_stash(setup, ulp_frac=0.05):
   spec, p, b, t_rand, u, model, fp, rngs = setup
   B = b['origins'].shape[0]
   gb = H.gpu_batch(b)
-  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=True)
+  grad, stats = model.loss_and_grad(fp, gb, warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=MLP)
   torch.cuda.synchronize()
-  ws = model.workspace(B, True, DEV, bf16=True)
+  ws = model.workspace(B, True, DEV, bf16=MLP)
   S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
   fine = spec.num_fine_samples > 0
   z_fine = torch.from_numpy(H._ws_words(model, ws, 'z', 1, B * S[1]).view('float32').reshape(B, S[1]).copy()).double() if fine else None
@@ -128,7 +132,7 @@ def check_forward_and_stash(setup, ulp_frac=0.05):
       close(hs[l][:, :tw], acts[(f'{name}/MLP_0', l)], (name, l))
       assert (hs[l][:, tw:] == 0).all()   # padded units of a narrower trunk stay dead
     close(rg[:, :rw], acts[(f'{name}/MLP_1', 0)], (name, 'rgb hidden'))
-  out = model.apply({'params': fp}, gb, {'alpha': WARP_ALPHA}, rngs=rngs, return_weights=True, bf16=True)
+  out = model.apply({'params': fp}, gb, {'alpha': WARP_ALPHA}, rngs=rngs, return_weights=True, bf16=MLP)
   for lv in out:
     np.testing.assert_allclose(out[lv]['weights'].cpu().numpy(), ret[lv]['weights'].detach().numpy(), atol=1e-4)
     np.testing.assert_allclose(out[lv]['rgb'].cpu().numpy(), ret[lv]['rgb'].detach().numpy(), atol=1e-3)
@@ -149,9 +153,9 @@ def check_backward_given_the_stash(setup):
   from nerfies_amd import params as P
   spec, p, b, t_rand, u, model, fp, rngs = setup
   B = b['origins'].shape[0]
-  grad, stats = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=True)
+  grad, stats = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': WARP_ALPHA}, rngs=rngs, bf16=MLP)
   torch.cuda.synchronize()
-  ws = model.workspace(B, True, DEV, bf16=True)
+  ws = model.workspace(B, True, DEV, bf16=MLP)
   S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
   got = P.tree_from_flat(grad.cpu(), model.layout)
   tw, rw, P_ = spec.nerf_trunk_width, spec.nerf_rgb_branch_width, 3 + 6 * spec.num_nerf_point_freqs
@@ -218,14 +222,16 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
   check_backward_given_the_stash(_setup(B, **kw))
 
 
-@pytest.mark.parametrize('kw,cos_floor', [({}, 0.99), (dict(use_warp=True, num_warp_freqs=6), 0.97)])
+# warp on: the bf16 SE3 trunk moves the warped points by ~1e-3 of the displacement, which the NeRF posenc amplifies by 2^(F_p - 1): the
+# first-layer / skip-row gradients of the high bands decorrelate (tests/test_gpu_bf16_warp.py separates the two effects)
+@pytest.mark.parametrize('kw,cos_floor', [({}, 0.99), (dict(use_warp=True, num_warp_freqs=6), 0.80)])
 def test_bf16_gradient_against_the_fp32_path(kw, cos_floor):
   from nerfies_amd import params as P
   B = 128
   spec, p, b, t_rand, u, model, fp, rngs = _setup(B, seed=9, **kw)
   gb = H.gpu_batch(b)
   extra = dict(warp_extra={'alpha': WARP_ALPHA}, rngs=rngs)
-  if kw:   # the regularisers run on the float32 warp kernels whatever the MLP mode
+  if kw:   # the regularisers' algebra (exp_se3, SVD) stays float32; the trunk they differentiate runs in the call's mode
     extra['elastic'] = {'weight': 0.01, 'reduce_method': 'weight'}
   g32, s32 = model.loss_and_grad(fp, gb, **extra)
   g32, s32 = g32.clone(), s32.clone()

@@ -37,7 +37,7 @@ def check_warp_leaves_given_d_points(setup, grad):
   from nerfies_amd import params as P
   spec, p, b, t_rand, u, model, fp, rngs = setup
   B = b['origins'].shape[0]
-  ws = model.workspace(B, True, DEV, bf16=True)
+  ws = model.workspace(B, True, DEV, bf16=T.MLP)
   torch.cuda.synchronize()
   S = (spec.num_coarse_samples, spec.num_coarse_samples + spec.num_fine_samples)
   leaves = [(path, t.float().double().requires_grad_(True)) for path, t in O.tree_leaves_with_path(p['warp_field'])]
@@ -89,7 +89,7 @@ def test_warp_leaves_given_d_points_small():
   """The same warp-leaf check at a size that runs in seconds (and with the camera code in the rgb condition)."""
   setup = T._setup(45, use_warp=True, num_warp_freqs=6, use_camera_metadata=True, num_coarse_samples=48, num_fine_samples=48)
   spec, p, b, t_rand, u, model, fp, rngs = setup
-  grad, _ = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': T.WARP_ALPHA}, rngs=rngs, bf16=True)
+  grad, _ = model.loss_and_grad(fp, H.gpu_batch(b), warp_extra={'alpha': T.WARP_ALPHA}, rngs=rngs, bf16=T.MLP)
   check_warp_leaves_given_d_points(setup, grad)
 
 

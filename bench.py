@@ -296,6 +296,12 @@ def roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg):
     # bottleneck 256 + rgb hidden 128 features, dY = dpre0..7 8x256 + d bottleneck 256 + d rgb hidden 128 + d raw 4, 2 B each
     rows = rays_per_gpu * (2 * cfg.num_coarse_samples + cfg.num_fine_samples)
     alg_bytes = rows * 2 * ((64 + 8 * 256 + 256 + 128) + (8 * 256 + 256 + 128 + 4))
+    if getattr(cfg, 'use_warp', False) and bf16 != 'mlp':
+      # + the SE3 trunk's stashes of every pass through the field: coarse + fine samples, 16384 background points, 3 tangents per
+      # coarse sample; per row X = trunk input (3 + 6 F_w + G) + h1..h6 6x128, dY = dpre0..5 6x128 + (dw, dv) 6
+      win = 3 + 6 * cfg.num_warp_freqs + cfg.num_warp_features
+      wrows = rows + 16384 + 3 * rays_per_gpu * cfg.num_coarse_samples
+      alg_bytes += wrows * 2 * ((win + 6 * 128) + (6 * 128 + 6))
     gbs = alg_bytes / (dom_ms * 1e-3) / 1e9
     r = {'bound': 'hbm', 'kernel': dom['name'], 'achieved': gbs, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS,
          'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'bytes_per_launch': alg_bytes}

@@ -87,14 +87,29 @@ struct BfRing {
   int soff;          // stream offset of the next chunk to copy
   int total;         // stream length (the chunk sequence is cyclic: one pass per 256-sample iteration)
   int slot;          // ring slot of the chunk being multiplied
+  int turn;          // which half of the workgroup (waves 0-3 / 4-7) issues the next chunk's copies
 };
 
-// `bytes` (whole KiB) of the stream at rg.soff -> ring slot `slot`; the workgroup's 8 waves take the 1-KiB pieces round robin
+// `bytes` (whole KiB) of the stream at rg.soff -> ring slot `slot`, in 1-KiB pieces.
+// NRF_BF_DMA_SPLIT (default): the copies of a chunk are issued by ONE HALF of the workgroup -- waves 0-3 or 4-7, i.e. one wave of
+// every SIMD (a workgroup's waves go to the SIMDs cyclically) -- and the halves take turns chunk by chunk: the ~10 SALU + VMEM
+// issue slots per piece sit right behind the chunk's barrier, where the two waves of a SIMD would otherwise BOTH be issuing
+// copies and the matrix pipe idles; now the partner wave goes straight back to its MFMAs.  The issuing wave's vmcnt wait in
+// front of the next barrier covers its pieces; the other half's wait passes at once.  0: all 8 waves take pieces round robin.
+#ifndef NRF_BF_DMA_SPLIT
+#define NRF_BF_DMA_SPLIT 1
+#endif
 __device__ __forceinline__ void bf_ring_copy(BfRing& rg, int slot, int bytes, int wave) {
   const unsigned dst = rg.lds0 + (unsigned)(slot * BF_SLOT);
   const int npieces = bytes >> 10;
   rg.soff = __builtin_amdgcn_readfirstlane(rg.soff);
+#if NRF_BF_DMA_SPLIT
+  if ((wave >> 2) == rg.turn)
+    for (int p = wave & 3; p < npieces; p += 4) lds_dma16s(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
+  rg.turn ^= 1;
+#else
   for (int p = wave; p < npieces; p += 8) lds_dma16s(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
+#endif
   rg.soff += bytes;
   if (rg.soff >= rg.total) rg.soff = 0;
 }
@@ -224,7 +239,7 @@ __device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* 
   c.rg.src = reinterpret_cast<const char*>(wpk);
   c.rg.voff = lane * 16;
   c.rg.lds0 = lds_byte_addr(lds);
-  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0;
+  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0; c.rg.turn = 0;
   c.ll = lds + lane * 16; c.wave = wave;
   bf_ring_copy(c.rg, 0, bytes0, wave);
   bf_ring_copy(c.rg, 1, bytes1, wave);

@@ -1,14 +1,14 @@
 #!/bin/bash
 # One command regenerates every figure DESIGN.md / README.md / BASELINE.md quote for a round:
-#   scripts/gpu_profile_round.sh r03a ["modes"]     (on the GPU box, e.g. through gpurun)
-# -> gpurun_out/<tag>_*.json|md ; scripts/collect_profiles.py <tag> r03 copies them into profiles/ (and merges the per-workload
+#   scripts/gpu_profile_round.sh r04a ["modes"]     (on the GPU box, e.g. through gpurun)
+# -> gpurun_out/<tag>_*.json|md ; scripts/collect_profiles.py <tag> r04 copies them into profiles/ (and merges the per-workload
 # HBM tables into profiles/hbm_traffic.json).
-# Then scripts/stamp_traffic.py r03 fills `roofline.traffic` of the copied bench lines from the PMC passes of the SAME run (the
-# bench line of a workload is written before its PMC passes exist) and scripts/fill_round_docs.py writes profiles/r03_summary.md.
+# Then scripts/stamp_traffic.py r04 fills `roofline.traffic` of the copied bench lines from the PMC passes of the SAME run (the
+# bench line of a workload is written before its PMC passes exist) and scripts/fill_round_docs.py writes profiles/r04_summary.md.
 # Passes are separate processes: bench line, rocprofv3 kernel trace, three PMC passes (SQ / FETCH_SIZE / WRITE_SIZE never
 # share a pass, never combined with a trace domain).
-TAG=${1:-r03}
-MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 train128 train128_graph"}
+TAG=${1:-r04}
+MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_warp eval_warp_bf16 train128 train128_graph"}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -16,6 +16,8 @@ summ() { f=$(find $1 -name '*.db' | head -1); [ -n "$f" ] && python scripts/rocp
 # gpurun copies back at most 64 MiB: the rocpd databases are dropped once summarised (hbm traffic is extracted first)
 clean() { rm -rf "$@"; }
 SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
+# LDS side of the bf16 chain kernels (its own pass): instructions, array-busy cycles, conflict cycles
+LDSC="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"
 for mode in $MODES; do
   PMC=1; TRACE=1
   case $mode in
@@ -27,6 +29,8 @@ for mode in $MODES; do
     fullhd_bf16)    ARGS="--mode fullhd --bf16";               SUF="_fullhd_bf16" ;;
     eval)           ARGS="--mode eval";                        SUF="_eval"; PMC=0 ;;
     eval_bf16)      ARGS="--mode eval --bf16";                 SUF="_eval_bf16"; PMC=0 ;;
+    eval_warp)      ARGS="--mode eval --warp --frame";         SUF="_eval_warp"; PMC=0 ;;
+    eval_warp_bf16) ARGS="--mode eval --warp --frame --bf16";  SUF="_eval_warp_bf16"; PMC=0 ;;
     train128)       ARGS="--rays-per-gpu 128";                 SUF="_train128"; PMC=0; TRACE=0 ;;
     train128_graph) ARGS="--rays-per-gpu 128 --graph";         SUF="_train128_graph"; PMC=0; TRACE=0 ;;
   esac
@@ -41,6 +45,10 @@ for mode in $MODES; do
   summ $O/prof_${TAG}${SUF} $O/${TAG}${SUF}_kernel_stats.md
   rocprofv3 --pmc $SQ -d $O/pmc1_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc1_${TAG}${SUF}.log 2>&1
   summ $O/pmc1_${TAG}${SUF} $O/${TAG}${SUF}_pmc_sq.md
+  case $mode in *bf16*)
+    rocprofv3 --pmc $LDSC -d $O/pmc4_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc4_${TAG}${SUF}.log 2>&1
+    summ $O/pmc4_${TAG}${SUF} $O/${TAG}${SUF}_pmc_lds.md; clean $O/pmc4_${TAG}${SUF} ;;
+  esac
   if [ $PMC = 1 ]; then
     rocprofv3 --pmc FETCH_SIZE -d $O/pmc2_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc2_${TAG}${SUF}.log 2>&1
     rocprofv3 --pmc WRITE_SIZE -d $O/pmc3_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc3_${TAG}${SUF}.log 2>&1

@@ -236,7 +236,39 @@ def run_pinned(spec, B, alpha, seed=3, strat=True, elastic=None, background=None
     scale = max(og.abs().max().item(), 1e-30)
     errs[path] = ((leaf(got, path).double() - og).abs().max().item() / scale, scale)
   return dict(model=model, fp=fp, gb=gb, rngs=rngs, stats=stats.cpu(), loss=loss.item(), ostats=ostats, ret=ret, errs=errs, hook=hook,
-              alpha=alpha, time_alpha=time_alpha, tol=grad_tol(spec))
+              alpha=alpha, time_alpha=time_alpha, tol=grad_tol(spec), spec=spec, p64=p64, b64=b64, t_rand=t_rand, u=u, okw=okw, got=got)
+
+
+def assert_unpinned(r, label, factor=3.0):
+  """The UNPINNED full-shape statistic: the same HIP gradient against the FREE-RUNNING float64 oracle -- its own
+  ReLU branches, its own fine samples, nothing taken from the HIP path -- as per-leaf relative L2 distance, next to the distance of
+  the oracle's own float32 evaluation from that float64 run.  float32 ties flip whole ReLU columns in ANY float32 evaluation
+  order, so element-wise agreement is not a property a float32 path can have (that is what the pinned comparison removes); what
+  can be asserted without conditioning on the HIP path's outputs is that it sits no further from float64 than `factor` x the
+  reference arithmetic restated in float32 does."""
+  spec, p64, b64 = r['spec'], r['p64'], r['b64']
+  to32 = lambda t: t.float() if torch.is_tensor(t) and t.is_floating_point() else t
+  _, _, g64, _ = O.loss_and_grad(p64, spec, b64, warp_alpha=r['alpha'], t_rand=r['t_rand'], u=r['u'], **r['okw'])
+  p32 = O.tree_map(to32, p64)
+  b32 = {k: (O.tree_map(to32, v) if isinstance(v, dict) else to32(v)) for k, v in b64.items()}
+  okw32 = {k: (O.tree_map(to32, v) if isinstance(v, dict) else to32(v)) for k, v in r['okw'].items()}
+  _, _, g32, _ = O.loss_and_grad(p32, spec, b32, warp_alpha=r['alpha'], t_rand=to32(r['t_rand']) if r['t_rand'] is not None else None,
+                                 u=to32(r['u']) if r['u'] is not None else None, **okw32)
+  worst = ('', 0.0, 0.0)
+  rows = []
+  for (path, want), (_, f32) in zip(O.tree_leaves_with_path(g64), O.tree_leaves_with_path(g32)):
+    nrm = max(want.norm().item(), 1e-30)
+    l2_gpu = (leaf(r['got'], path).double() - want).norm().item() / nrm
+    l2_f32 = (f32.double() - want).norm().item() / nrm
+    rows.append((path, l2_gpu, l2_f32))
+    if l2_gpu > worst[1]:
+      worst = (path, l2_gpu, l2_f32)
+  med_gpu = sorted(x[1] for x in rows)[len(rows) // 2]
+  med_f32 = sorted(x[2] for x in rows)[len(rows) // 2]
+  print(f'[{label}, UNPINNED vs the free-running float64 oracle] per-leaf relative L2: worst {worst[0]} hip {worst[1]:.2e} '
+        f'(float32 oracle {worst[2]:.2e}); median hip {med_gpu:.2e} / float32 oracle {med_f32:.2e}')
+  for path, l2_gpu, l2_f32 in rows:
+    assert l2_gpu <= factor * l2_f32 + 1e-5, (label, path, l2_gpu, l2_f32)
 
 
 def assert_pinned(r, label, loss_tol=1e-5):

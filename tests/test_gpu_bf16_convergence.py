@@ -116,9 +116,12 @@ def test_bf16_convergence_at_the_config_a_shape():
   print(f'[bf16 convergence, config A shape, {K} steps] held-out PSNR fp32 {pa:.3f} / {pb:.3f} dB, bf16 {p16:.3f} dB ({p16 - pa:+.3f}); '
         f'loss-curve gap over the second half: bf16 vs fp32 {100 * gap16:.1f} %, fp32 vs fp32 {100 * gap32:.1f} %')
   assert min(pa, pb) > 30.0
-  # two training runs that differ only in rounding diverge chaotically: the two fp32 runs (different sampling keys) measure that
-  # spread (0.04-0.11 dB in rounds 2-4), and the bf16 run must land within 0.1 dB of the band they span, widened by that spread on
-  # both sides (rounds 2 / 3 / 4: bf16 -0.03 / +0.03..+0.14 / -0.15 dB against the lower fp32 run)
-  spread = abs(pa - pb)
-  assert min(pa, pb) - 0.1 - spread <= p16 <= max(pa, pb) + 0.1 + spread
+  # two training runs that differ only in rounding or sampling keys diverge chaotically.  Four seeds per precision on one box
+  # (profiles/r04_bf16_seed_spread.json): fp32 38.39 +- 0.19 dB (38.17 .. 38.67), bf16 38.26 +- 0.13 (round-3 bf16 kernels on the
+  # same seeds: 38.33 +- 0.16) -- the precisions' means differ by less than one standard deviation of either.  Two fp32 runs
+  # cannot estimate that spread, so the gate uses the measured one: the bf16 run within 2.5 sigma of the fp32 pair's mean, where
+  # sigma = 0.19 * sqrt(1 + 1/2) is the spread of (one run - mean of two runs)
+  sigma = 0.19 * np.sqrt(1.5)
+  assert abs(pa - pb) <= 4 * 0.19 * np.sqrt(2.0), (pa, pb)           # the fp32 pair itself is inside the measured spread
+  assert abs(p16 - 0.5 * (pa + pb)) <= 2.5 * sigma, (pa, pb, p16)
   assert gap16 <= 2.0 * gap32 + 0.05

@@ -222,9 +222,9 @@ def test_bf16_backward_matches_float64_given_the_stash(B, kw):
   check_backward_given_the_stash(_setup(B, **kw))
 
 
-# warp on: the bf16 SE3 trunk moves the warped points by ~1e-3 of the displacement, which the NeRF posenc amplifies by 2^(F_p - 1): the
-# first-layer / skip-row gradients of the high bands decorrelate (tests/test_gpu_bf16_warp.py separates the two effects)
-@pytest.mark.parametrize('kw,cos_floor', [({}, 0.99), (dict(use_warp=True, num_warp_freqs=6), 0.80)])
+# warp on: bf16='mlp' (NeRF MLPs in bf16, SE3 trunk float32) -- this test prices the MLP chain; the bf16 trunk in front of the
+# 2^(F_p - 1) posenc is priced separately (tests/test_gpu_bf16_warp.py: realistic and "trained-like" head scales)
+@pytest.mark.parametrize('kw,cos_floor', [({}, 0.99), (dict(use_warp=True, num_warp_freqs=6), 0.97)])
 def test_bf16_gradient_against_the_fp32_path(kw, cos_floor):
   from nerfies_amd import params as P
   B = 128
@@ -235,7 +235,7 @@ def test_bf16_gradient_against_the_fp32_path(kw, cos_floor):
     extra['elastic'] = {'weight': 0.01, 'reduce_method': 'weight'}
   g32, s32 = model.loss_and_grad(fp, gb, **extra)
   g32, s32 = g32.clone(), s32.clone()
-  g16, s16 = model.loss_and_grad(fp, gb, bf16=True, **extra)
+  g16, s16 = model.loss_and_grad(fp, gb, bf16=MLP if kw else True, **extra)
   assert torch.isfinite(g16).all()
   assert abs(s16[4].item() - s32[4].item()) < 1e-3
   t32, t16 = P.tree_from_flat(g32.cpu(), model.layout), P.tree_from_flat(g16.cpu(), model.layout)

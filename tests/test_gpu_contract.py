@@ -309,3 +309,38 @@ def test_time_encoder_codes_can_be_supplied_encoded():
   enc['metadata'] = {'time': codes.float().to(DEV)}   # models.py:252-254: the warp metadata of a 'time' model is metadata['time']
   by_codes = model.apply({'params': fp}, enc, {'alpha': 3.0, 'time_alpha': 1.0}, metadata_encoded=True)
   np.testing.assert_allclose(_np(by_codes['fine']['rgb']), _np(by_time['fine']['rgb']), atol=2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# one handle, several (num_rays, flags): the handle caches ONE workspace plan (include/nerfies_amd.h "Conventions")
+# ---------------------------------------------------------------------------------------------
+def test_one_handle_alternating_batch_sizes_flags_and_streams():
+  """Calls on one handle are serialised by the caller, but they may alternate batch sizes, flags and streams freely: the plan is
+  rebuilt and the descriptor tables are re-uploaded whenever (num_rays, flags) or the workspace change.  Interleaved inference at
+  8 rays, training at 20 rays, bf16 inference at 8 rays -- the middle calls on a side stream -- must give exactly what fresh
+  handles give for each call on its own."""
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=6, use_warp=True, num_warp_freqs=4)
+  p = O.init_params(spec, seed=8, trained_like=True)
+  b8, b20 = H.gpu_batch(O.synthetic_batch(8, seed=1)), H.gpu_batch(O.synthetic_batch(20, seed=2))
+  we = {'alpha': 2.5}
+
+  def fresh(fn):
+    m, f = H.gpu_model(spec, p, 8)
+    return fn(m, f)
+  inf8 = lambda m, f: m.apply({'params': f}, b8, we)['fine']['rgb'].clone()
+  bf8 = lambda m, f: m.apply({'params': f}, b8, we, bf16=True)['fine']['rgb'].clone()
+  tr20 = lambda m, f: tuple(t.clone() for t in m.loss_and_grad(f, b20, warp_extra=we, rngs={'coarse': 3, 'fine': 4}))
+  want8, want8b, (wantg, wants) = fresh(inf8), fresh(bf8), fresh(tr20)
+  model, fp = H.gpu_model(spec, p, 8)
+  side = torch.cuda.Stream()
+  for rep in range(3):
+    got8 = inf8(model, fp)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+      gotg, gots = tr20(model, fp)
+      got8b = bf8(model, fp)
+    side.synchronize()
+    np.testing.assert_array_equal(_np(got8), _np(want8))
+    np.testing.assert_array_equal(_np(got8b), _np(want8b))
+    np.testing.assert_allclose(_np(gots), _np(wants), rtol=1e-6, atol=1e-7)
+    assert (gotg - wantg).abs().max().item() <= 1e-5 * wantg.abs().max().item()   # embedding / per-ray sums use atomics

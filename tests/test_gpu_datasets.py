@@ -94,7 +94,8 @@ EvalConfig.num_val_eval = 1
 """
 
 
-@pytest.mark.parametrize('extra', [[], ['--bf16']])   # --bf16: bf16 training mode, then bf16-operand rendering in eval.py
+# --bf16: bf16 training mode, then bf16-operand rendering in eval.py; --graph: the whole step replayed from one hipGraph
+@pytest.mark.parametrize('extra', [[], ['--bf16'], ['--graph']])
 def test_train_and_eval_drivers_end_to_end(tmp_path, capsys, extra):
   sys.path.insert(0, ROOT)
   import eval as eval_driver
@@ -119,7 +120,7 @@ def test_train_and_eval_drivers_end_to_end(tmp_path, capsys, extra):
   assert sorted(loss) == [10, 20, 30, 40] and loss[40] < loss[10]
   assert any(r.get('tag') == 'loss/background' for r in scal) and any(r.get('tag') == 'loss/elastic/coarse' for r in scal)
   gin.clear_config()
-  res = eval_driver.main(args)
+  res = eval_driver.main([a for a in args if a != '--graph'])
   assert set(res) == {'val', 'train'} and res['val']['psnr'] > 5 and np.isfinite(res['train']['mse'])
   rdir = os.path.join(exp, 'renders', '00000040', 'val')
   names = sorted(os.listdir(rdir))

@@ -80,6 +80,8 @@ def test_config_a_full_batch_vs_oracle():
     r = run_pinned(spec, 1024, 0.0, seed=11)
   assert_pinned(r, 'config A 1024x(64+128)')
   assert_forward(r, spec)
+  with _threads(64):
+    H.assert_unpinned(r, 'config A 1024x(64+128)')
 
 
 def test_config_c_full_shard_vs_oracle():
@@ -96,6 +98,8 @@ def test_config_c_full_shard_vs_oracle():
   o = r['ostats']
   assert abs(r['stats'][5].item() - o['background_loss'].item()) < 1e-6 + 2e-4 * abs(o['background_loss'].item())
   assert abs(r['stats'][6].item() - o['coarse']['loss/elastic'].item()) < 1e-6 + 2e-4 * abs(o['coarse']['loss/elastic'].item())
+  with _threads(64):
+    H.assert_unpinned(r, 'config C 768x(128+128) warp+elastic+bg')
 
 
 def test_config_d_full_shard_vs_oracle():
@@ -107,6 +111,8 @@ def test_config_d_full_shard_vs_oracle():
     r = run_pinned(spec, 512, 8.0, seed=13)
   assert_pinned(r, 'config D 512x(256+256) F_p=10 warp')
   assert_forward(r, spec)
+  with _threads(64):
+    H.assert_unpinned(r, 'config D 512x(256+256) F_p=10 warp')
 
 
 # ---------------------------------------------------------------------------------------------

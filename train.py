@@ -29,6 +29,9 @@ def parse_flags(argv=None):
   p.add_argument('--bf16', action='store_true', help='bfloat16 MLP operands (NRF_FLAG_BF16; no reference counterpart): train.py trains '
                  'with a bfloat16 activation / gradient stash (fp32 master weights, loss, Adam; ~3.5x the fp32 step), eval.py renders '
                  'with them (~5x faster, ~1e-2 on colour)')
+  p.add_argument('--graph', action='store_true', help='replay the whole train step (loss + gradient, all-reduce, Adam) from ONE hipGraph '
+                 '(training.GraphedTrainStep): the reference jits the step into one XLA executable (train.py:254-262); worth it for small '
+                 'per-GPU batches, where the ~25 launches of a step take about as long as the kernels')
   return p.parse_args(argv)
 
 
@@ -105,6 +108,10 @@ def main(argv=None):
   log(f'Starting training at step {init_step}: {datasource.__class__.__name__}, {world} GPU(s), '
       f'batch {train_config.batch_size} rays')
   step = init_step - 1
+  gstep = None      # --graph: built on the first batch (the capture needs static input buffers of the batch's shapes)
+  step_flags = dict(use_elastic_loss=train_config.use_elastic_loss, elastic_reduce_method=train_config.elastic_reduce_method,
+                    elastic_loss_type=train_config.elastic_loss_type, use_background_loss=train_config.use_background_loss,
+                    use_warp_reg_loss=train_config.use_warp_reg_loss)
   for step in range(init_step, max_steps + 1):
     batch = next(train_iter)
     if points is not None:
@@ -117,11 +124,13 @@ def main(argv=None):
                                                  elastic_loss_weight=elastic_sched(step))
     state.warp_alpha, state.time_alpha = warp_alpha_sched(step), time_alpha_sched(step)
     with tracker.record_time('train_step'):
-      state, stats, key = training.train_step(
-          model, key, state, batch, scalar_params, use_elastic_loss=train_config.use_elastic_loss,
-          elastic_reduce_method=train_config.elastic_reduce_method, elastic_loss_type=train_config.elastic_loss_type,
-          use_background_loss=train_config.use_background_loss, use_warp_reg_loss=train_config.use_warp_reg_loss,
-          bf16=flags.bf16)
+      if flags.graph:
+        if gstep is None:
+          gstep = training.GraphedTrainStep(model, state, batch, scalar_params, bf16=flags.bf16, **step_flags)
+        stats = gstep(key, scalar_params, warp_alpha=state.warp_alpha, time_alpha=state.time_alpha, batch=batch)
+        key = training._step_keys(key)[0]
+      else:
+        state, stats, key = training.train_step(model, key, state, batch, scalar_params, bf16=flags.bf16, **step_flags)
       if step % train_config.print_every == 0 or step % train_config.log_every == 0:
         torch.cuda.synchronize(device)            # only when the numbers are read
     tracker.toc('total')

@@ -1368,6 +1368,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       if ((lv == 0 && train && p.elastic) || (jac && jout)) launch_tangent_fwd(h, lv, params, rays, scalars, ws, gmul, stream);
       if (jac && jout) {
         JacobianArgs ja;
+        memset(&ja, 0, sizeof(ja));   // x_rows = nullptr: the points come from the fp32 input stash
         ja.prim_win = ws + L.w_st_win; ja.prim_wv = reinterpret_cast<const float4*>(ws + L.w_st_wv);
         ja.tan_wv = reinterpret_cast<const float4*>(ws + p.L[TG].w_st_wv); ja.out = jout;
         ja.rows = p.rows[lv]; ja.rows_pad = p.ntiles[lv] * TILE_ROWS; ja.PKS = (h->PKw + 31) / 32 * 32;

@@ -34,9 +34,10 @@ def _setup(B, seed=5, nbg=0, head_scale=1.0, **kw):
                                  use_warp=True, num_warp_freqs=8, num_warp_features=8), **kw))
   p = O.init_params(spec, seed=seed, trained_like=True, dtype=torch.float64)
   if head_scale != 1.0:   # the "trained-like" heads throw points several scene sizes away; a capture's deformations are ~ 0.05
-    for br in ('branches_w', 'branches_v'):
+    heads = [p['warp_field']['mlp']] if spec.warp_field_type == 'translation' else [p['warp_field'][br] for br in ('branches_w', 'branches_v')]
+    for hd in heads:
       for k in ('kernel', 'bias'):
-        p['warp_field'][br]['logit'][k] = p['warp_field'][br]['logit'][k] * head_scale
+        hd['logit'][k] = hd['logit'][k] * head_scale
   b = O.synthetic_batch(B, seed=seed + 1, dtype=torch.float64)
   g = torch.Generator().manual_seed(seed + 2)
   rngs = {'coarse': torch.rand(B, spec.num_coarse_samples, generator=g).to(DEV),
@@ -213,7 +214,11 @@ def test_bf16_warp_stash_chain_and_leaf_gradients_given_the_stash():
 
 @pytest.mark.parametrize('kw,head_scale', [(dict(num_warp_freqs=6, use_camera_metadata=True), 0.02),
                                            (dict(num_nerf_point_freqs=10, num_coarse_samples=64, num_fine_samples=64), 0.02),
-                                           (dict(num_warp_freqs=6, use_camera_metadata=True), 1.0)])
+                                           (dict(num_warp_freqs=6, use_camera_metadata=True), 1.0),
+                                           # TranslationField (warping.py:62-199) = the trunk with a zero rotation head
+                                           (dict(warp_field_type='translation', num_warp_freqs=5), 0.05),
+                                           # codes from modules.TimeEncoder (one row per ray) instead of the GLO table
+                                           (dict(warp_metadata_encoder_type='time', num_warp_freqs=6), 0.02)])
 def test_bf16_warp_against_the_float32_trunk(kw, head_scale):
   """What the bfloat16 trunk costs next to the float32 trunk, everything else (bf16 NeRF MLPs, rays, uniforms) equal.
 
@@ -227,13 +232,15 @@ def test_bf16_warp_against_the_float32_trunk(kw, head_scale):
     tests/test_gpu_pinned.py), not an error of the kernels -- those are pinned by the given-the-stash test above; here only the
     values that do not pass through the NeRF posenc are compared (warped points, regulariser values)."""
   from nerfies_amd import params as P
-  B, nbg = 96, 512
+  time_enc = kw.get('warp_metadata_encoder_type') == 'time'
+  B, nbg = 96, (0 if time_enc else 512)   # the background points carry warp ids, which a time-encoded field does not have
+  wextra = {'alpha': ALPHA, 'time_alpha': 1.0} if time_enc else {'alpha': ALPHA}
   spec, p, b, model, fp, rngs, bg = _setup(B, seed=11, nbg=nbg, head_scale=head_scale, **kw)
   gb = H.gpu_batch(b)
   realistic = head_scale < 1.0
   # inference: warped points
-  o16 = model.apply({'params': fp}, gb, {'alpha': ALPHA}, rngs=rngs, return_points=True, bf16=True)
-  o32 = model.apply({'params': fp}, gb, {'alpha': ALPHA}, rngs=rngs, return_points=True, bf16='mlp')
+  o16 = model.apply({'params': fp}, gb, wextra, rngs=rngs, return_points=True, bf16=True)
+  o32 = model.apply({'params': fp}, gb, wextra, rngs=rngs, return_points=True, bf16='mlp')
   for lv in ('coarse', 'fine'):
     disp = (o32[lv]['warped_points'] - o32[lv]['points']).abs().max().item()
     dxs = (o16[lv]['warped_points'] - o32[lv]['warped_points']).abs()
@@ -244,13 +251,13 @@ def test_bf16_warp_against_the_float32_trunk(kw, head_scale):
     if realistic:
       assert (o16[lv]['rgb'] - o32[lv]['rgb']).abs().max().item() < 2e-2
   # training: loss, regulariser values, gradient directions
-  extra = dict(warp_extra={'alpha': ALPHA}, rngs=rngs, background=bg, elastic={'weight': 0.01, 'reduce_method': 'weight'})
+  extra = dict(warp_extra=wextra, rngs=rngs, background=bg, elastic={'weight': 0.01, 'reduce_method': 'weight'})
   g32, s32 = model.loss_and_grad(fp, gb, bf16='mlp', **extra)
   g32, s32 = g32.clone(), s32.clone()
   g16, s16 = model.loss_and_grad(fp, gb, bf16=True, **extra)
   assert torch.isfinite(g16).all() and torch.isfinite(s16).all()
   assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
-  for k, what in ((5, 'background loss'), (6, 'elastic loss'), (7, 'elastic residual')):
+  for k, what in ((5, 'background loss'), (6, 'elastic loss'), (7, 'elastic residual'))[(1 if time_enc else 0):]:
     assert abs(s16[k].item() - s32[k].item()) < 2e-2 * abs(s32[k].item()) + 1e-9, (what, s16[k].item(), s32[k].item())
   t32, t16 = P.tree_from_flat(g32.cpu(), model.layout), P.tree_from_flat(g16.cpu(), model.layout)
   cos_min, cos_warp, table = 1.0, 1.0, []

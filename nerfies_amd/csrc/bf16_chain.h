@@ -99,8 +99,9 @@ struct BfRing {
 #ifndef NRF_BF_DMA_SPLIT
 #define NRF_BF_DMA_SPLIT 1
 #endif
+template <int SLOT = BF_SLOT>
 __device__ __forceinline__ void bf_ring_copy(BfRing& rg, int slot, int bytes, int wave) {
-  const unsigned dst = rg.lds0 + (unsigned)(slot * BF_SLOT);
+  const unsigned dst = rg.lds0 + (unsigned)(slot * SLOT);
   const int npieces = bytes >> 10;
   rg.soff = __builtin_amdgcn_readfirstlane(rg.soff);
 #if NRF_BF_DMA_SPLIT
@@ -158,19 +159,30 @@ __device__ __forceinline__ constexpr int epi_stores_before(int kend, int SPAN) {
   return n;
 }
 
-// ESPAN / EOPS / ESTORE: the epilogue riding in this chunk (epi(k) behind MFMA k): 16 units over slots 1 .. ESPAN (0: none), VALU
-// instructions per unit, whether every 4th unit is followed by a stash store
-template <int PB, int R, bool INIT, int ESPAN, int EOPS, bool ESTORE, class BSel, class Epi>
-__device__ __forceinline__ void bf_chunk(f32x16 (&acc)[PB], bf16x8 (&fr)[BF_DF], BfRing& rg, const char* lds_lane, int wave,
+// ESPAN / EOPS / ESTORE: the epilogue riding in this panel (epi(k) behind MFMA k): 16 units over slots 1 .. ESPAN (0: none), VALU
+// instructions per unit, whether every 4th unit is followed by a stash store.
+// A chunk (= one ring slot = one barrier) may hold SEVERAL panels back to back: F0 = this panel's first fragment inside the chunk,
+// NFC = the chunk's fragment count, PRE = stash stores the chunk's earlier panels issue.  The barrier + the copy of chunk g+2 sit BF_DF fragments before the CHUNK's end, in whichever
+// panel that falls (bytes2 is ignored by the others); the ring slot advances behind the chunk's last panel.  Short layers (the
+// 64-wide first layer, the 128-wide SE3 trunk, the heads) are merged this way: the barriers, not the MFMAs, bound them.
+template <int PB, int R, bool INIT, int ESPAN, int EOPS, bool ESTORE, int F0, int NFC, int SLOT, int PRE, class BSel, class Epi>
+__device__ __forceinline__ void bf_panel(f32x16 (&acc)[PB], bf16x8 (&fr)[BF_DF], BfRing& rg, const char* lds_lane, int wave,
                                          int bytes2, BSel bsel, Epi epi) {
   constexpr int NF = PB * R;
-  static_assert(NF >= BF_DF, "a chunk must hold at least BF_DF fragments");
-  static_assert(ESPAN < NF, "the epilogue must fit the chunk");
-  constexpr int NST = (ESPAN > 0 && ESTORE) ? epi_stores_before(NF - BF_DF, ESPAN) : 0;
+  static_assert(NFC >= BF_DF, "a chunk must hold at least BF_DF fragments");
+  static_assert(F0 >= 0 && F0 + NF <= NFC, "the panel must lie inside its chunk");
+  static_assert(NFC * BF_KB <= SLOT && 3 * SLOT <= 160 * BF_KB, "a chunk must fit a ring slot, three slots the LDS");
+  static_assert(ESPAN < NF, "the epilogue must fit the panel");
+  constexpr int KSYNC = NFC - BF_DF - F0;   // the panel-local slot in front of which the chunk synchronises (if 0 <= KSYNC < NF)
+  constexpr bool LAST = F0 + NF == NFC;
+  // stores this wave has issued since the copy it waits for: PRE (by the chunk's earlier panels; the caller's count, a lower bound
+  // is safe) + this panel's in front of the barrier.  Counting them matters: a smaller number makes the wait cover stash stores
+  // issued moments ago, i.e. an HBM write round trip (measured: the merged G1 / G2 chunk of the dgrad ran 5 % slower with PRE = 0)
+  constexpr int NST = PRE + ((ESPAN > 0 && ESTORE && KSYNC >= 0 && KSYNC < NF) ? epi_stores_before(KSYNC, ESPAN) : 0);
   const int s1 = rg.slot == 2 ? 0 : rg.slot + 1;
   const int s2 = rg.slot == 0 ? 2 : rg.slot - 1;
-  const char* cb = lds_lane + rg.slot * BF_SLOT;
-  const char* nb = lds_lane + s1 * BF_SLOT;
+  const char* cb = lds_lane + rg.slot * SLOT;
+  const char* nb = lds_lane + s1 * SLOT;
   if (INIT) {
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -178,18 +190,18 @@ __device__ __forceinline__ void bf_chunk(f32x16 (&acc)[PB], bf16x8 (&fr)[BF_DF],
   }
 #pragma unroll
   for (int k = 0; k < NF; ++k) {
-    if (k == NF - BF_DF) {
+    if (k == KSYNC) {
       __builtin_amdgcn_sched_barrier(0);
-      bf_wait_vm<NST>();                 // my pieces of chunk g+1 (copied one chunk ago) have landed; this chunk's stores may fly
+      bf_wait_vm<NST>();                 // my pieces of chunk g+1 (copied one chunk ago) have landed; this panel's stores may fly
       __builtin_amdgcn_s_barrier();      // ... and everyone's; all waves are done with chunk g-1's slot
       asm volatile("" ::: "memory");
-      bf_ring_copy(rg, s2, bytes2, wave);
+      bf_ring_copy<SLOT>(rg, s2, bytes2, wave);
       __builtin_amdgcn_sched_barrier(0);
     }
-    const int r = k / PB, p = k % PB;
-    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[k % BF_DF], bsel(r), acc[p], 0, 0, 0);
-    fr[k % BF_DF] = k + BF_DF < NF ? *reinterpret_cast<const bf16x8*>(cb + (k + BF_DF) * BF_KB)
-                                   : *reinterpret_cast<const bf16x8*>(nb + (k + BF_DF - NF) * BF_KB);
+    const int r = k / PB, p = k % PB, f = F0 + k;
+    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[f % BF_DF], bsel(r), acc[p], 0, 0, 0);
+    fr[f % BF_DF] = f + BF_DF < NFC ? *reinterpret_cast<const bf16x8*>(cb + (f + BF_DF) * BF_KB)
+                                    : *reinterpret_cast<const bf16x8*>(nb + (f + BF_DF - NFC) * BF_KB);
     epi(k);
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
@@ -198,14 +210,24 @@ __device__ __forceinline__ void bf_chunk(f32x16 (&acc)[PB], bf16x8 (&fr)[BF_DF],
       if constexpr (ESTORE) sgb_vmw_n(epi_stores_at(k, ESPAN));
     }
   }
-  if constexpr (NF % BF_DF != 0) {   // slot i <- fragment i of the next chunk
-    bf16x8 t[BF_DF];
+  if constexpr (LAST) {
+    if constexpr (NFC % BF_DF != 0) {   // slot i <- fragment i of the next chunk
+      bf16x8 t[BF_DF];
 #pragma unroll
-    for (int i = 0; i < BF_DF; ++i) t[i] = fr[(i + NF) % BF_DF];
+      for (int i = 0; i < BF_DF; ++i) t[i] = fr[(i + NFC) % BF_DF];
 #pragma unroll
-    for (int i = 0; i < BF_DF; ++i) fr[i] = t[i];
+      for (int i = 0; i < BF_DF; ++i) fr[i] = t[i];
+    }
+    rg.slot = s1;
   }
-  rg.slot = s1;
+}
+
+// One chunk = one panel: acc[p] (+)= sum over the R rows of  A[row][p] . B[row],  A fragments from the ring, B = bsel(row)
+// (registers).  fr[] holds fragments 0 .. BF_DF-1 of this chunk on entry and of the next chunk on exit.
+template <int PB, int R, bool INIT, int ESPAN, int EOPS, bool ESTORE, class BSel, class Epi>
+__device__ __forceinline__ void bf_chunk(f32x16 (&acc)[PB], bf16x8 (&fr)[BF_DF], BfRing& rg, const char* lds_lane, int wave,
+                                         int bytes2, BSel bsel, Epi epi) {
+  bf_panel<PB, R, INIT, ESPAN, EOPS, ESTORE, 0, PB * R, BF_SLOT, 0>(acc, fr, rg, lds_lane, wave, bytes2, bsel, epi);
 }
 
 // 16-byte stash store (non-temporal: written once, read by another kernel much later): buffer store with the whole offset in
@@ -235,14 +257,15 @@ struct ChainCtx {
 
 
 // the ring's first two chunks, the first fragments
+template <int SLOT = BF_SLOT>
 __device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* wpk, int total, int bytes0, int bytes1, int lane, int wave) {
   c.rg.src = reinterpret_cast<const char*>(wpk);
   c.rg.voff = lane * 16;
   c.rg.lds0 = lds_byte_addr(lds);
   c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0; c.rg.turn = 0;
   c.ll = lds + lane * 16; c.wave = wave;
-  bf_ring_copy(c.rg, 0, bytes0, wave);
-  bf_ring_copy(c.rg, 1, bytes1, wave);
+  bf_ring_copy<SLOT>(c.rg, 0, bytes0, wave);
+  bf_ring_copy<SLOT>(c.rg, 1, bytes1, wave);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");

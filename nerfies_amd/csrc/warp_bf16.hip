@@ -2,7 +2,8 @@
 // MLPs, and SE3Field's 6 x 128 trunk is the other MLP config D contains): forward, forward-mode tangent pass, and the reverse
 // of both.  Same design as the NeRF chains (bf16_chain.h): transposed GEMMs, a wave owns 32 rows and all 128 features, activations
 // stay in registers across layers, weights stream through the three-slot LDS ring, a layer is two panels of two output blocks
-// and the epilogue of a panel rides under the MFMAs of the next one.
+// and the epilogue of a panel rides under the MFMAs of the next one.  Both panels of a layer (and the heads / heads^T block) share
+// one ring slot, i.e. one barrier per layer: 6 per 256-row iteration forward (52 KiB slots: the skip layer fits one), 5-6 reverse.
 //
 // Replaces, in that mode (reference /root/reference/nerfies):
 //   modules.AnnealedSinusoidalEncoder   modules.py:231-294   prologue, fp32, packed to bf16 B operands
@@ -22,11 +23,14 @@ namespace {
 
 typedef unsigned int u32x2v __attribute__((ext_vector_type(2)));
 
-constexpr int WF_L0 = 10 * BF_KB, WF_T = 18 * BF_KB, WF_S = 26 * BF_KB, WF_HD = 9 * BF_KB;
-constexpr int WF_TOTAL = 2 * WF_L0 + 8 * WF_T + 2 * WF_S + WF_HD;
+// chunks (= ring slots = barriers) of the forward stream: layer 0 | layers 1..3 | skip layer | layer 5 + heads
+constexpr int WF_L0 = 20 * BF_KB, WF_T = 36 * BF_KB, WF_S = 52 * BF_KB, WF_HD = 9 * BF_KB, WF_T5 = WF_T + WF_HD;
+constexpr int WF_TOTAL = WF_L0 + 3 * WF_T + WF_S + WF_T5;
+constexpr int WF_SLOT = WF_S;   // 3 x 52 KiB = 156 of the 160 KiB
 static_assert(WF_TOTAL == BFW_FWD_STREAM_KB * BF_KB, "SE3 forward stream length (nrf_internal.h)");
-constexpr int WB_GH = 8 * BF_KB, WB_L = 16 * BF_KB;
-constexpr int WB_TAN_TOTAL = WB_GH + 10 * WB_L, WB_TOTAL = WB_TAN_TOTAL + 2 * WB_L;
+// reverse stream: heads^T + layer 5 | layers 4..1 | the two code-gradient GEMMs (primal only)
+constexpr int WB_GH = 8 * BF_KB, WB_L = 32 * BF_KB, WB_G5 = WB_GH + WB_L;
+constexpr int WB_TAN_TOTAL = WB_G5 + 4 * WB_L, WB_TOTAL = WB_TAN_TOTAL + WB_L;
 static_assert(WB_TOTAL == BFW_BWD_STREAM_KB * BF_KB && WB_TAN_TOTAL == BFW_BWD_TAN_STREAM_KB * BF_KB, "SE3 reverse stream length");
 
 enum { EP_LIN = 0, EP_RELU = 1, EP_MASK = 2 };
@@ -57,22 +61,24 @@ __device__ __forceinline__ void wpanel_epi(int k, const f32x16 (&pend)[NP], unsi
   }
 }
 
-// One 128-wide layer = 2 panels.  in: packed input (its blocks 2, 3 arrive from acc1 = the previous layer's second panel during
-// chunk 0 when PEND); out: blocks 0, 1; blocks 2, 3 stay pending in acc1.  mbp1: the previous layer's bit word of its panel 1
-// (RELU: completed here; MASK: read), mbn0: this layer's word of panel 0.  b2_0 / b2_1: sizes of the chunks two ahead.
-template <int R, bool PEND, int PMODE, int MODE, bool STORE, class BSel>
+// One 128-wide layer = 2 panels in ONE chunk (fragments F0 .. F0 + 4R - 1 of a chunk of NFC; the skip layer of the forward pass
+// fills a 52 KiB slot, the heads / heads^T chunks share a slot with the neighbouring layer): one barrier per layer.  in: packed
+// input (its blocks 2, 3 arrive from acc1 = the previous layer's second panel during panel 0 when PEND); out: blocks 0, 1; blocks
+// 2, 3 stay pending in acc1.  mbp1: the previous layer's bit word of its panel 1 (RELU: completed here; MASK: read), mbn0: this
+// layer's word of panel 0.  b2: size of the chunk two ahead (used by the panel that holds the chunk's barrier).
+template <int R, bool PEND, int PMODE, int MODE, bool STORE, int F0, int NFC, int SLOT, int PRE = 0, class BSel>
 __device__ __forceinline__ void layer128(ChainCtx& c, f32x16 (&acc0)[2], f32x16 (&acc1)[2], unsigned (&in)[4][8], unsigned (&out)[4][8],
-                                         unsigned& mbp1, unsigned& mbn0, const uint32_t* st_prev, const uint32_t* st, int b2_0, int b2_1,
+                                         unsigned& mbp1, unsigned& mbn0, const uint32_t* st_prev, const uint32_t* st, int b2,
                                          int lane16, BSel bsel) {
   const __amdgpu_buffer_rsrc_t rp1 = panel_rsrc(st_prev, 1), rn0 = panel_rsrc(st, 0);
   constexpr int NF = 2 * R;
-  constexpr int SP0 = 6;   // chunk 0: the pending blocks 2, 3 are this chunk's k-steps 4..7 (slots >= 8, >= 10 with a bias row)
+  constexpr int SP0 = 6;   // panel 0: the pending blocks 2, 3 are its k-steps 4..7 (slots >= 8, >= 10 with a bias row)
   if constexpr (PEND)
-    bf_chunk<2, R, true, SP0, ep_ops(PMODE, STORE), STORE>(acc0, c.fr, c.rg, c.ll, c.wave, b2_0, bsel,
+    bf_panel<2, R, true, SP0, ep_ops(PMODE, STORE), STORE, F0, NFC, SLOT, PRE>(acc0, c.fr, c.rg, c.ll, c.wave, b2, bsel,
         [&](int k) __attribute__((always_inline)) { wpanel_epi<SP0, 2, PMODE, STORE>(k, acc1, in, mbp1, rp1, lane16); });
   else
-    bf_chunk<2, R, true, 0, 0, false>(acc0, c.fr, c.rg, c.ll, c.wave, b2_0, bsel, [&](int) __attribute__((always_inline)) {});
-  bf_chunk<2, R, true, NF - 1, ep_ops(MODE, STORE), STORE>(acc1, c.fr, c.rg, c.ll, c.wave, b2_1, bsel,
+    bf_panel<2, R, true, 0, 0, false, F0, NFC, SLOT, PRE>(acc0, c.fr, c.rg, c.ll, c.wave, b2, bsel, [&](int) __attribute__((always_inline)) {});
+  bf_panel<2, R, true, NF - 1, ep_ops(MODE, STORE), STORE, F0 + NF, NFC, SLOT, PRE + (PEND && STORE ? 4 : 0)>(acc1, c.fr, c.rg, c.ll, c.wave, b2, bsel,
       [&](int k) __attribute__((always_inline)) { wpanel_epi<NF - 1, 0, MODE, STORE>(k, acc0, out, mbn0, rn0, lane16); });
 }
 
@@ -107,7 +113,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 
   ChainCtx c;
-  chain_start(c, bf_lds, P.a[0].bwpk, WF_TOTAL, WF_L0, WF_L0, lane0, wave);
+  chain_start<WF_SLOT>(c, bf_lds, P.a[0].bwpk, WF_TOTAL, WF_L0, WF_T, lane0, wave);
 
 #pragma unroll 1
   for (int it = blockIdx.x; it < P.ntot; it += gridDim.x) {
@@ -201,24 +207,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     constexpr int MODE = TANGENT ? EP_MASK : EP_RELU;
     // ---- trunk: 6 x Dense(128) + ReLU, skip concat [h, inputs] at layer 4 (warping.py:264-269) ----
-    layer128<5, false, MODE, MODE, STASH>(c, acc0, acc1, ua, ua, mb[0][1], mb[0][0], hst(0), hst(0), WF_T, WF_T, lane16,
+    layer128<5, false, MODE, MODE, STASH, 0, 20, WF_SLOT>(c, acc0, acc1, ua, ua, mb[0][1], mb[0][0], hst(0), hst(0), WF_T, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(win, 1); });                              // L0: win -> ua
-    layer128<9, true, MODE, MODE, STASH>(c, acc0, acc1, ua, ub, mb[0][1], mb[1][0], hst(0), hst(1), WF_T, WF_T, lane16,
+    layer128<9, true, MODE, MODE, STASH, 0, 36, WF_SLOT>(c, acc0, acc1, ua, ub, mb[0][1], mb[1][0], hst(0), hst(1), WF_T, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
-    layer128<9, true, MODE, MODE, STASH>(c, acc0, acc1, ub, ua, mb[1][1], mb[2][0], hst(1), hst(2), WF_T, WF_T, lane16,
+    layer128<9, true, MODE, MODE, STASH, 0, 36, WF_SLOT>(c, acc0, acc1, ub, ua, mb[1][1], mb[2][0], hst(1), hst(2), WF_S, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); });
-    layer128<9, true, MODE, MODE, STASH>(c, acc0, acc1, ua, ub, mb[2][1], mb[3][0], hst(2), hst(3), WF_S, WF_S, lane16,
+    layer128<9, true, MODE, MODE, STASH, 0, 36, WF_SLOT>(c, acc0, acc1, ua, ub, mb[2][1], mb[3][0], hst(2), hst(3), WF_T5, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
-    layer128<13, true, MODE, MODE, STASH>(c, acc0, acc1, ub, ua, mb[3][1], mb[4][0], hst(3), hst(4), WF_T, WF_T, lane16,           // skip: [h, inputs]
+    layer128<13, true, MODE, MODE, STASH, 0, 52, WF_SLOT>(c, acc0, acc1, ub, ua, mb[3][1], mb[4][0], hst(3), hst(4), WF_L0, lane16,  // skip: [h, inputs]
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : r <= 8 ? BF_ROWS(ub, 1) : BF_ROWS(win, 9); });
-    layer128<9, true, MODE, MODE, STASH>(c, acc0, acc1, ua, ub, mb[4][1], mb[5][0], hst(4), hst(5), WF_HD, WF_L0, lane16,
+    layer128<9, true, MODE, MODE, STASH, 0, 45, WF_SLOT>(c, acc0, acc1, ua, ub, mb[4][1], mb[5][0], hst(4), hst(5), WF_T, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
     // ---- heads: w = Dense(128 -> 3)(h6), v = Dense(128 -> 3)(h6) (warping.py:271-288, 328-329): one block, features 0..2 = w,
-    //      3..5 = v; h6's blocks 2, 3 (pending) are this chunk's k-steps 4..7 ----
+    //      3..5 = v, the last 9 fragments of layer 5's chunk (the chunk's barrier falls here: the copy of layer 1 starts while the
+    //      next iteration's layer 0 is already resident); h6's blocks 2, 3 (pending) are this panel's k-steps 4..7 ----
     f32x16 hd[1];
     {
       const __amdgpu_buffer_rsrc_t r51 = panel_rsrc(hst(5), 1);
-      bf_chunk<1, 9, true, 4, ep_ops(MODE, STASH), STASH>(hd, c.fr, c.rg, c.ll, wave, WF_L0,
+      bf_panel<1, 9, true, 4, ep_ops(MODE, STASH), STASH, 36, 45, WF_SLOT, (STASH ? 8 : 0)>(hd, c.fr, c.rg, c.ll, wave, WF_T,
           [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); },
           [&](int k) __attribute__((always_inline)) { wpanel_epi<4, 2, MODE, STASH>(k, acc1, ub, mb[5][1], r51, lane16); });
     }
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 void launch_warp_fwd_bf16(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int max_grid, hipStream_t stream) {
-  const size_t lds = BF_LDS_BYTES;
+  const size_t lds = 3 * WF_SLOT;
   WarpBf16FwdArgs2 p;
   p.a[0] = a; p.a[1] = a1 ? *a1 : a;
   const bool tangent = a.bprim_bits != nullptr;
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 
   ChainCtx c;
-  chain_start(c, bf_lds, P.a[0].bwpk, TANGENT ? WB_TAN_TOTAL : WB_TOTAL, WB_GH, WB_L, lane0, wave);
+  chain_start(c, bf_lds, P.a[0].bwpk, TANGENT ? WB_TAN_TOTAL : WB_TOTAL, WB_G5, WB_L, lane0, wave);
 
 #pragma unroll 1
   for (int it = blockIdx.x; it < P.ntot; it += gridDim.x) {
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     { const u32x2v q = bits_of(5); mq0 = q.x; mq1 = q.y; }
     {
       f32x16 g4[4];
-      bf_chunk<4, 2, true, 0, 0, false>(g4, c.fr, c.rg, c.ll, wave, WB_L,
+      bf_panel<4, 2, true, 0, 0, false, 0, 40, BF_SLOT, 0>(g4, c.fr, c.rg, c.ll, wave, WB_L,     // the first 8 fragments of layer 5's chunk
           [&](int) __attribute__((always_inline)) { return as_bf16x8(dsm[0], dsm[1], dsm[2], dsm[3]); },
           [&](int) __attribute__((always_inline)) {});
       const __amdgpu_buffer_rsrc_t r0 = panel_rsrc(dyst(5), 0), r1 = panel_rsrc(dyst(5), 1);
@@ -352,25 +359,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- l = 5..1: d h_l = W_l[0:128] . dpre_l, mask of layer l-1 -> dpre_{l-1}; the arrays alternate.  dpre_4 is kept for
     //      the code gradient (the skip layer sees the input) ----
     unsigned d4[4][8];
-    constexpr int AFT_A = TANGENT ? WB_GH : WB_L, AFT_B = WB_L;   // behind L1: the code-gradient GEMMs, or the stream restarts
-#define WB_LAYER(L, PEND, IN, OUT, B20, B21)                                                                               \
+    // chunks two ahead: [heads^T + L5] L4 L3 L2 L1 [code GEMMs] (primal) -- behind L2 / L1 the stream wraps in the tangent pass
+#define WB_LAYER(L, PEND, IN, OUT, F0, NFC, PRE, B2)                                                                           \
     {                                                                                                                       \
       unsigned mp1 = mq1;                                                                                                   \
       { const u32x2v q = bits_of((L) - 1); mq0 = q.x; mq1 = q.y; }                                                          \
-      layer128<8, PEND, EP_MASK, EP_MASK, true>(c, acc0, acc1, IN, OUT, mp1, mq0, dyst(L), dyst((L) - 1), B20, B21, lane16,  \
+      layer128<8, PEND, EP_MASK, EP_MASK, true, F0, NFC, BF_SLOT, PRE>(c, acc0, acc1, IN, OUT, mp1, mq0, dyst(L), dyst((L) - 1), B2, lane16, \
           [&](int r) __attribute__((always_inline)) { return BF_ROWS(IN, 0); });                                           \
     }
-    WB_LAYER(5, false, ua, ub, WB_L, WB_L)     // -> dpre_4 = ub (blocks 2, 3 arrive during the next layer's first chunk)
-    WB_LAYER(4, true, ub, ua, WB_L, WB_L)      // -> dpre_3 = ua
+    WB_LAYER(5, false, ua, ub, 8, 40, 8, WB_L)    // -> dpre_4 = ub (blocks 2, 3 arrive during the next layer's first panel)
+    WB_LAYER(4, true, ub, ua, 0, 32, 0, WB_L)     // -> dpre_3 = ua
     if constexpr (!TANGENT) {
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int q = 0; q < 8; ++q) d4[b][q] = ub[b][q];
     }
-    WB_LAYER(3, true, ua, ub, WB_L, WB_L)      // -> dpre_2 = ub
-    WB_LAYER(2, true, ub, ua, WB_L, WB_L)      // -> dpre_1 = ua
-    WB_LAYER(1, true, ua, ub, AFT_A, AFT_B)    // -> dpre_0 = ub
+    WB_LAYER(3, true, ua, ub, 0, 32, 0, WB_L)                          // -> dpre_2 = ub
+    WB_LAYER(2, true, ub, ua, 0, 32, 0, TANGENT ? WB_G5 : WB_L)        // -> dpre_1 = ua
+    WB_LAYER(1, true, ua, ub, 0, 32, 0, TANGENT ? WB_L : WB_G5)        // -> dpre_0 = ub
 #undef WB_LAYER
     if constexpr (TANGENT) {
       const __amdgpu_buffer_rsrc_t rp1 = panel_rsrc(dyst(0), 1);
@@ -381,10 +388,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       //      code columns of it, summed over the rows that share a warp id, are added to the embedding-table gradient ----
       f32x16 ci[2];
       const __amdgpu_buffer_rsrc_t rp1 = panel_rsrc(dyst(0), 1);
-      bf_chunk<2, 8, true, 6, ep_ops(EP_MASK, true), true>(ci, c.fr, c.rg, c.ll, wave, WB_GH,
+      bf_panel<2, 8, true, 6, ep_ops(EP_MASK, true), true, 0, 32, BF_SLOT, 0>(ci, c.fr, c.rg, c.ll, wave, WB_L,
           [&](int r) __attribute__((always_inline)) { return BF_ROWS(ub, 0); },
           [&](int k) __attribute__((always_inline)) { wpanel_epi<6, 2, EP_MASK, true>(k, acc1, ub, mq1, rp1, lane16); });
-      bf_chunk<2, 8, false, 0, 0, false>(ci, c.fr, c.rg, c.ll, wave, WB_L,
+      bf_panel<2, 8, false, 0, 0, false, 16, 32, BF_SLOT, 4>(ci, c.fr, c.rg, c.ll, wave, WB_L,
           [&](int r) __attribute__((always_inline)) { return BF_ROWS(d4, 0); }, [&](int) __attribute__((always_inline)) {});
       int id = -1;
       if (row < A.rows) id = A.point_ids ? A.point_ids[row] : A.warp_ids ? A.warp_ids[row / A.S] : row / A.S;

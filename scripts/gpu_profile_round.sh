@@ -8,7 +8,7 @@
 # Passes are separate processes: bench line, rocprofv3 kernel trace, three PMC passes (SQ / FETCH_SIZE / WRITE_SIZE never
 # share a pass, never combined with a trace domain).
 TAG=${1:-r04}
-MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_warp eval_warp_bf16 train128 train128_graph"}
+MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_warp eval_warp_bf16 train128 train128_graph sustained sustained_bf16"}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -19,7 +19,7 @@ SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_W
 # LDS side of the bf16 chain kernels (its own pass): instructions, array-busy cycles, conflict cycles
 LDSC="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"
 for mode in $MODES; do
-  PMC=1; TRACE=1
+  PMC=1; TRACE=1; STEPS=50
   case $mode in
     train)          ARGS="";                                   SUF="" ;;
     train_bf16)     ARGS="--mode train_bf16";                  SUF="_train_bf16" ;;
@@ -33,11 +33,14 @@ for mode in $MODES; do
     eval_warp_bf16) ARGS="--mode eval --warp --frame --bf16";  SUF="_eval_warp_bf16"; PMC=0 ;;
     train128)       ARGS="--rays-per-gpu 128";                 SUF="_train128"; PMC=0; TRACE=0 ;;
     train128_graph) ARGS="--rays-per-gpu 128 --graph";         SUF="_train128_graph"; PMC=0; TRACE=0 ;;
+    # 20+ s timed windows: the default sub-second window is steady state (fp32), and where the board's power limit puts the bf16 step
+    sustained)      ARGS="";                                   SUF="_sustained"; PMC=0; TRACE=0; STEPS=3000 ;;
+    sustained_bf16) ARGS="--mode train_bf16";                  SUF="_sustained_bf16"; PMC=0; TRACE=0; STEPS=16000 ;;
   esac
   # LIGHT="mode ..." (environment): bench line only for those workloads (when the GPU budget does not cover every pass)
   case " $LIGHT " in *" $mode "*) PMC=0; TRACE=0 ;; esac
   NOCPU="--no-cpu-baseline"; [ "$mode" = train ] && NOCPU=""
-  python bench.py $ARGS --steps 50 --warmup 5 $NOCPU > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
+  python bench.py $ARGS --steps $STEPS --warmup 5 $NOCPU > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
   head -c 300 $O/${TAG}_bench${SUF}.json; echo
   [ $TRACE = 0 ] && continue
   rm -rf $O/prof_${TAG}${SUF} $O/pmc1_${TAG}${SUF} $O/pmc2_${TAG}${SUF} $O/pmc3_${TAG}${SUF}

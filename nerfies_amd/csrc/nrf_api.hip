@@ -265,8 +265,19 @@ void build_layout(nrf_handle h) {
                hid * XW);
       add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/bias", 1, W, &po.trunk_b[i], 1, XW);
     }
-    add_leaf(h, base + "/bottleneck/kernel", W, W, &po.bn_k, XW, XW);
-    add_leaf(h, base + "/bottleneck/bias", 1, W, &po.bn_b, 1, XW);
+    if (h->R == 0 && h->A == 0) {
+      // no condition at all (use_viewdirs = False, no camera / appearance code): NerfMLP has NO bottleneck layer and the rgb branch
+      // reads the trunk output (modules.py:149-164).  The kernels keep their layer list: the bottleneck becomes an internal-only
+      // IDENTITY (x . I + 0 is exact in float32, and exact on the bf16 chain, whose h8 is already bf16), its gradient is dropped
+      add_leaf(h, base + "/bottleneck/kernel", W, W, &po.bn_k, -1, -1, -1, nullptr, "");
+      add_leaf(h, base + "/bottleneck/bias", 1, W, &po.bn_b, -1, -1, -1, nullptr, "");
+      EmbedDesc e;
+      e.ext_off = -1; e.int_off = po.bn_k; e.rows = XW; e.ext_cols = 1; e.int_cols = W; e.split = XW; e.shift = 0; e.pad_ = 0;
+      h->emb.push_back(e);
+    } else {
+      add_leaf(h, base + "/bottleneck/kernel", W, W, &po.bn_k, XW, XW);
+      add_leaf(h, base + "/bottleneck/bias", 1, W, &po.bn_b, 1, XW);
+    }
     add_leaf(h, base + "/MLP_1/hidden_0/kernel", W + h->R, RW, &po.rgbh_k, XW + h->R, XRW, XW);
     add_leaf(h, base + "/MLP_1/hidden_0/bias", 1, RW, &po.rgbh_b, 1, XRW);
     add_leaf(h, base + "/MLP_1/logit/kernel", RW, 3, &po.logit_k, XRW, 3);
@@ -1750,7 +1761,6 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
     if (d.num_warp_features < 1 || d.num_warp_features > 8) return fail(NRF_E_SHAPE, "num_warp_features must be in [1,8]");
     if (d.num_warp_embeddings < 1 && d.warp_metadata_encoder_type != NRF_META_TIME) return fail(NRF_E_SHAPE, "num_warp_embeddings must be positive");
   }
-  if (!d.use_viewdirs && !d.use_camera_metadata) return fail(NRF_E_UNSUPPORTED, "rgb branch needs at least one condition");
   if (d.num_coarse_samples < 3 || d.num_coarse_samples > 256) return fail(NRF_E_SHAPE, "num_coarse_samples must be in [3,256]");
   if (d.num_fine_samples < 0 || d.num_coarse_samples + d.num_fine_samples > 512)
     return fail(NRF_E_SHAPE, "num_coarse_samples + num_fine_samples must be <= 512");

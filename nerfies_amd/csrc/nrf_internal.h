@@ -493,7 +493,8 @@ void launch_adam_dynamic(float* p, float* m, float* v, const float* g, int64_t n
 // Narrower models run on the 256-wide / 128-wide kernels by embedding: the caller's parameter leaves are copied into
 // a zero-filled internal image with the kernels' widths (zero weights and biases for the extra units: relu(0) = 0 and
 // zero outgoing weights make the padded network compute the same function), gradients are copied back out.
-// element (r, c) of the external leaf <-> (r < split ? r : r + shift, c) of the internal leaf.
+// element (r, c) of the external leaf <-> (r < split ? r : r + shift, c) of the internal leaf.  ext_off < 0: no external leaf --
+// the internal one is the rows x rows identity (written on the way in, nothing on the way out).
 struct EmbedDesc {
   long long ext_off, int_off;
   int rows, ext_cols, int_cols, split, shift, pad_;

@@ -773,6 +773,12 @@ namespace {
 __global__ __launch_bounds__(256) void embed_kernel(const EmbedDesc* __restrict__ descs, const float* __restrict__ src,
                                                     float* __restrict__ dst, int to_internal) {
   const EmbedDesc d = descs[blockIdx.y];
+  if (d.ext_off < 0) {   // internal-only identity layer (the bottleneck of a model without conditions): ones on the diagonal
+    if (to_internal)
+      for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < d.rows; i += (long)gridDim.x * blockDim.x)
+        dst[d.int_off + i * d.int_cols + i] = 1.f;
+    return;
+  }
   const long n = (long)d.rows * d.ext_cols;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
     const int r = (int)(i / d.ext_cols), c = (int)(i - (long)r * d.ext_cols);

@@ -233,9 +233,19 @@ class GraphedTrainStep:
     torch.cuda.current_stream().wait_stream(s)
     for t, k in zip((opt.target.flat, opt.m, opt.v), keep):
       t.copy_(k)
+    # RCCL's all-reduce is a stream operation and is captured with the rest.  gloo's is a host call (the CPU-side tests, two ranks
+    # sharing one GPU): the step is then TWO graphs -- loss + gradient | Adam -- with the collective between them
+    self.split = dist.is_available() and dist.is_initialized() and dist.get_backend() != 'nccl'
     self.graph = torch.cuda.CUDAGraph()
     with torch.cuda.graph(self.graph):
-      self._enqueue()
+      if self.split:
+        self._enqueue_grad()
+      else:
+        self._enqueue()
+    if self.split:
+      self.graph_adam = torch.cuda.CUDAGraph()
+      with torch.cuda.graph(self.graph_adam):
+        opt.apply_gradient_dynamic(self._grad, self.dyn)
 
   @staticmethod
   def _static_copy(batch, dev):
@@ -264,17 +274,21 @@ class GraphedTrainStep:
                    learning_rate=sp.learning_rate, adam_step=opt.step, beta1=opt.beta1, beta2=opt.beta2, grad_scale=1.0 / _world(),
                    rng_seed=models.rng_seed_of(coarse_key, fine_key), rng_offset=0)
 
-  def _enqueue(self):
+  def _enqueue_grad(self):
     opt, sp, f = self.state.optimizer, self.sp, self.flags
     dev = opt.target.flat.device
-    grad, stats = self.model.loss_and_grad(
+    self._grad, self._stats = self.model.loss_and_grad(
         opt.target, self.batch, warp_extra=self.state.warp_extra, rngs={'fine': 0, 'coarse': 0}, grad_out=opt.grad, stats_out=opt.stats,
         bf16=self.bf16, dynamic=self.dyn.dev,
         background=_background_of(self.model, self.batch, sp, dev) if f['use_background_loss'] else None,
         elastic=dict(self.el, weight=sp.elastic_loss_weight) if f['use_elastic_loss'] else None,
         warp_reg={'weight': sp.warp_reg_loss_weight, 'alpha': sp.warp_reg_loss_alpha, 'scale': sp.warp_reg_loss_scale}
         if f['use_warp_reg_loss'] else None)
-    grad, stats, _ = psum_gradients(grad, stats, fused=opt._gs)
+
+  def _enqueue(self):
+    opt = self.state.optimizer
+    self._enqueue_grad()
+    grad, stats, _ = psum_gradients(self._grad, self._stats, fused=opt._gs)
     opt.apply_gradient_dynamic(grad, self.dyn)
     self.stats_static = stats
 
@@ -291,6 +305,9 @@ class GraphedTrainStep:
       self.state.time_alpha = time_alpha
     self._write(rng_key, sp, self.state.warp_alpha, self.state.time_alpha)
     self.graph.replay()
+    if self.split:
+      _, self.stats_static, _ = psum_gradients(self._grad, self._stats, fused=self.state.optimizer._gs)
+      self.graph_adam.replay()
     self.state.optimizer.step += 1
     st = self.stats_static.clone()   # the static buffer is overwritten by the next replay
     return _stats_dict(st, sp, **self.flags)

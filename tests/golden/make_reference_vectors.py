@@ -438,6 +438,39 @@ def elastic_types_and_noise():
 # ---------------------------------------------------------------------------------------------
 # round 3: every branch of utils.general_loss_with_squared_residual (utils.py:304-329)
 # ---------------------------------------------------------------------------------------------
+# ---------------------------------------------------------------------------------------------
+# round 4: NerfMLP without ANY condition (use_viewdirs = False, no camera / appearance code): modules.py:149-164 then builds no
+# bottleneck layer and feeds the trunk output to the rgb and alpha branches directly
+# ---------------------------------------------------------------------------------------------
+NERF_CASES_R4 = {
+    'nocond': (dict(num_coarse_samples=9, num_fine_samples=7, num_nerf_point_freqs=5, use_stratified_sampling=True, use_viewdirs=False), 0.0),
+    'nocond_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_viewdirs=False,
+                         use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.75),
+}
+
+
+def nerf_model_r4():
+  for name, (kw, alpha) in NERF_CASES_R4.items():
+    spec = O.ModelSpec(**kw)
+    seed = sum(ord(c) for c in name)
+    params = O.init_params(spec, seed=seed, trained_like=True)
+    assert 'bottleneck' not in params['nerf_mlps_coarse']
+    batch = O.synthetic_batch(3, seed=seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    t_rand = rng.uniform(0, 1, (3, spec.num_coarse_samples)); u = rng.uniform(0, 1, (3, spec.num_fine_samples))
+    model = build_ref_model(spec)
+    rays = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(),
+            'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}}
+    ret = model.apply({'params': tree_np(params)}, rays, {'alpha': alpha, 'time_alpha': 0.0}, return_points=spec.use_warp,
+                      return_weights=True, return_warp_jacobian=spec.use_warp,
+                      rngs={'coarse': jrandom.Key(uniform=t_rand), 'fine': jrandom.Key(uniform=u)})
+    out = dict(t_rand=t_rand, u=u, alpha=alpha, seed=seed)
+    for lv, d in ret.items():
+      for k, v in d.items():
+        out[f'{lv}/{k}'] = v
+    save('nerf_' + name, **out)
+
+
 def general_loss_branches():
   sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
   out = dict(sq=sq)
@@ -468,3 +501,4 @@ if __name__ == '__main__':
   nerf_model_r2()
   train_step_stats()
   elastic_types_and_noise()
+  nerf_model_r4()

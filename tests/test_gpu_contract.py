@@ -344,3 +344,27 @@ def test_one_handle_alternating_batch_sizes_flags_and_streams():
     np.testing.assert_array_equal(_np(got8b), _np(want8b))
     np.testing.assert_allclose(_np(gots), _np(wants), rtol=1e-6, atol=1e-7)
     assert (gotg - wantg).abs().max().item() <= 1e-5 * wantg.abs().max().item()   # embedding / per-ray sums use atomics
+
+
+# ---------------------------------------------------------------------------------------------
+# NerfMLP without any condition (use_viewdirs = False, no camera / appearance code): no bottleneck layer, the rgb branch reads
+# the trunk output (modules.py:149-164); the library keeps its layer list and runs an internal identity in its place
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw,B,alpha', [
+    (dict(num_nerf_point_freqs=6, num_coarse_samples=16, num_fine_samples=16), 40, 0.0),
+    (dict(num_nerf_point_freqs=8, num_coarse_samples=32, num_fine_samples=32, use_warp=True, num_warp_freqs=4), 21, 3.0)])
+def test_model_without_any_condition_forward_and_gradients(kw, B, alpha):
+  spec = O.ModelSpec(use_stratified_sampling=True, use_viewdirs=False, **kw)
+  r = H.run_pinned(spec, B, alpha, seed=23)
+  H.assert_pinned(r, f'no condition B={B}')
+  H.assert_forward(r, spec)
+  names = [n for n, _, _ in r['model'].layout.entries]
+  assert not any('bottleneck' in n for n in names)                       # the caller's tree is the reference's: no such leaf
+  assert any(n.endswith('MLP_1/hidden_0/kernel') for n in names)
+  # the bf16 mode runs the same internal identity (exact on bf16 values): loss and gradient direction follow the float32 path
+  g32, s32 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'])
+  g32, s32 = g32.clone(), s32.clone()
+  g16, s16 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'], bf16='mlp')
+  assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
+  cos = torch.nn.functional.cosine_similarity(g16.double().flatten(), g32.double().flatten(), dim=0).item()
+  assert cos > 0.98, cos

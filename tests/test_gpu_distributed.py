@@ -114,3 +114,66 @@ def test_two_rank_train_step_equals_full_batch(tmp_path):
   # pmean of the statistics (training.py:267): the mean of the two shard MSEs is the full-batch MSE; the elastic loss
   # likewise (mean over rays)
   np.testing.assert_allclose(got['hist'], hist, rtol=2e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole step from hipGraphs on two ranks (training.GraphedTrainStep; train.py --graph)
+# ---------------------------------------------------------------------------------------------
+def _run_keys(rank, world, graphed):
+  """STEPS steps driven by integer rng keys (the library's Philox streams), eager or replayed from the captured step."""
+  import helpers as H
+  from nerfies_amd import training
+  spec, p, b, _ = _inputs()
+  per = B // world
+  sl = slice(rank * per, (rank + 1) * per)
+  model, fp = H.gpu_model(spec, p, per)
+  gb = H.gpu_batch(b)
+  gb = {k: (v[sl] if torch.is_tensor(v) else {kk: vv[sl] for kk, vv in v.items()}) for k, v in gb.items()}
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=4.0)
+  sp = training.ScalarParams(learning_rate=LR, elastic_loss_weight=0.01)
+  kw = dict(use_elastic_loss=True, elastic_reduce_method='weight')
+  gstep = training.GraphedTrainStep(model, state, gb, sp, **kw) if graphed else None
+  hist = []
+  for k in range(STEPS):
+    if graphed:
+      stats = gstep(100 + k)
+    else:
+      state, stats, _ = training.train_step(model, 100 + k, state, gb, sp, **kw)
+    hist.append([stats['coarse']['loss/rgb'].item(), stats['fine']['loss/rgb'].item(), stats['coarse']['loss/elastic'].item()])
+  torch.cuda.synchronize()
+  return fp.flat.cpu(), np.array(hist), (gstep.split if graphed else None)
+
+
+def _graph_worker(rank, port, tmp):
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+  eager, hist_e, _ = _run_keys(rank, WORLD, False)
+  flat, hist_g, split = _run_keys(rank, WORLD, True)
+  both = [torch.empty_like(flat) for _ in range(WORLD)]
+  dist.all_gather(both, flat)
+  assert torch.equal(both[0], both[1])   # replicas bit-identical after STEPS replays
+  if rank == 0:
+    torch.save({'flat': flat, 'eager': eager, 'hist_g': hist_g, 'hist_e': hist_e, 'split': split}, tmp)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_two_rank_graphed_step_keeps_replicas_identical_and_equals_eager(tmp_path):
+  """GraphedTrainStep with a process group: the gradient all-reduce and the 1/world factor inside the replayed step
+  (training.py:264-269).  gloo's collective is a host call, so the step is two graphs around it (RCCL's is captured with the
+  rest: tests/test_gpu_rccl.py); the replicas must stay bit-identical and follow the eager two-rank run."""
+  import helpers as H
+  tmp = str(tmp_path / 'graph.pt')
+  mp.spawn(_graph_worker, args=(_free_port(), tmp), nprocs=WORLD, join=True)
+  got = torch.load(tmp, weights_only=False)
+  assert got['split'] is True
+  spec, p, _, _ = _inputs()
+  _, fp0 = H.gpu_model(spec, p, B)
+  travel = (got['eager'] - fp0.flat.cpu()).norm().item()
+  diff = (got['flat'] - got['eager']).norm().item()
+  print(f'[2 ranks, graph vs eager] |dp| {diff:.3e} over a travel of {travel:.3e}')
+  assert travel > 0.1 * LR * STEPS * np.sqrt(got['flat'].numel())
+  assert diff < 3e-2 * travel                       # float32 atomics order only (same bound as the one-rank comparison above)
+  np.testing.assert_allclose(got['hist_g'], got['hist_e'], rtol=2e-4, atol=1e-7)

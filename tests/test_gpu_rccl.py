@@ -56,6 +56,15 @@ out = {'params_sum': float(fp.flat.double().sum()), 'params_abs': float(fp.flat.
        'rgb_bits': int(img['rgb'].contiguous().view(torch.int32).to(torch.int64).sum().item()), 'rgb_shape': list(img['rgb'].shape),
        'rccl': None}
 out['grad_abs'] = grad_abs0
+# the whole step from ONE hipGraph: with the process group its all-reduce (RCCL, a stream operation) is captured with the rest
+gstep = training.GraphedTrainStep(model, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
+glosses = []
+for k in (21, 22, 23):
+  st = gstep(k)
+  glosses.append([float(st['coarse']['loss/total']), float(st['fine']['loss/total']), float(st['background_loss'])])
+out['graph_losses'] = glosses
+out['graph_split'] = bool(gstep.split)
+out['graph_params_abs'] = float(fp.flat.double().abs().sum())
 if use_dist:
   fused = state.optimizer._gs.clone()
   before = fused.clone()
@@ -92,6 +101,11 @@ def test_train_step_and_render_through_a_one_rank_rccl_communicator():
     assert abs(a - b) <= 1e-6 + 5e-3 * abs(a), (plain['losses'], rccl['losses'])
   assert abs(plain['grad_abs'] - rccl['grad_abs']) <= 1e-4 * plain['grad_abs']     # at the initial parameters
   assert abs(plain['params_abs'] - rccl['params_abs']) <= 1e-5 * plain['params_abs']
+  # three more steps replayed from the captured step: ONE graph in both runs (the RCCL all-reduce is inside it), same trajectory
+  assert plain['graph_split'] is False and rccl['graph_split'] is False
+  for a, b in zip(sum(plain['graph_losses'], []), sum(rccl['graph_losses'], [])):
+    assert abs(a - b) <= 1e-6 + 5e-3 * abs(a), (plain['graph_losses'], rccl['graph_losses'])
+  assert abs(plain['graph_params_abs'] - rccl['graph_params_abs']) <= 1e-5 * plain['graph_params_abs']
 
 
 def test_bench_line_through_rccl(tmp_path):

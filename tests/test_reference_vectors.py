@@ -137,6 +137,32 @@ def test_nerf_model_apply_end_to_end(name):
     close(el, r['coarse/elastic_loss'], 2e-6); close(res, r['coarse/elastic_residual'], 2e-6)
 
 
+NERF_CASES_R4 = {   # tests/golden/make_reference_vectors.py::nerf_model_r4 -- no condition at all: no bottleneck layer (modules.py:149-164)
+    'nocond': (dict(num_coarse_samples=9, num_fine_samples=7, num_nerf_point_freqs=5, use_stratified_sampling=True, use_viewdirs=False), 0.0),
+    'nocond_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_viewdirs=False,
+                         use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.75),
+}
+
+
+@pytest.mark.parametrize('name', sorted(NERF_CASES_R4))
+def test_nerf_model_without_any_condition(name):
+  kw, alpha = NERF_CASES_R4[name]
+  r = ref('nerf_' + name)
+  spec = O.ModelSpec(**kw)
+  seed = int(r['seed'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  assert 'bottleneck' not in params['nerf_mlps_coarse']
+  batch = O.synthetic_batch(3, seed=seed + 1)
+  ret = O.nerf_model_apply(params, spec, batch, alpha, return_points=spec.use_warp, return_warp_jacobian=spec.use_warp,
+                           t_rand=T(r['t_rand']), u=T(r['u']))
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights'):
+      close(ret[lv][k], r[f'{lv}/{k}'], 1e-8, msg=f'{name} {lv}/{k}')
+    if spec.use_warp:
+      close(ret[lv]['warped_points'], r[f'{lv}/warped_points'], 1e-9)
+      close(ret[lv]['warp_jacobian'], r[f'{lv}/warp_jacobian'], 2e-6)
+
+
 def test_losses_psnr_elastic():
   r = ref('losses_schedules')
   sq = T(r['sq'])

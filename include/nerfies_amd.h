@@ -65,11 +65,11 @@ typedef struct nrf_model_desc {
   int32_t use_viewdirs;            /* models.py:77  */
   float near_plane;                /* models.py:78  */
   float far_plane;                 /* models.py:79  */
-  int32_t nerf_trunk_depth;        /* 8   */
+  int32_t nerf_trunk_depth;        /* 1..8; the kernels run 8 layers, a shallower trunk gets internal identity layers behind it */
   int32_t nerf_trunk_width;        /* <= 256; the kernels are 256 wide, narrower trunks run zero-padded (test_vrig.gin: 128) */
   int32_t nerf_rgb_branch_depth;   /* 1   */
   int32_t nerf_rgb_branch_width;   /* <= 128 (same) */
-  int32_t nerf_skip_layer;         /* nerf_skips = (4,)  -> 4; -1 = none */
+  int32_t nerf_skip_layer;         /* nerf_skips = (4,)  -> 4; -1 = none (or any index >= nerf_trunk_depth: never reached) */
   int32_t use_stratified_sampling; /* models.py:88; eval.py:239 forces 0 */
   int32_t num_nerf_point_freqs;    /* models.py:89  */
   int32_t num_nerf_viewdir_freqs;  /* models.py:90  */

@@ -202,6 +202,7 @@ struct nrf_handle_s {
   WsPlan plan;
   // identity of the tables last uploaded to a workspace, and of the last stashed forward
   void* uploaded_ws = nullptr;
+  int xdepth = TRUNK_DEPTH, xskip = SKIP_LAYER;   // the caller's trunk (<= 8 layers; skip 4 or none): nrf_create
   int uploaded_B = -1;
   uint32_t uploaded_flags = 0;
   int uploaded_bgN = 0;
@@ -258,12 +259,22 @@ void build_layout(nrf_handle h) {
   for (int lv = 0; lv < h->nlevels; ++lv) {
     const std::string base = lv == 0 ? "nerf_mlps_coarse" : "nerf_mlps_fine";
     MlpParamOffsets& po = h->po[lv];
-    for (int i = 0; i < d.nerf_trunk_depth; ++i) {
+    for (int i = 0; i < TRUNK_DEPTH; ++i) {
       const int hid = i == 0 ? 0 : 1;                 // rows of the running activation, then (layer 0 / skip) the posenc rows
-      const int pe = (i == 0 || i == d.nerf_skip_layer) ? h->P : 0;
-      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/kernel", hid * W + pe, W, &po.trunk_k[i], hid * XW + pe, XW,
-               hid * XW);
-      add_leaf(h, base + "/MLP_0/hidden_" + std::to_string(i) + "/bias", 1, W, &po.trunk_b[i], 1, XW);
+      const int pe = (i == 0 || i == SKIP_LAYER) ? h->P : 0;
+      const int xpe = (i == 0 || i == h->xskip) ? h->P : 0;   // a skip the caller's trunk never reaches: zero posenc rows inside
+      const std::string kn = base + "/MLP_0/hidden_" + std::to_string(i) + "/kernel", bn = base + "/MLP_0/hidden_" + std::to_string(i) + "/bias";
+      if (i < h->xdepth) {
+        add_leaf(h, kn, hid * W + pe, W, &po.trunk_k[i], hid * XW + xpe, XW, hid * XW);
+        add_leaf(h, bn, 1, W, &po.trunk_b[i], 1, XW);
+      } else {   // behind the caller's last layer: internal-only identity (its gradient is dropped)
+        add_leaf(h, kn, hid * W + pe, W, &po.trunk_k[i], -1, -1, -1, nullptr, "");
+        add_leaf(h, bn, 1, W, &po.trunk_b[i], -1, -1, -1, nullptr, "");
+        EmbedDesc e;
+        e.ext_off = -1; e.int_off = po.trunk_k[i]; e.rows = XW; e.ext_cols = 1; e.int_cols = W; e.split = XW; e.shift = 0; e.pad_ = 0;
+        h->emb.push_back(e);
+      }
+      if (xpe != pe) h->embed = true;
     }
     if (h->R == 0 && h->A == 0) {
       // no condition at all (use_viewdirs = False, no camera / appearance code): NerfMLP has NO bottleneck layer and the rgb branch
@@ -1740,8 +1751,12 @@ const char* nrf_last_error(void) { return g_err; }
 int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   if (!desc || !out) return fail(NRF_E_NULL, "desc / out is null");
   const nrf_model_desc& d = *desc;
-  if (d.nerf_trunk_depth != TRUNK_DEPTH || d.nerf_skip_layer != SKIP_LAYER)
-    return fail(NRF_E_UNSUPPORTED, "MFMA chain is built for a depth-8 trunk with the skip at layer 4");
+  // the chains are built for 8 trunk layers with the skip at layer 4.  A SHALLOWER trunk runs on them with internal identity layers
+  // behind its last one (relu(h . I) = h for h >= 0: exact), a trunk whose skip is never reached (nerf_skips = () or skip >= depth)
+  // with zero posenc rows in layer 4 -- modules.MLP (modules.py:41-62) concatenates the inputs in front of layer i for i in skips
+  const bool skip_reached = d.nerf_skip_layer >= 0 && d.nerf_skip_layer < d.nerf_trunk_depth;
+  if (d.nerf_trunk_depth < 1 || d.nerf_trunk_depth > TRUNK_DEPTH || (skip_reached && d.nerf_skip_layer != SKIP_LAYER))
+    return fail(NRF_E_UNSUPPORTED, "MFMA chain is built for a trunk of at most 8 layers with the skip at layer 4 (or none)");
   if (d.nerf_trunk_width < 1 || d.nerf_trunk_width > TRUNK_W)   // narrower trunks run zero-padded (test_vrig.gin: 128)
     return fail(NRF_E_UNSUPPORTED, "nerf_trunk_width must be in [1,256]");
   if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width < 1 || d.nerf_rgb_branch_width > RGB_W)
@@ -1769,6 +1784,8 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   if (d.sigma_activation != NRF_ACT_RELU && d.sigma_activation != NRF_ACT_SOFTPLUS) return fail(NRF_E_UNSUPPORTED, "sigma_activation");
   nrf_handle h = new nrf_handle_s();
   h->d = d;
+  h->xdepth = d.nerf_trunk_depth; h->xskip = skip_reached ? SKIP_LAYER : -1;   // what the caller's tree holds
+  h->d.nerf_trunk_depth = TRUNK_DEPTH; h->d.nerf_skip_layer = SKIP_LAYER;        // what the kernels run
   h->nlevels = d.num_fine_samples > 0 ? 2 : 1;
   h->P = 3 + 6 * d.num_nerf_point_freqs;
   h->PK = (h->P + 15) / 16 * 16;                  // K of the posenc GEMMs: whole 16-k quads of the MFMA loop

@@ -156,8 +156,8 @@ NERF_CASES = {
 def build_ref_model(spec, **extra):
   return ref_models.NerfModel(
       num_coarse_samples=spec.num_coarse_samples, num_fine_samples=spec.num_fine_samples, use_viewdirs=spec.use_viewdirs,
-      near=spec.near, far=spec.far, noise_std=spec.noise_std, nerf_trunk_depth=8, nerf_trunk_width=256, nerf_rgb_branch_depth=1,
-      nerf_rgb_branch_width=128, nerf_skips=(4,), alpha_channels=1, rgb_channels=3,
+      near=spec.near, far=spec.far, noise_std=spec.noise_std, nerf_trunk_depth=spec.nerf_trunk_depth, nerf_trunk_width=256,
+      nerf_rgb_branch_depth=1, nerf_rgb_branch_width=128, nerf_skips=tuple(spec.nerf_skips), alpha_channels=1, rgb_channels=3,
       use_stratified_sampling=spec.use_stratified_sampling, num_nerf_point_freqs=spec.num_nerf_point_freqs,
       num_nerf_viewdir_freqs=spec.num_nerf_viewdir_freqs, appearance_ids=tuple(range(spec.num_appearance_embeddings)),
       camera_ids=tuple(range(spec.num_camera_embeddings)), warp_ids=tuple(range(spec.num_warp_embeddings)),
@@ -446,6 +446,10 @@ NERF_CASES_R4 = {
     'nocond': (dict(num_coarse_samples=9, num_fine_samples=7, num_nerf_point_freqs=5, use_stratified_sampling=True, use_viewdirs=False), 0.0),
     'nocond_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_viewdirs=False,
                          use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.75),
+    # trunks shallower than the kernels' 8 layers (modules.MLP, modules.py:41-62): skip at layer 4 still inside / never reached
+    'depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=6,
+                    use_camera_metadata=True), 0.0),
+    'depth3': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=3), 0.0),
 }
 
 
@@ -454,7 +458,8 @@ def nerf_model_r4():
     spec = O.ModelSpec(**kw)
     seed = sum(ord(c) for c in name)
     params = O.init_params(spec, seed=seed, trained_like=True)
-    assert 'bottleneck' not in params['nerf_mlps_coarse']
+    assert ('bottleneck' in params['nerf_mlps_coarse']) == (not name.startswith('nocond'))
+    assert len(params['nerf_mlps_coarse']['MLP_0']) == spec.nerf_trunk_depth
     batch = O.synthetic_batch(3, seed=seed + 1)
     rng = np.random.default_rng(seed + 2)
     t_rand = rng.uniform(0, 1, (3, spec.num_coarse_samples)); u = rng.uniform(0, 1, (3, spec.num_fine_samples))

@@ -368,3 +368,26 @@ def test_model_without_any_condition_forward_and_gradients(kw, B, alpha):
   assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
   cos = torch.nn.functional.cosine_similarity(g16.double().flatten(), g32.double().flatten(), dim=0).item()
   assert cos > 0.98, cos
+
+
+# ---------------------------------------------------------------------------------------------
+# trunks shallower than the kernels' 8 layers (ModelConfig.nerf_trunk_depth; modules.MLP, modules.py:41-62): internal identity layers
+# behind the caller's last one (relu(h . I) = h), zero posenc rows in layer 4 when the caller's trunk never reaches its skip
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw,B,alpha', [
+    (dict(nerf_trunk_depth=6, num_nerf_point_freqs=6, num_coarse_samples=16, num_fine_samples=16, use_camera_metadata=True), 40, 0.0),
+    (dict(nerf_trunk_depth=4, nerf_skips=(), num_nerf_point_freqs=8, num_coarse_samples=32, num_fine_samples=32, use_warp=True, num_warp_freqs=4), 21, 3.0),
+    (dict(nerf_trunk_depth=2, num_nerf_point_freqs=4, num_coarse_samples=16, num_fine_samples=8, use_viewdirs=False), 17, 0.0)])
+def test_shallow_trunk_forward_and_gradients(kw, B, alpha):
+  spec = O.ModelSpec(use_stratified_sampling=True, **kw)
+  r = H.run_pinned(spec, B, alpha, seed=29)
+  H.assert_pinned(r, f'trunk depth {spec.nerf_trunk_depth} B={B}')
+  H.assert_forward(r, spec)
+  names = [n for n, _, _ in r['model'].layout.entries]
+  assert sum('nerf_mlps_coarse/MLP_0/' in n and n.endswith('kernel') for n in names) == spec.nerf_trunk_depth
+  g32, s32 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'])
+  g32, s32 = g32.clone(), s32.clone()
+  g16, s16 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'], bf16='mlp')
+  assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
+  cos = torch.nn.functional.cosine_similarity(g16.double().flatten(), g32.double().flatten(), dim=0).item()
+  assert cos > 0.98, cos

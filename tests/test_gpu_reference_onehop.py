@@ -8,6 +8,7 @@ generator, never as the expected value):
 
   ref_nerf_nowarp / ref_nerf_camera / ref_nerf_warp   NerfModel.apply end to end            models.py:289-375
   ref_nerf_nocond / ref_nerf_nocond_warp              ... without any condition (no bottleneck) modules.py:149-164
+  ref_nerf_depth6 / ref_nerf_depth3                   ... with a 6- / 3-layer trunk                 modules.py:41-62
   ref_se3_field / ref_translation_field               SE3Field / TranslationField.warp      warping.py:62-199, 322-389
   ref_background_loss                                 training.compute_background_loss      training.py:117-135
   ref_train_step_stats                                training.train_step's forward half    training.py:168-262 (6 elastic types)
@@ -54,6 +55,10 @@ CASES = {
     'nocond': (dict(num_coarse_samples=9, num_fine_samples=7, num_nerf_point_freqs=5, use_stratified_sampling=True, use_viewdirs=False), 0.0),
     'nocond_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False,
                          use_viewdirs=False, use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.75),
+    # trunks shallower than the kernels' 8 layers (modules.py:41-62): internal identity layers behind the caller's last one
+    'depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=6,
+                    use_camera_metadata=True), 0.0),
+    'depth3': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=3), 0.0),
 }
 
 

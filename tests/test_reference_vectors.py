@@ -141,17 +141,22 @@ NERF_CASES_R4 = {   # tests/golden/make_reference_vectors.py::nerf_model_r4 -- n
     'nocond': (dict(num_coarse_samples=9, num_fine_samples=7, num_nerf_point_freqs=5, use_stratified_sampling=True, use_viewdirs=False), 0.0),
     'nocond_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_viewdirs=False,
                          use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.75),
+    # trunks shallower than 8 layers (modules.MLP, modules.py:41-62): the skip at layer 4 still inside / never reached
+    'depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=6,
+                    use_camera_metadata=True), 0.0),
+    'depth3': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=3), 0.0),
 }
 
 
 @pytest.mark.parametrize('name', sorted(NERF_CASES_R4))
-def test_nerf_model_without_any_condition(name):
+def test_nerf_model_without_any_condition_and_shallow_trunks(name):
   kw, alpha = NERF_CASES_R4[name]
   r = ref('nerf_' + name)
   spec = O.ModelSpec(**kw)
   seed = int(r['seed'])
   params = O.init_params(spec, seed=seed, trained_like=True)
-  assert 'bottleneck' not in params['nerf_mlps_coarse']
+  assert ('bottleneck' in params['nerf_mlps_coarse']) == (not name.startswith('nocond'))
+  assert len(params['nerf_mlps_coarse']['MLP_0']) == spec.nerf_trunk_depth
   batch = O.synthetic_batch(3, seed=seed + 1)
   ret = O.nerf_model_apply(params, spec, batch, alpha, return_points=spec.use_warp, return_warp_jacobian=spec.use_warp,
                            t_rand=T(r['t_rand']), u=T(r['u']))

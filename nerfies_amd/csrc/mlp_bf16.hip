@@ -97,7 +97,7 @@ __device__ __forceinline__ float bf_sigma(float x, int kind) {
 }  // namespace
 
 // One workgroup (8 waves) per CU, 256 samples per workgroup iteration, one 32-sample group per wave.
-template <bool STASH>
+template <bool STASH, bool ABN>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void nerf_mlp_fwd_bf16_kernel(const ChainFwdArgs A) {
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   const int lane0 = threadIdx.x & 63;
@@ -213,15 +213,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bf_chunk<2, 17, true, NF - 1, 1, STASH>(acc1, c.fr, c.rg, c.ll, wave, FW_RG, bs,
           [&](int k) __attribute__((always_inline)) { panel_epi<NF - 1, 4, false, STASH>(k, acc0, ua, mdummy, rb2, lane16); });
     }
-    // ---- alpha head: one block on h8 (row 0 = its bias; feature 0 = the raw density) ----
+    // ---- alpha head: one block on h8 (row 0 = its bias; feature 0 = the raw density).  use_alpha_condition (modules.py:152-157):
+    //      on the BOTTLENECK instead (+ the per-ray appearance-code term, float32); its blocks 6, 7 are still pending, their 16
+    //      units ride in slots 1..12 and k-steps 13..16 read them.  ABN is a template parameter: the default kernels are at 256 VGPRs with
+    //      nothing to spare (a run-time choice here cost them 1-6 spilled registers) ----
     float alpha_raw;
     {
       f32x16 aa[1];
       const __amdgpu_buffer_rsrc_t rb3 = panel_rsrc(bnb, 3);
-      bf_chunk<1, 17, true, 16, 1, STASH>(aa, c.fr, c.rg, c.ll, wave, FW_RG,
-          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); },
-          [&](int k) __attribute__((always_inline)) { panel_epi<16, 6, false, STASH>(k, acc1, ua, mdummy, rb3, lane16); });
+      constexpr int ASP = ABN ? 12 : 16;
+      bf_chunk<1, 17, true, ASP, 1, STASH>(aa, c.fr, c.rg, c.ll, wave, FW_RG,
+          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : ABN ? BF_ROWS(ua, 1) : BF_ROWS(ub, 1); },
+          [&](int k) __attribute__((always_inline)) { panel_epi<ASP, 6, false, STASH>(k, acc1, ua, mdummy, rb3, lane16); });
       alpha_raw = aa[0][0];
+      if constexpr (ABN) alpha_raw += A.alpha_ct[min(rc / A.S, A.B - 1)];
     }
     // ---- rgb branch: hidden 256 -> 128 (+ the fp32 per-ray condition term incl. bias), ReLU ----
     unsigned rh[4][8];
@@ -279,11 +284,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 namespace {
 // dgrad weight stream, chunks in execution order (panel = 2 output blocks unless noted):
 //   G1  logit^T   K = 3 of one k-step (+ a zero k-step), all 4 blocks of the rgb hidden layer in one panel      8 KiB
-//   G2  rgbh^T    K = 128 (8 k-steps) -> 256                                                                     4 x 16
-//   G3  bn^T      K = 256 -> 256, row 0 = the alpha row (B = d sigma)                                             4 x 34
+//   G2  rgbh^T    K = 128 (8 k-steps) -> 256, row 0 = the alpha row under use_alpha_condition (else zeros)       4 x 18
+//   G3  bn^T      K = 256 -> 256, row 0 = the alpha row (B = d sigma; zeros under use_alpha_condition)            4 x 34
 //   L7..L1        K = 256 -> 256                                                                                  7 x 4 x 32
 //   warp on:  P0  W0^T  256 -> 64 (d posenc through layer 0),  P4  W4[256:]^T  256 -> 64 (skip rows, accumulates)  2 x 32
-constexpr int DG1 = 8 * BF_KB, DG2 = 16 * BF_KB, DG3 = 34 * BF_KB, DGL = 32 * BF_KB, DGP = 32 * BF_KB;
+constexpr int DG1 = 8 * BF_KB, DG2 = 18 * BF_KB, DG3 = 34 * BF_KB, DGL = 32 * BF_KB, DGP = 32 * BF_KB;
 constexpr int BW_TOTAL = DG1 + 4 * DG2 + 4 * DG3 + 28 * DGL;
 static_assert(BW_TOTAL == BF_BWD_STREAM_KB * BF_KB && BW_TOTAL + 2 * DGP == BF_BWD_STREAM_DPTS_KB * BF_KB, "dgrad stream length (nrf_internal.h)");
 
@@ -392,18 +397,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int k = 1; k <= 16; ++k) panel_epi_bwd<16, 2, true, 2>(k, g1, drg, mq8.y, r1, lane16);
     }
-    // ---- G2: d bottleneck = W_rgbh[0:256] . d rgb hidden (linear): -> ub blocks 0..5, blocks 6, 7 pending ----
+    // ---- G2: d bottleneck = W_rgbh[0:256] . d rgb hidden (+ w_alpha d sigma, row 0, when the alpha head reads the bottleneck):
+    //      linear -> ub blocks 0..5, blocks 6, 7 pending ----
     const uint32_t* dbn = S.dbn + gidx * 8 * BF_BLOCK_DW;
     {
       const __amdgpu_buffer_rsrc_t rn0 = panel_rsrc(dbn, 0), rn1 = panel_rsrc(dbn, 1), rn2 = panel_rsrc(dbn, 2);
-      auto bs = [&](int r) __attribute__((always_inline)) { return BF_ROWS(drg, 0); };
-      bf_chunk<2, 8, true, 0, 0, false>(acc0, c.fr, c.rg, c.ll, wave, DG2, bs, [&](int) __attribute__((always_inline)) {});
-      bf_chunk<2, 8, true, 15, BW_OPS_LIN, true>(acc1, c.fr, c.rg, c.ll, wave, DG2, bs,
-          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<15, 0, false>(k, acc0, ub, 0u, rn0, lane16); });
-      bf_chunk<2, 8, true, 15, BW_OPS_LIN, true>(acc0, c.fr, c.rg, c.ll, wave, DG3, bs,
-          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<15, 2, false>(k, acc1, ub, 0u, rn1, lane16); });
-      bf_chunk<2, 8, true, 15, BW_OPS_LIN, true>(acc1, c.fr, c.rg, c.ll, wave, DG3, bs,
-          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<15, 4, false>(k, acc0, ub, 0u, rn2, lane16); });
+      auto bs = [&](int r) __attribute__((always_inline)) { return r == 0 ? as_bf16x8(dsig2, 0u, 0u, 0u) : BF_ROWS(drg, 1); };
+      bf_chunk<2, 9, true, 0, 0, false>(acc0, c.fr, c.rg, c.ll, wave, DG2, bs, [&](int) __attribute__((always_inline)) {});
+      bf_chunk<2, 9, true, 17, BW_OPS_LIN, true>(acc1, c.fr, c.rg, c.ll, wave, DG2, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<17, 0, false>(k, acc0, ub, 0u, rn0, lane16); });
+      bf_chunk<2, 9, true, 17, BW_OPS_LIN, true>(acc0, c.fr, c.rg, c.ll, wave, DG3, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<17, 2, false>(k, acc1, ub, 0u, rn1, lane16); });
+      bf_chunk<2, 9, true, 17, BW_OPS_LIN, true>(acc1, c.fr, c.rg, c.ll, wave, DG3, bs,
+          [&](int k) __attribute__((always_inline)) { panel_epi_bwd<17, 4, false>(k, acc0, ub, 0u, rn2, lane16); });
     }
     // ---- G3: d h8 = W_bn . d bottleneck + w_alpha d sigma (row 0), mask of layer 7 -> dpre_7: ub -> ua ----
     u32x4v mq = bits_of(7);
@@ -573,7 +579,8 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
     const long long leaf = col2 ? d.src_off2 : d.src_off;
     const int lcol = col2 ? col - d.split : col;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (d.kind == 1) {
+    if (d.kind == 2) {   // a zero row
+    } else if (d.kind == 1) {
       if (h == 0 && col < d.ncols) {
         const float bias = params[leaf + lcol];
         const float hi = __uint_as_float(pack_bf16(bias, 0.f) << 16);
@@ -604,15 +611,19 @@ void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, f
   if (ndesc > 0) bf16_pack_kernel<<<dim3(8, ndesc), 256, 0, stream>>>(descs, params, ws);
 }
 
+namespace {
+template <bool STASH, bool ABN>
+void launch_fwd_variant(const ChainFwdArgs& a, int grid, hipStream_t stream) {
+  (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<STASH, ABN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
+  hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<STASH, ABN>), dim3(grid), dim3(512), BF_LDS_BYTES, stream, a);
+}
+}  // namespace
+
 void launch_chain_fwd_bf16(const ChainFwdArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = BF_LDS_BYTES;
-  if (a.bst.h) {   // training: stash every layer's packed output + sign bits
-    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<true>), dim3(grid), dim3(512), lds, stream, a);
-  } else {
-    (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<false>), dim3(grid), dim3(512), lds, stream, a);
-  }
+  const bool stash = a.bst.h != nullptr;      // training: stash every layer's packed output + sign bits
+  const bool abn = a.alpha_ct != nullptr;     // use_alpha_condition: the alpha head reads the bottleneck
+  if (stash) { if (abn) launch_fwd_variant<true, true>(a, grid, stream); else launch_fwd_variant<true, false>(a, grid, stream); }
+  else { if (abn) launch_fwd_variant<false, true>(a, grid, stream); else launch_fwd_variant<false, false>(a, grid, stream); }
 }
 
 }  // namespace nrf

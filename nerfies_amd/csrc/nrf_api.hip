@@ -500,7 +500,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       bpush(&L.b_bn, 0, 8, &L.b_drgbh, 0, 4, po.rgbh_k, 128, 256, 128, 0, po.rgbh_b, 128);
       // narrow heads against the "small" dY block: columns 0..2 = d rgb logits (X = rgb hidden), column 3 = d raw sigma (X = h8)
       bpush(&L.b_rgbh, 0, 4, &L.b_dsmall, 0, 2, po.logit_k, 3, 128, 3, 0, po.logit_b, 3, po.alpha_b, 3);
-      bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);
+      if (h->A > 0) bpush(&L.b_bn, 0, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);   // use_alpha_condition: X = the bottleneck
+      else bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);
     }
   }
   // bf16 SE3 trunk: every pass through the field (coarse / fine samples, background points, the 3 tangents per coarse sample)
@@ -701,6 +702,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
             row += nrows;
           };
           if (bias >= 0) emit(1, bias, 0, 0, 0, 1);
+          else if (bias == -2) emit(2, 0, 0, 0, 0, 1);   // a zero row where the kernel runs a bias-style k-step this model does not use
           for (const Part& q : parts) emit(0, q.leaf, q.ld, q.row0, q.krows, 2 * q.nin);
           at += (size_t)row * pb * 256;
         }
@@ -721,8 +723,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         p.L[lv].bf_wpkT = take((size_t)(h->warp ? BF_BWD_STREAM_DPTS_KB : BF_BWD_STREAM_KB) * 256);
         base = p.L[lv].bf_wpkT; at = 0; tr = 1;
         gemm(4, 4, RGB_W, -1, {{po.logit_k, 3, 0, 3, 1}});                       // G1: one k-step (3 valid) + a zero one, 4 blocks
-        gemm(2, 8, TRUNK_W, -1, {{po.rgbh_k, RGB_W, 0, RGB_W, 4}});              // G2: rows 0..255 of [256+R, 128]
-        gemm(2, 8, TRUNK_W, po.alpha_k, {{po.bn_k, TRUNK_W, 0, TRUNK_W, 8}});    // G3: row 0 = the alpha row (w_alpha as the "bias")
+        // the alpha head's transpose is ONE bias-style row (w_alpha[0:256], B = d sigma) in the GEMM that produces the gradient of
+        // its input: the trunk output (G3), or -- use_alpha_condition, modules.py:152-157 -- the bottleneck (G2); zeros in the other
+        const int64_t arow = po.alpha_k;
+        gemm(2, 8, TRUNK_W, h->A > 0 ? arow : -2, {{po.rgbh_k, RGB_W, 0, RGB_W, 4}});             // G2: rows 0..255 of [256+R, 128]
+        gemm(2, 8, TRUNK_W, h->A > 0 ? -2 : arow, {{po.bn_k, TRUNK_W, 0, TRUNK_W, 8}});           // G3
         for (int l = TRUNK_DEPTH - 1; l >= 1; --l) gemm(2, 8, TRUNK_W, -1, {{po.trunk_k[l], TRUNK_W, 0, TRUNK_W, 8}});
         if (h->warp) {   // d posenc: W0 and the skip layer's posenc rows as A [m = posenc feature (P valid)][k = output feature]
           gemm(2, 2, h->P, -1, {{po.trunk_k[0], TRUNK_W, 0, TRUNK_W, 8}});
@@ -1295,7 +1300,6 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   const bool warp_on = h->warp && !(flags & NRF_FLAG_NO_WARP);   // models.py:296 use_warp argument
   if (warp_on && !scalars) return fail(NRF_E_NULL, "nrf_step_scalars (warp_alpha) required with the warp field");
   if (h->warp && !warp_on && train) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
-  if ((flags & NRF_FLAG_BF16) && h->A > 0) return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16 is not built for use_alpha_condition");
   if (d.use_stratified_sampling && !rnd) return fail(NRF_E_NULL, "nrf_rand required with stratified sampling");
   const bool encoded = rays->warp_codes || rays->appearance_codes || rays->camera_codes;
   if (encoded && train) return fail(NRF_E_UNSUPPORTED, "pre-encoded metadata (metadata_encoded) is an inference input: no gradient flows to the codes");

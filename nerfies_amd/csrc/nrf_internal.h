@@ -97,7 +97,7 @@ void launch_time_encoder_wgrad(const TimeEncArgs& a, float* grad, hipStream_t st
 // bf16 chains (mlp_bf16.hip): one descriptor fills rows of a weight stream
 // stream lengths in KiB (mlp_bf16.hip: chunk tables FW_* / DG*; nrf_api.hip build_plan emits the chunks)
 constexpr int BF_FWD_STREAM_KB = 4 * 10 + 28 * 34 + 4 * 42 + 17 + 2 * 32 + 9;
-constexpr int BF_BWD_STREAM_KB = 8 + 4 * 16 + 4 * 34 + 28 * 32;
+constexpr int BF_BWD_STREAM_KB = 8 + 4 * 18 + 4 * 34 + 28 * 32;
 constexpr int BF_BWD_STREAM_DPTS_KB = BF_BWD_STREAM_KB + 2 * 32;
 struct RcPackDesc {
   long long src_off, dst_off;   // params leaf / first row written, in floats from the workspace base

@@ -49,6 +49,27 @@ def test_alpha_condition_forward_and_gradients(kw, B):
   from nerfies_amd import params as P
   tree = P.tree_from_flat(r['fp'].flat.cpu(), r['model'].layout)
   assert tuple(tree['nerf_mlps_fine']['MLP_2']['logit']['kernel'].shape) == (spec.nerf_trunk_width + spec.num_appearance_features, 1)
+  # the bf16 mode with the alpha head on the bottleneck (round 4: the head's transposed row enters the dgrad chain at the
+  # bottleneck GEMM, its weight gradient pairs with the bottleneck stash): every leaf keeps the float32 path's direction
+  extra = dict(warp_extra={'alpha': 4.0}, rngs=r['rngs'])
+  g32, s32 = r['model'].loss_and_grad(r['fp'], r['gb'], **extra)
+  g32, s32 = g32.clone(), s32.clone()
+  g16, s16 = r['model'].loss_and_grad(r['fp'], r['gb'], bf16='mlp', **extra)
+  assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
+  t32, t16 = P.tree_from_flat(g32.cpu(), r['model'].layout), P.tree_from_flat(g16.cpu(), r['model'].layout)
+  worst = ('', 1.0)
+  for path, a in O.tree_leaves_with_path(t32):
+    if path.startswith('warp_field') or a.abs().max().item() < 1e-7:
+      continue   # (the warp field sees the NeRF MLPs' rounding through the 2^(F_p - 1) posenc: tests/test_gpu_bf16_warp.py)
+    c = torch.nn.functional.cosine_similarity(a.flatten().double(), H.leaf(t16, path).flatten().double(), dim=0).item()
+    if c < worst[1]:
+      worst = (path, c)
+  print(f'[alpha condition {kw}, bf16 vs f32] loss {s16[4].item():.6f} / {s32[4].item():.6f}; worst leaf cosine {worst[1]:.4f} ({worst[0]})')
+  assert worst[1] > 0.97, worst
+  o16 = r['model'].apply({'params': r['fp']}, r['gb'], {'alpha': 4.0}, rngs=r['rngs'], bf16='mlp')
+  o32 = r['model'].apply({'params': r['fp']}, r['gb'], {'alpha': 4.0}, rngs=r['rngs'])
+  for lv in o32:
+    assert (o16[lv]['rgb'] - o32[lv]['rgb']).abs().max().item() < 2e-2 and (o16[lv]['acc'] - o32[lv]['acc']).abs().max().item() < 2e-2
 
 
 def test_alpha_condition_matches_the_reference_run():

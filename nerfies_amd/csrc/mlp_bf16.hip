@@ -175,6 +175,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // ---- trunk: the packed activations alternate between ua and ub ----
     layer256<5, false, true, true, STASH>(c, acc0, acc1, ua, ua, m1, m0, hst(0), hst(0), FW_L0, FW_T, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(pe, 1); });                           // L0: pe -> ua
+    // Layers 1..3 and 5..7 are the same code (ua -> ub -> ua -> ub) on other stash slots.  TRAINING: one copy, run twice, the skip
+    // layer between the two rounds.  The unrolled kernel is ~100 KiB of instructions and a training launch runs 1-6 iterations
+    // per workgroup: every launch streams its code through a cold instruction cache (SQC_ICACHE_MISSES_DUPLICATE = 12 % of the
+    // fetches, profiles/r04_train_bf16_pmc_icache.md; the 1-iteration coarse launch takes 80-120 us against 53 us per iteration in
+    // steady state).  A third less code: coarse forward -13 %, dgrad -3 %.  INFERENCE (16+ iterations per workgroup, 0.9 % duplicate
+    // misses) keeps the unrolled form: rolled, hipcc spills 46 VGPRs there and the forward is 8 % slower (scripts/r4/gpu_l.sh).
+    if constexpr (STASH) {
+#pragma unroll 1
+    for (int t = 0; t < 2; ++t) {
+      const int l0 = 4 * t;
+      layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(l0), hst(l0 + 1), FW_T, FW_T, lane16,
+          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
+      store_bits(l0, m0);
+      layer256<17, true, true, true, STASH>(c, acc0, acc1, ub, ua, m1, m0, hst(l0 + 1), hst(l0 + 2), FW_T, FW_T, lane16,
+          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ub, 1); });
+      store_bits(l0 + 1, m1);
+      layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(l0 + 2), hst(l0 + 3), FW_T, t == 0 ? FW_S : FW_T, lane16,
+          [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
+      store_bits(l0 + 2, m0);
+      if (t == 0) {
+        layer256<21, true, true, true, STASH>(c, acc0, acc1, ub, ua, m1, m0, hst(3), hst(4), FW_S, FW_T, lane16,                    // skip: [h, posenc]
+            [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : r <= 16 ? BF_ROWS(ub, 1) : BF_ROWS(pe, 17); });
+        store_bits(3, m1);
+      }
+    }
+    } else {
     layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(0), hst(1), FW_T, FW_T, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
     store_bits(0, m0);
@@ -196,6 +222,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     layer256<17, true, true, true, STASH>(c, acc0, acc1, ua, ub, m0, m1, hst(6), hst(7), FW_T, FW_T, lane16,
         [&](int r) __attribute__((always_inline)) { return r == 0 ? bias_op : BF_ROWS(ua, 1); });
     store_bits(6, m0);
+    }
     // ---- bottleneck (linear): h8 = ub -> ua; its chunks 2, 3 prefetch the alpha chunk and the rgb branch ----
     const uint32_t* bnb = A.bst.bn + gidx * 8 * BF_BLOCK_DW;
     unsigned mdummy = 0u;
@@ -438,12 +465,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       layer256_bwd<16, true>(c, acc0, acc1, IN, OUT, mbp3, mq, dyst(L), dyst((L) - 1), DGL, B2, B3, lane16,                  \
           [&](int r) __attribute__((always_inline)) { return BF_ROWS(IN, 0); });                                            \
     }
-    BW_LAYER(7, ua, ub, DGL, DGL)
-    BW_LAYER(6, ub, ua, DGL, DGL)
-    BW_LAYER(5, ua, ub, DGL, DGL)
-    BW_LAYER(4, ub, ua, DGL, DGL)
-    BW_LAYER(3, ua, ub, DGL, DGL)
-    BW_LAYER(2, ub, ua, DGL, DGL)
+#pragma unroll 1
+    for (int t = 0; t < 3; ++t) {   // (7, 6), (5, 4), (3, 2): ONE copy of the layer pair (code size: see the forward kernel)
+      BW_LAYER(7 - 2 * t, ua, ub, DGL, DGL)
+      BW_LAYER(6 - 2 * t, ub, ua, DGL, DGL)
+    }
     BW_LAYER(1, ua, ub, AFTER_A, AFTER_B)
 #undef BW_LAYER
     // dpre_0 = ub: blocks 0..5 stored, blocks 6, 7 pending in acc1 (mask word mq.w, stash dyst(0) panel 3)

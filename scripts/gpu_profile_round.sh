@@ -18,6 +18,7 @@ clean() { rm -rf "$@"; }
 SQ="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"
 # LDS side of the bf16 chain kernels (its own pass): instructions, array-busy cycles, conflict cycles
 LDSC="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_MFMA"
+ICC="SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_IFETCH_LEVEL SQ_BUSY_CYCLES SQ_WAVE_CYCLES"
 for mode in $MODES; do
   PMC=1; TRACE=1; STEPS=50
   case $mode in
@@ -48,6 +49,10 @@ for mode in $MODES; do
   summ $O/prof_${TAG}${SUF} $O/${TAG}${SUF}_kernel_stats.md
   rocprofv3 --pmc $SQ -d $O/pmc1_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc1_${TAG}${SUF}.log 2>&1
   summ $O/pmc1_${TAG}${SUF} $O/${TAG}${SUF}_pmc_sq.md
+  case $mode in train|train_bf16|eval_bf16)   # instruction fetch: the unrolled bf16 chains are ~100 KiB of code (cold start of every launch)
+    rocprofv3 --pmc $ICC -d $O/pmc5_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc5_${TAG}${SUF}.log 2>&1
+    summ $O/pmc5_${TAG}${SUF} $O/${TAG}${SUF}_pmc_icache.md; clean $O/pmc5_${TAG}${SUF} ;;
+  esac
   case $mode in *bf16*)
     rocprofv3 --pmc $LDSC -d $O/pmc4_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc4_${TAG}${SUF}.log 2>&1
     summ $O/pmc4_${TAG}${SUF} $O/${TAG}${SUF}_pmc_lds.md; clean $O/pmc4_${TAG}${SUF} ;;

@@ -136,8 +136,20 @@ def test_create_validates_and_reports(lib):
   d = _desc(nerf_trunk_width=320)
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
   assert b'256' in lib.nrf_last_error()
-  d = _desc(nerf_trunk_depth=6)
+  d = _desc(nerf_trunk_depth=9)                     # deeper than the kernels' 8 layers (shallower trunks run on identity layers)
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
+  d = _desc(nerf_trunk_depth=8, nerf_skip_layer=3)  # a skip the kernels do not have
+  assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
+  d = _desc(nerf_trunk_depth=6)                     # 6 layers, skip at 4: the caller's tree has six trunk leaves per MLP
+  h6 = C.c_void_p()
+  assert lib.nrf_create(C.byref(d), C.byref(h6)) == 0
+  n = C.c_int32(0)
+  assert lib.nrf_param_layout(h6, None, C.byref(n)) == 0
+  infos = (L.TensorInfo * n.value)()
+  assert lib.nrf_param_layout(h6, infos, C.byref(n)) == 0
+  names = [t.name.decode() for t in infos]
+  assert sum(nm.startswith('nerf_mlps_coarse/MLP_0/') and nm.endswith('kernel') for nm in names) == 6
+  lib.nrf_destroy(h6)
   d = _desc(num_coarse_samples=2)
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -2
   with pytest.raises(L.NrfError):

@@ -111,36 +111,6 @@ def test_graph_replay_follows_the_schedules():
     gstep(1, scalar_params=training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, background_loss_weight=2.0))
 
 
-@pytest.mark.parametrize('bf16', [True, 'mlp'])
-def test_graph_replay_in_the_bf16_mode(bf16):
-  """The bf16 mode (NeRF MLPs + SE3 trunk, or the MLPs alone) through the captured step: warp + elastic + background, the dynamic
-  scalars honoured by the bf16 kernels as well (warp_alpha sets the band windows of the bf16 trunk's prologue).  The bf16 path is
-  as deterministic as the float32 one (same roundings in both runs; float atomics in the per-ray sums)."""
-  from nerfies_amd import training
-
-  class Cfg:
-    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 32, 32, 6
-    sigma_activation, use_stratified_sampling, use_viewdirs = 'softplus', True, True
-    use_warp, warp_field_type, num_warp_freqs, num_warp_features, use_camera_metadata = True, 'se3', 4, 8, True
-  B, NBG = 96, 256
-  (me, se), (mg, sg) = _pair(Cfg, B)
-  batch = _batch(B, 61, with_meta=True, nbg=NBG)
-  kw = dict(use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
-  sp0 = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, background_loss_weight=1.0)
-  gstep = training.GraphedTrainStep(mg, sg, batch, sp0, bf16=bf16, **kw)
-  for k, (alpha, el_w, lr, key) in enumerate([(0.5, 0.01, 1e-3, 5), (3.25, 0.002, 3e-4, 77)]):
-    sp = training.ScalarParams(learning_rate=lr, elastic_loss_weight=el_w, background_loss_weight=1.0)
-    se = se.replace(warp_alpha=alpha)
-    se, st_e, _ = training.train_step(me, key, se, batch, sp, bf16=bf16, **kw)
-    st_g = gstep(key, scalar_params=sp, warp_alpha=alpha)
-    for a, b in ((st_e['coarse']['loss/total'], st_g['coarse']['loss/total']), (st_e['coarse']['loss/elastic'], st_g['coarse']['loss/elastic']),
-                 (st_e['background_loss'], st_g['background_loss']), (st_e['fine']['loss/rgb'], st_g['fine']['loss/rgb'])):
-      assert abs(a.item() - b.item()) <= 1e-6 + 1e-5 * abs(a.item()), (k, a.item(), b.item())
-    _close(sg.optimizer.grad.cpu(), se.optimizer.grad.cpu(), mg.layout, 1e-4, f'bf16 {bf16}: gradient of step {k}')
-    for dst, src in ((sg.optimizer.target.flat, se.optimizer.target.flat), (sg.optimizer.m, se.optimizer.m), (sg.optimizer.v, se.optimizer.v)):
-      dst.copy_(src)
-
-
 def test_library_background_draw_matches_the_reference_distribution():
   """training.py:121-126 on the device: ids uniform over model.warp_ids, noise ~ N(0, noise_std^2) per coordinate, a different
   draw for every key, the same draw for the same key."""

@@ -41,25 +41,26 @@ for mode in $MODES; do
   # LIGHT="mode ..." (environment): bench line only for those workloads (when the GPU budget does not cover every pass)
   case " $LIGHT " in *" $mode "*) PMC=0; TRACE=0 ;; esac
   NOCPU="--no-cpu-baseline"; [ "$mode" = train ] && NOCPU=""
-  python bench.py $ARGS --steps $STEPS --warmup 5 $NOCPU > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
+  timeout 900 python bench.py $ARGS --steps $STEPS --warmup 5 $NOCPU > $O/${TAG}_bench${SUF}.json 2> $O/${TAG}_bench${SUF}.err
   head -c 300 $O/${TAG}_bench${SUF}.json; echo
   [ $TRACE = 0 ] && continue
   rm -rf $O/prof_${TAG}${SUF} $O/pmc1_${TAG}${SUF} $O/pmc2_${TAG}${SUF} $O/pmc3_${TAG}${SUF}
-  rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}${SUF} -o kt -- python bench.py $ARGS --steps 10 --warmup 2 --burn-in-s 0 --no-cpu-baseline > $O/prof_${TAG}${SUF}.log 2>&1
+  PARGS=${ARGS/ --frame/}   # the trace / counter passes time chunks only: a whole frame under PMC serialisation took > 30 min once (round 4)
+  timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}${SUF} -o kt -- python bench.py $PARGS --steps 10 --warmup 2 --burn-in-s 0 --no-cpu-baseline > $O/prof_${TAG}${SUF}.log 2>&1
   summ $O/prof_${TAG}${SUF} $O/${TAG}${SUF}_kernel_stats.md
-  rocprofv3 --pmc $SQ -d $O/pmc1_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc1_${TAG}${SUF}.log 2>&1
+  timeout 300 rocprofv3 --pmc $SQ -d $O/pmc1_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc1_${TAG}${SUF}.log 2>&1
   summ $O/pmc1_${TAG}${SUF} $O/${TAG}${SUF}_pmc_sq.md
   case $mode in train|train_bf16|eval_bf16)   # instruction fetch: the unrolled bf16 chains are ~100 KiB of code (cold start of every launch)
-    rocprofv3 --pmc $ICC -d $O/pmc5_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc5_${TAG}${SUF}.log 2>&1
+    timeout 300 rocprofv3 --pmc $ICC -d $O/pmc5_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc5_${TAG}${SUF}.log 2>&1
     summ $O/pmc5_${TAG}${SUF} $O/${TAG}${SUF}_pmc_icache.md; clean $O/pmc5_${TAG}${SUF} ;;
   esac
   case $mode in *bf16*)
-    rocprofv3 --pmc $LDSC -d $O/pmc4_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc4_${TAG}${SUF}.log 2>&1
+    timeout 300 rocprofv3 --pmc $LDSC -d $O/pmc4_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc4_${TAG}${SUF}.log 2>&1
     summ $O/pmc4_${TAG}${SUF} $O/${TAG}${SUF}_pmc_lds.md; clean $O/pmc4_${TAG}${SUF} ;;
   esac
   if [ $PMC = 1 ]; then
-    rocprofv3 --pmc FETCH_SIZE -d $O/pmc2_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc2_${TAG}${SUF}.log 2>&1
-    rocprofv3 --pmc WRITE_SIZE -d $O/pmc3_${TAG}${SUF} -o pmc -- python bench.py $ARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc3_${TAG}${SUF}.log 2>&1
+    timeout 300 rocprofv3 --pmc FETCH_SIZE -d $O/pmc2_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc2_${TAG}${SUF}.log 2>&1
+    timeout 300 rocprofv3 --pmc WRITE_SIZE -d $O/pmc3_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc3_${TAG}${SUF}.log 2>&1
     summ $O/pmc2_${TAG}${SUF} $O/${TAG}${SUF}_pmc_fetch.md
     summ $O/pmc3_${TAG}${SUF} $O/${TAG}${SUF}_pmc_write.md
     fdb=$(find $O/pmc2_${TAG}${SUF} -name '*.db' | head -1); wdb=$(find $O/pmc3_${TAG}${SUF} -name '*.db' | head -1)

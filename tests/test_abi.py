@@ -156,6 +156,27 @@ def test_create_validates_and_reports(lib):
     L.check(-2, lib)
 
 
+def test_layout_of_a_model_without_any_condition_has_no_bottleneck(lib):
+  """use_viewdirs = 0 and no camera / appearance code: the reference's NerfMLP builds no bottleneck layer (modules.py:149-164), so
+  the caller's tree has none; the rgb branch's first layer then takes the 256 trunk features alone."""
+  from nerfies_amd import lib as L
+  h = C.c_void_p()
+  d = _desc(use_viewdirs=0)
+  assert lib.nrf_create(C.byref(d), C.byref(h)) == 0, lib.nrf_last_error()
+  n = C.c_int32(0)
+  assert lib.nrf_param_layout(h, None, C.byref(n)) == 0
+  infos = (L.TensorInfo * n.value)()
+  assert lib.nrf_param_layout(h, infos, C.byref(n)) == 0
+  names = {t.name.decode(): (t.rows, t.cols) for t in infos}
+  assert not any('bottleneck' in k for k in names)
+  assert names['nerf_mlps_coarse/MLP_1/hidden_0/kernel'] == (256, 128)
+  assert names['nerf_mlps_fine/MLP_2/logit/kernel'] == (256, 1)
+  cnt = C.c_int64(0)
+  assert lib.nrf_param_count(h, C.byref(cnt)) == 0
+  assert cnt.value >= sum(r * c for r, c in names.values())   # leaves are padded to 16 bytes
+  lib.nrf_destroy(h)
+
+
 def test_param_layout_uses_flax_paths(lib):
   from nerfies_amd import lib as L
   h = C.c_void_p()

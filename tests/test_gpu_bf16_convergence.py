@@ -119,9 +119,10 @@ def test_bf16_convergence_at_the_config_a_shape():
   # two training runs that differ only in rounding or sampling keys diverge chaotically.  Four seeds per precision on one box
   # (profiles/r04_bf16_seed_spread.json): fp32 38.39 +- 0.19 dB (38.17 .. 38.67), bf16 38.26 +- 0.13 (round-3 bf16 kernels on the
   # same seeds: 38.33 +- 0.16) -- the precisions' means differ by less than one standard deviation of either.  Two fp32 runs
-  # cannot estimate that spread, so the gate uses the measured one: the bf16 run within 2.5 sigma of the fp32 pair's mean, where
+  # cannot estimate that spread, so the gate uses the measured one: the bf16 run within 3 sigma of the fp32 pair's mean (a 2.5 sigma
+  # gate would trip about once in a hundred runs of a suite that the driver runs with -x), where
   # sigma = 0.19 * sqrt(1 + 1/2) is the spread of (one run - mean of two runs)
   sigma = 0.19 * np.sqrt(1.5)
   assert abs(pa - pb) <= 4 * 0.19 * np.sqrt(2.0), (pa, pb)           # the fp32 pair itself is inside the measured spread
-  assert abs(p16 - 0.5 * (pa + pb)) <= 2.5 * sigma, (pa, pb, p16)
+  assert abs(p16 - 0.5 * (pa + pb)) <= 3.0 * sigma, (pa, pb, p16)
   assert gap16 <= 2.0 * gap32 + 0.05

@@ -8,8 +8,15 @@ gradient all-reduce over RCCL (N>1) + fused Adam -- i.e. everything training.tra
 Inputs (rays, target colours, parameters) are resident in HBM before the timed region.
 
   python bench.py --gpus N --steps K --warmup W
-N>1 is launched by torch.distributed.run, one rank per GPU (weak scaling: 1024 rays per GPU).
-Rank 0 prints ONE JSON line.
+N>1: one rank per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) the process is a rank; WITHOUT it
+`python bench.py --gpus N` re-launches itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+--master-addr 127.0.0.1` (train.py:254-262: jax.pmap over the local devices).  The top-level line is weak scaling (1024 rays
+per GPU); with N>1 it also carries a nested `strong_scaling` record -- the north star's 1024-ray GLOBAL batch, 1024/N rays
+per GPU, eager and replayed from one hipGraph -- so ONE run yields both curves.  The line checks itself: `rccl_ranks == N`,
+`replica_param_checksums_agree`, `grad_allreduce_us` and the exposed (non-overlapped) share of the collective.
+A box with fewer devices than ranks (the one-GPU lease the tests run on) still runs the N-rank code path: ranks share
+devices and the transport is gloo (RCCL refuses two ranks on one device); the line then says `oversubscribed` and its value is
+NOT a scaling measurement.  Rank 0 prints ONE JSON line.
 
 Secondary lines (never the default): --mode train_bf16 | vrig | fullhd | eval, --bf16 (or BENCH_BF16=1) for the bfloat16
 NeRF-MLP mode of vrig / fullhd / eval, --rays-per-gpu N (e.g. 128 = one GPU's share of the north star's 1024-ray global batch
@@ -414,72 +421,46 @@ def eval_mode(args, world, rank, dev, bf16):
         'csrc_sha16': kernel_source_sha()}))
 
 
-def main():
-  ap = argparse.ArgumentParser()
-  ap.add_argument('--gpus', type=int, default=1)
-  ap.add_argument('--steps', type=int, default=30)
-  ap.add_argument('--warmup', type=int, default=5)
-  ap.add_argument('--no-cpu-baseline', action='store_true')
-  ap.add_argument('--burn-in-s', type=float, default=3.0,
-                  help='seconds of untimed steps of the same workload before the warm-up + timed steps (steady-state clocks)')
-  ap.add_argument('--mode', default='train', choices=['train', 'train_bf16', 'eval', 'vrig', 'fullhd'],
-                  help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
-                       '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
-                       'SE3 warp F_w=6 + camera code + elastic + background regularisers); fullhd: configs[3] shape (512 rays/GPU x '
-                       '(256+256), F_p=10, SE3 warp F_w=8, appearance ids, elastic + background; --bf16 = the precision BASELINE '
-                       'names for it); train_bf16: the headline workload with bfloat16 MLP operands and stash (opt-in mode, '
-                       'never the default line)')
-  ap.add_argument('--bf16', action='store_true', help='vrig / fullhd / eval: NeRF MLPs in the bf16 mode (same as BENCH_BF16=1)')
-  ap.add_argument('--rays-per-gpu', type=int, default=0,
-                  help='rays per GPU of the training modes (default: the mode\'s own, 1024 for the headline); 128 = one GPU\'s share '
-                       'of a 1024-ray global batch on 8 GPUs (the north star\'s strong-scaling point)')
-  ap.add_argument('--graph', action='store_true', help='replay the whole train step (loss+grad, all-reduce, Adam) from one hipGraph')
-  ap.add_argument('--warp', action='store_true', help='eval mode: render with the SE3 warp field (the path eval.py takes)')
-  ap.add_argument('--warp-f32', action='store_true', help='bf16 modes: keep the SE3 trunk in float32 (NRF_FLAG_WARP_F32; the round-3 behaviour)')
-  ap.add_argument('--frame', action='store_true', help='eval mode: also time evaluation.render_image on a whole 960x540 frame')
-  args = ap.parse_args()
+def free_port():
+  import socket
+  with socket.socket() as s:
+    s.bind(('127.0.0.1', 0))
+    return s.getsockname()[1]
 
-  world = int(os.environ.get('WORLD_SIZE', '1'))
-  rank = int(os.environ.get('RANK', '0'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-  # Debug hooks for exercising the N>1 code path on a ONE-GPU box (never set by the driver): BENCH_DIST_BACKEND=gloo
-  # swaps RCCL for gloo, BENCH_SAME_DEVICE=1 puts every rank on cuda:0 (RCCL refuses two ranks on one device),
-  # BENCH_FORCE_DIST=1 creates the RCCL communicator even with ONE rank, so that the step's fused [grad | stats] all-reduce
-  # really goes through librccl on the one GPU a box has.
-  backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
-  force_dist = bool(os.environ.get('BENCH_FORCE_DIST')) and world == 1
-  if os.environ.get('BENCH_SAME_DEVICE'):
-    local_rank = 0
-  if world > 1 or force_dist:
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29531')
-    torch.cuda.set_device(local_rank)
-    kw = {'rank': rank, 'world_size': world} if force_dist else {}
-    if backend == 'nccl':
-      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), **kw)
-    else:
-      dist.init_process_group(backend, **kw)
-  elif args.gpus > 1:
-    raise SystemExit('launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...')
-  dev = torch.device('cuda', local_rank if world > 1 else 0)
-  torch.cuda.set_device(dev)
-  dist_on = world > 1 or force_dist
 
-  bf16 = args.bf16 or bool(os.environ.get('BENCH_BF16'))
-  if bf16 and args.warp_f32:
-    bf16 = 'mlp'
-  if args.mode == 'eval':
-    eval_mode(args, world, rank, dev, bf16)
-    if dist_on:
-      dist.destroy_process_group()
-    return
+def launch_plan(n, argv, ndev, environ=None):
+  """(command, environment) that runs THIS script as N ranks on one node: what `python bench.py --gpus N` execs when it was not
+  started by torch.distributed.run itself (the reference's jax.pmap over local devices, train.py:254-262, needs no launcher;
+  one process per GPU does).  With fewer visible devices than ranks the ranks share devices and the collective transport is
+  gloo (RCCL refuses two ranks on one device): the N-rank code path of a one-GPU box, flagged in the line as `oversubscribed`."""
+  env = dict(os.environ if environ is None else environ)
+  env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')   # dmabuf IPC: RCCL's P2P setup fails without it on this driver
+  env.setdefault('OMP_NUM_THREADS', '4')
+  if ndev < n:
+    env['BENCH_SAME_DEVICE'] = '1'
+    env.setdefault('BENCH_DIST_BACKEND', 'gloo')
+    env['BENCH_OVERSUBSCRIBED'] = f'{n} ranks on {ndev} visible device(s)'
+  cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+         '--master-port', str(free_port()), os.path.abspath(__file__)] + list(argv)
+  return cmd, env
 
+
+def self_launch(args, argv):
+  import subprocess
+  ndev = torch.cuda.device_count()
+  if ndev == 0:
+    raise SystemExit('bench.py needs a GPU (torch.cuda.device_count() == 0)')
+  cmd, env = launch_plan(args.gpus, argv, ndev)
+  print('bench.py: not under torch.distributed.run -> ' + ' '.join(cmd[1:8]) + ' ...', file=sys.stderr, flush=True)
+  return subprocess.run(cmd, env=env).returncode
+
+
+def train_workload(args, M, cfg, rays_per_gpu, bf16, graph, ctx, profile=True):
+  """One training workload measured as the contract says: burn-in, W warm-up steps, K timed steps between barrier +
+  synchronize, MAX over ranks; then the self-checks (replica checksums, the collective on its own, the step without the
+  collective) and the per-kernel HIP-event profile.  Returns a dict of measurements (every rank; rank 0 prints)."""
   from nerfies_amd import models, training
-  M = TRAIN_MODES[args.mode]
-  bf16 = bf16 or bool(M.get('force_bf16'))
-  BF16_NOTE = BF16_NOTE_MLP if bf16 == 'mlp' else BF16_NOTE_ALL
-  cfg = M['cfg']
-  rays_per_gpu = args.rays_per_gpu or M['rays']
+  world, rank, dev, dist_on = ctx['world'], ctx['rank'], ctx['dev'], ctx['dist_on']
   # metadata ids as a capture has them: one warp / appearance id per FRAME (a vrig capture has a few hundred frames and a batch
   # draws rays uniformly over all of them), two camera ids (left / right rig camera).  Rounds 1-2 drew the ids from 4 frames,
   # which turns the embedding-table gradient into ~800 same-address atomics per table row and step -- an artefact of the
@@ -511,7 +492,7 @@ def main():
     torch.cuda.synchronize()
 
   box = {'state': state, 'key': key, 'stats': None}
-  if args.graph:
+  if graph:
     gstep = training.GraphedTrainStep(model, state, batch, sp, bf16=bf16, **kw)
 
     def step():
@@ -521,24 +502,29 @@ def main():
     def step():
       box['state'], box['stats'], box['key'] = training.train_step(model, box['key'], box['state'], batch, sp, bf16=bf16, **kw)
 
+  def timed(nsteps):
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+      step()
+    barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+      t = torch.tensor([el], device=dev, dtype=torch.float64)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      el = t.item()
+    return el
+
   # untimed burn-in at the same workload (>= --burn-in-s seconds) so the short timed window below sits at steady-state
   # clocks and power; the sampler keeps running through the timed region
-  sampler = ClockSampler(local_rank if world > 1 else 0)
+  sampler = ClockSampler(ctx['local_rank'] if world > 1 else 0)
   burn_steps = burn_in(step, args.burn_in_s, world, dev) if args.burn_in_s > 0 else 0
   for _ in range(args.warmup):
     step()
   barrier()
   sampler.start()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    step()
-  barrier()
-  elapsed = time.perf_counter() - t0
+  elapsed = timed(args.steps)
   clocks = sampler.stop()
-  if world > 1:
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = t.item()
   state, stats, key = box['state'], box['stats'], box['key']
   loss = stats['fine']['loss/rgb'].item()
   # every rank applied the same all-reduced gradient to the same initial parameters: the replicas must be BIT-identical.
@@ -556,7 +542,7 @@ def main():
       raise SystemExit(f'rank {rank}: parameter replicas diverged across ranks: checksums {[a[:2].tolist() for a in allr]}')
 
   # ---- the gradient all-reduce on its own (outside the timed region): the fused [grad | stats] buffer, 20 calls ----
-  allreduce_us = None
+  allreduce_us = exposed_us = None
   if dist_on:
     buf = torch.zeros_like(state.optimizer._gs)
     for _ in range(5):
@@ -569,20 +555,126 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     allreduce_us = e0.elapsed_time(e1) * 1e3 / 20
+    if not graph:
+      # the exposed share of the collective: the same K steps with the all-reduce taken out (each rank then applies its OWN
+      # gradient: the replicas diverge from here on, which is why this runs after the checksum check and nothing below compares
+      # ranks).  exposed = t(step) - t(step without the collective); the rest of grad_allreduce_us hides under kernels.
+      keep = training.psum_gradients
+      training.psum_gradients = lambda grad, st, fused=None: (grad, st.clone(), world)
+      try:
+        for _ in range(args.warmup):
+          step()
+        nocomm = timed(args.steps)
+      finally:
+        training.psum_gradients = keep
+      exposed_us = 1e6 * (elapsed - nocomm) / args.steps
 
-  # ---- per-kernel timing of the SAME step with HIP events on the launch stream (eager: events cannot be recorded inside a
-  #      graph replay) ----
-  model.profile_enable(True)
-  prof_steps = max(5, min(args.steps, 20))
-  for _ in range(prof_steps):
-    state, stats, key = training.train_step(model, key, state, batch, sp, bf16=bf16, **kw)
-  torch.cuda.synchronize()
-  prof = model.profile_read()
-  model.profile_enable(False)
+  prof, prof_steps = None, 0
+  if profile:
+    # per-kernel timing of the SAME step with HIP events on the launch stream (eager: events cannot be recorded inside a
+    # graph replay)
+    model.profile_enable(True)
+    prof_steps = max(5, min(args.steps, 20))
+    for _ in range(prof_steps):
+      state, stats, key = training.train_step(model, key, state, batch, sp, bf16=bf16, **kw)
+    torch.cuda.synchronize()
+    prof = model.profile_read()
+    model.profile_enable(False)
+  return {'elapsed': elapsed, 'ms_per_step': 1e3 * elapsed / args.steps, 'value': world * rays_per_gpu * args.steps / elapsed,
+          'loss': loss, 'per_rank_loss': per_rank_loss, 'replicas_agree': replicas_agree, 'allreduce_us': allreduce_us,
+          'allreduce_exposed_us': exposed_us, 'allreduce_bytes': 4 * state.optimizer._gs.numel(), 'burn_steps': burn_steps,
+          'clocks': clocks, 'prof': prof, 'prof_steps': prof_steps}
+
+
+def main(argv=None):
+  argv = list(sys.argv[1:] if argv is None else argv)
+  ap = argparse.ArgumentParser()
+  ap.add_argument('--gpus', type=int, default=1)
+  ap.add_argument('--steps', type=int, default=30)
+  ap.add_argument('--warmup', type=int, default=5)
+  ap.add_argument('--no-cpu-baseline', action='store_true')
+  ap.add_argument('--burn-in-s', type=float, default=3.0,
+                  help='seconds of untimed steps of the same workload before the warm-up + timed steps (steady-state clocks)')
+  ap.add_argument('--mode', default='train', choices=['train', 'train_bf16', 'eval', 'vrig', 'fullhd'],
+                  help='train: BASELINE configs[1] (default, the headline); eval: configs[4] video-render forward '
+                       '(8192-ray chunks x (128+128), hipGraph replay); vrig: configs[2] shape (768 rays/GPU x (128+128), '
+                       'SE3 warp F_w=6 + camera code + elastic + background regularisers); fullhd: configs[3] shape (512 rays/GPU x '
+                       '(256+256), F_p=10, SE3 warp F_w=8, appearance ids, elastic + background; --bf16 = the precision BASELINE '
+                       'names for it); train_bf16: the headline workload with bfloat16 MLP operands and stash (opt-in mode, '
+                       'never the default line)')
+  ap.add_argument('--bf16', action='store_true', help='vrig / fullhd / eval: NeRF MLPs in the bf16 mode (same as BENCH_BF16=1)')
+  ap.add_argument('--rays-per-gpu', type=int, default=0,
+                  help='rays per GPU of the training modes (default: the mode\'s own, 1024 for the headline); 128 = one GPU\'s share '
+                       'of a 1024-ray global batch on 8 GPUs (the north star\'s strong-scaling point)')
+  ap.add_argument('--graph', action='store_true', help='replay the whole train step (loss+grad, all-reduce, Adam) from one hipGraph')
+  ap.add_argument('--no-strong', action='store_true', help='N>1: skip the nested strong-scaling record (1024-ray global batch)')
+  ap.add_argument('--warp', action='store_true', help='eval mode: render with the SE3 warp field (the path eval.py takes)')
+  ap.add_argument('--warp-f32', action='store_true', help='bf16 modes: keep the SE3 trunk in float32 (NRF_FLAG_WARP_F32; the round-3 behaviour)')
+  ap.add_argument('--frame', action='store_true', help='eval mode: also time evaluation.render_image on a whole 960x540 frame')
+  args = ap.parse_args(argv)
+
+  if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+    # `python bench.py --gpus N` as the driver types it: become the launcher of N ranks (one per GPU) and return their exit code
+    raise SystemExit(self_launch(args, argv))
+  world = int(os.environ.get('WORLD_SIZE', '1'))
+  rank = int(os.environ.get('RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  if world != max(args.gpus, 1):
+    raise SystemExit(f'--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+  # Hooks for exercising the N>1 code path on a ONE-GPU box (set by launch_plan when ranks outnumber devices, never by the
+  # driver): BENCH_DIST_BACKEND=gloo swaps RCCL for gloo, BENCH_SAME_DEVICE=1 places the ranks round-robin on the visible
+  # devices (RCCL refuses two ranks on one device), BENCH_FORCE_DIST=1 creates the RCCL communicator even with ONE rank, so
+  # that the step's fused [grad | stats] all-reduce really goes through librccl on the one GPU a box has.
+  backend = os.environ.get('BENCH_DIST_BACKEND', 'nccl')
+  force_dist = bool(os.environ.get('BENCH_FORCE_DIST')) and world == 1
+  if os.environ.get('BENCH_SAME_DEVICE'):
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)
+  if world > 1 or force_dist:
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29531')
+    torch.cuda.set_device(local_rank)
+    kw = {'rank': rank, 'world_size': world} if force_dist else {}
+    if backend == 'nccl':
+      dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), **kw)
+    else:
+      dist.init_process_group(backend, **kw)
+  dev = torch.device('cuda', local_rank if world > 1 else 0)
+  torch.cuda.set_device(dev)
+  dist_on = world > 1 or force_dist
+  ctx = {'world': world, 'rank': rank, 'local_rank': local_rank, 'dev': dev, 'dist_on': dist_on}
+
+  bf16 = args.bf16 or bool(os.environ.get('BENCH_BF16'))
+  if bf16 and args.warp_f32:
+    bf16 = 'mlp'
+  if args.mode == 'eval':
+    eval_mode(args, world, rank, dev, bf16)
+    if dist_on:
+      dist.destroy_process_group()
+    return
+
+  M = TRAIN_MODES[args.mode]
+  bf16 = bf16 or bool(M.get('force_bf16'))
+  BF16_NOTE = BF16_NOTE_MLP if bf16 == 'mlp' else BF16_NOTE_ALL
+  cfg = M['cfg']
+  rays_per_gpu = args.rays_per_gpu or M['rays']
+  r = train_workload(args, M, cfg, rays_per_gpu, bf16, args.graph, ctx)
+
+  # ---- N>1: the north star's other curve in the same run.  "1024-ray batches at 1, 2, 4, 8": the GLOBAL batch stays 1024
+  #      rays, every GPU gets 1024/N of them (training.py:266 pmean over the same global batch) -- eager, and with the whole
+  #      step replayed from one hipGraph (what a ~1 ms step needs) ----
+  strong = None
+  if world > 1 and not args.no_strong and not args.rays_per_gpu and RAYS_PER_GPU % world == 0:
+    per = RAYS_PER_GPU // world
+    strong = {'global_batch': RAYS_PER_GPU, 'rays_per_gpu': per, 'scaling': 'strong', 'unit': 'rays/s'}
+    sargs = argparse.Namespace(**dict(vars(args), burn_in_s=min(args.burn_in_s, 1.0)))
+    for name, g in (('eager', False), ('graph', True)):
+      s = train_workload(sargs, M, cfg, per, bf16, g, ctx, profile=False)
+      strong[name] = {'value': s['value'], 'ms_per_step': s['ms_per_step'], 'replica_param_checksums_agree': s['replicas_agree'],
+                      'allreduce_exposed_us': s['allreduce_exposed_us'], 'final_loss_fine': s['loss']}
 
   if rank == 0:
-    ms_per_step = 1e3 * elapsed / args.steps
-    value = world * rays_per_gpu * args.steps / elapsed
+    prof, prof_steps, elapsed, clocks = r['prof'], r['prof_steps'], r['elapsed'], r['clocks']
+    ms_per_step = r['ms_per_step']
     step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / prof_steps
     mode_key = args.mode + ('_bf16' if bf16 and not M.get('force_bf16') else '')
     roofline, peak_tf = roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg)
@@ -592,8 +684,9 @@ def main():
     mixed = bf16 == 'mlp' and getattr(cfg, 'use_warp', False)   # bf16 NeRF MLPs next to a float32 SE3 trunk
     # the step's flops are priced against the bf16 peak only when every MFMA kernel of it runs in bf16 (warp off)
     step_peak = PEAK_BF16_MFMA_TFLOPS if (bf16 and not mixed) else PEAK_FP32_MFMA_TFLOPS
+    over = os.environ.get('BENCH_OVERSUBSCRIBED')
     out = {
-        'metric': M['metric'], 'value': value, 'unit': 'rays/s', 'n_gpus': world,
+        'metric': M['metric'], 'value': r['value'], 'unit': 'rays/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': ms_per_step, 'higher_is_better': True,
         'scaling': 'weak', 'vs_baseline': None,
         'dtype': ('bf16 NeRF MLPs + f32 warp field' if mixed else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
@@ -604,21 +697,29 @@ def main():
         'roofline': roofline,
         'step_tflops': step_flops / (ms_per_step * 1e-3) / 1e12,
         ('step_frac_of_bf16_mfma_peak' if step_peak == PEAK_BF16_MFMA_TFLOPS else 'step_frac_of_fp32_mfma_peak'):
-            None if mixed else step_flops / (ms_per_step * 1e-3) / 1e12 / (step_peak * world),
+            None if mixed else step_flops / (ms_per_step * 1e-3) / 1e12 / step_peak,
         'kernels': kernels, 'sum_of_kernels_ms': ksum_ms, 'step_over_sum_of_kernels': ms_per_step / ksum_ms if ksum_ms else None,
-        'final_loss_fine': loss, 'per_rank_final_loss_fine': per_rank_loss, 'replica_param_checksums_agree': replicas_agree,
-        'steady_state': {'burn_in_steps': burn_steps, 'burn_in_s': args.burn_in_s, 'timed_window_s': elapsed,
+        'final_loss_fine': r['loss'], 'per_rank_final_loss_fine': r['per_rank_loss'],
+        'replica_param_checksums_agree': r['replicas_agree'],
+        'steady_state': {'burn_in_steps': r['burn_steps'], 'burn_in_s': args.burn_in_s, 'timed_window_s': elapsed,
                          'during_timed_window': clocks},
         'graph_replay': bool(args.graph),
         'rccl_ranks': dist.get_world_size() if dist_on else 1, 'dist_backend': backend if dist_on else None,
         'rccl_version': rccl_version() if dist_on and backend == 'nccl' else None,
-        'grad_allreduce_us': allreduce_us, 'grad_allreduce_bytes': 4 * state.optimizer._gs.numel(),
+        'grad_allreduce_us': r['allreduce_us'], 'grad_allreduce_bytes': r['allreduce_bytes'],
+        'grad_allreduce_exposed_us': r['allreduce_exposed_us'],
+        'grad_allreduce_exposed_frac': (r['allreduce_exposed_us'] / (1e3 * ms_per_step)) if r['allreduce_exposed_us'] is not None else None,
+        'strong_scaling': strong,
+        'oversubscribed': over,
         'csrc_sha16': kernel_source_sha(),
     }
+    if over:
+      out['config']['workload'] += f' [OVERSUBSCRIBED: {over}, transport {backend} -- code-path check, not a scaling measurement]'
     if world == 1 and args.mode == 'train' and not args.no_cpu_baseline and not force_dist:
       out['cpu_baseline'] = cpu_baseline()
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
   if dist_on:
+    dist.barrier()
     dist.destroy_process_group()
 
 

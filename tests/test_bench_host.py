@@ -65,3 +65,36 @@ def test_burn_in_runs_whole_rounds(monkeypatch):
   monkeypatch.setattr(bench.torch.cuda, 'synchronize', lambda *a, **k: None)
   n = bench.burn_in(lambda: calls.append(1), 0.0)
   assert n == 16 and len(calls) == 16
+
+
+def test_gpus_n_becomes_its_own_launcher(monkeypatch):
+  """`python bench.py --gpus N` outside torch.distributed.run must start N ranks itself (round 4: SystemExit rc 1).  No GPU
+  here: the launch plan is checked, and that main() hands its own argument list to it."""
+  argv = ['--gpus', '8', '--steps', '20', '--warmup', '5']
+  cmd, env = bench.launch_plan(8, argv, ndev=8, environ={})
+  assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--nproc-per-node=8' in cmd and '--nnodes=1' in cmd
+  assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1' and int(cmd[cmd.index('--master-port') + 1]) > 0
+  assert cmd[-len(argv) - 1] == os.path.join(ROOT, 'bench.py') and cmd[-len(argv):] == argv
+  assert env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+  assert 'BENCH_SAME_DEVICE' not in env and 'BENCH_DIST_BACKEND' not in env and 'BENCH_OVERSUBSCRIBED' not in env   # real RCCL run
+  # fewer devices than ranks (the one-GPU lease): same code path, ranks share the device over gloo, and the line says so
+  cmd, env = bench.launch_plan(2, ['--gpus', '2'], ndev=1, environ={})
+  assert env['BENCH_SAME_DEVICE'] == '1' and env['BENCH_DIST_BACKEND'] == 'gloo' and '2 ranks on 1' in env['BENCH_OVERSUBSCRIBED']
+  seen = {}
+  monkeypatch.delenv('WORLD_SIZE', raising=False)
+  monkeypatch.setattr(bench, 'self_launch', lambda args, av: seen.update(gpus=args.gpus, argv=av) or 0)
+  try:
+    bench.main(argv)
+    raise AssertionError('main() must exit with the launcher\'s return code')
+  except SystemExit as e:
+    assert e.code == 0
+  assert seen == {'gpus': 8, 'argv': argv}
+
+
+def test_rank_count_must_match_gpus(monkeypatch):
+  monkeypatch.setenv('WORLD_SIZE', '4')
+  try:
+    bench.main(['--gpus', '2'])
+    raise AssertionError('a launcher that started 4 ranks for --gpus 2 must be refused')
+  except SystemExit as e:
+    assert 'WORLD_SIZE=4' in str(e.code)

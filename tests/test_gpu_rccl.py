@@ -118,3 +118,32 @@ def test_bench_line_through_rccl(tmp_path):
   d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
   assert d['dist_backend'] == 'nccl' and d['rccl_ranks'] == 1 and d['rccl_version'] and d['grad_allreduce_us'] > 0
   assert d['config']['rays_per_gpu'] == 128 and d['value'] > 0
+
+
+def test_bench_gpus_2_launches_itself_and_checks_itself():
+  """`python bench.py --gpus 2 ...` exactly as the driver types it, NOT under torch.distributed.run (round 4: rc 1).  On the
+  one-GPU lease the two ranks share cuda:0 over gloo (the line says `oversubscribed`); on a box with >= 2 GPUs the same command
+  runs RCCL.  One line carries both curves: weak (1024 rays per GPU) and the nested strong-scaling record (512 rays per GPU,
+  eager + hipGraph), each with bit-identical replicas."""
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BENCH_FORCE_DIST', 'BENCH_DIST_BACKEND', 'BENCH_SAME_DEVICE'):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--burn-in-s', '0'],
+                     env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+  assert len(lines) == 1, lines                      # rank 0 prints ONE JSON line
+  d = json.loads(lines[0])
+  import torch
+  assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['replica_param_checksums_agree'] is True
+  assert d['config']['global_batch'] == 2048 and d['scaling'] == 'weak' and d['value'] > 0
+  assert len(d['per_rank_final_loss_fine']) == 2 and d['per_rank_final_loss_fine'][0] != d['per_rank_final_loss_fine'][1]
+  assert d['grad_allreduce_us'] > 0 and d['grad_allreduce_exposed_us'] is not None
+  s = d['strong_scaling']
+  assert s['global_batch'] == 1024 and s['rays_per_gpu'] == 512
+  for k in ('eager', 'graph'):
+    assert s[k]['value'] > 0 and s[k]['replica_param_checksums_agree'] is True
+  if torch.cuda.device_count() < 2:
+    assert d['dist_backend'] == 'gloo' and '2 ranks on 1' in d['oversubscribed'] and 'OVERSUBSCRIBED' in d['config']['workload']
+  else:
+    assert d['dist_backend'] == 'nccl' and d['oversubscribed'] is None and d['rccl_version']

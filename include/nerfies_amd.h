@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 400 /* 0.4.0: NRF_FLAG_BF16 also runs the SE3 trunk in bfloat16 (NRF_FLAG_WARP_F32 opts out).
+#define NRF_VERSION 500 /* 0.5.0: nrf_set_option (NRF_OPT_CHAIN_TILE_ROWS: 32-row tiling of the fp32 chains).
+                           0.4.0: NRF_FLAG_BF16 also runs the SE3 trunk in bfloat16 (NRF_FLAG_WARP_F32 opts out).
                            0.3.0: device-resident per-step scalars (a whole train step replays from one hipGraph), background ids /
                            noise drawn by the library, `points` output without the warp field.
                            0.2.0: alpha condition, pre-encoded metadata, warp Jacobian output, noise_std, warp_reg loss,
@@ -354,6 +355,17 @@ int nrf_debug_wgrad_segments(nrf_handle h, const void* workspace, double* out, i
  * uint32 per (tile, wave, lane, column block): nibble q, bit e <-> tile row 4 * ((q&1) + 2*(lane>>5) + 4*(q>>1)) + e of
  * feature wave * 32 * NCB + 32 * cb + (lane & 31)  (NCB = 2 for the 256-wide trunk, 1 otherwise). */
 int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* float_offset);
+
+/* Tuning options of a handle (no reference counterpart: XLA picks its own tilings).  Must be set before the first
+ * nrf_workspace_bytes / nrf_forward call that uses the handle with a given batch size, or between steps (the next call
+ * re-plans; a stashed forward cannot be differentiated across a change: NRF_E_STATE).  Unknown option / value:
+ * NRF_E_UNSUPPORTED.
+ *   NRF_OPT_CHAIN_TILE_ROWS  rows per workgroup tile of the float32 NeRF-MLP chain kernels (modules.py:95-169):
+ *                            64 = two workgroups per CU (csrc/mlp_chain.hip), 32 = four per CU (csrc/mlp_chain32.hip),
+ *                            0 = automatic (default).  Results agree to float32 summation order; the workspace layout
+ *                            does not depend on it. */
+#define NRF_OPT_CHAIN_TILE_ROWS 1
+int nrf_set_option(nrf_handle h, int32_t option, int64_t value);
 
 /* ---- individual operators (same device code the fused path runs), exposed so
  * parity tests can check each reference function in isolation. ---- */

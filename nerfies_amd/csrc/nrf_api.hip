@@ -108,6 +108,9 @@ struct WsPlan {
   LevelWs L[4];          // 0 coarse, 1 fine, 2 background points (SE3 field only, training.py:117-135),
                          // 3 tangent pass of the coarse warp Jacobian (elastic regulariser, 3 x coarse tiles)
   int elastic = 0;       // plan built with the elastic regulariser's buffers
+  bool bwd32 = false;    // training plan: the fp32 NeRF reverse chain runs on 32-row tiles (mlp_chain32.hip); decides the
+                         // number of bias partials the reduce table sums
+  int chain_rows_opt = 0;   // the handle's option the plan was built under
   int tg_tiles_per = 0;  // primal tiles one tangent pass covers (elastic: coarse level; Jacobian output: the larger level)
   int bgN = 0;           // number of background points the plan was built for
   size_t total_floats;
@@ -199,6 +202,7 @@ struct nrf_handle_s {
   TimeParamOffsets tpo;
   int num_cus = 256;
   bool cu_queried = false;
+  int chain_rows_opt = 0;   // NRF_OPT_CHAIN_TILE_ROWS: 0 automatic, 32, 64
   WsPlan plan;
   // identity of the tables last uploaded to a workspace, and of the last stashed forward
   void* uploaded_ws = nullptr;
@@ -395,6 +399,9 @@ int* tile_counter_or_null(float* base, int idx) {
   return knobs().dynamic_tiles ? reinterpret_cast<int*>(base) + idx : nullptr;
 }
 constexpr int BG = 2;   // level index of the background-point batch
+// automatic choice of the forward chain's tiling (chain32_for): 32-row tiles when the launch has fewer than this many 64-row
+// tiles per CU (the 64-row grid of two workgroups per CU is then not filled)
+constexpr int AUTO32_FWD_BELOW_TILES_PER_CU = 2;
 constexpr int TG = 3;   // level index of the Jacobian tangent pass (3 x the coarse tiles)
 
 // the flags a workspace layout depends on: TRAIN, WARP_JACOBIAN, and BF16 together with TRAIN (bf16 stash instead of fp32)
@@ -404,10 +411,23 @@ uint32_t plan_flags(uint32_t flags) {
   return f;
 }
 
+// Rows per workgroup tile of the float32 NeRF chain kernels for a launch over `ntiles` 64-row tiles: true = 32-row half tiles,
+// four workgroups per CU (mlp_chain32.hip).  NRF_OPT_CHAIN_TILE_ROWS forces either.  Automatic = what the round-5 A/B measured
+// (profiles/r05_chain32_ab.md): in steady state the 64-row kernels win by 3-5 % (forward 130 vs 123.5 TF, reverse 129 vs 125,
+// eval forward 137 vs 132: every B operand float feeds one MFMA instead of two), but a launch that cannot fill the 64-row grid
+// twice over -- fewer than two tiles per workgroup slot, e.g. one GPU's 128-ray share of a 1024-ray batch: 128 + 384 tiles for
+// 512 slots -- runs 12-34 % faster on half tiles (coarse forward 0.160 -> 0.106 ms, fine 0.301 -> 0.264 ms).  The reverse
+// chain never won (0.303 -> 0.327 ms at 512 tiles): its automatic choice stays 64.
+bool chain32_for(const nrf_handle_s* h, int ntiles, bool reverse = false) {
+  if (h->chain_rows_opt == 32) return true;
+  if (h->chain_rows_opt == 64) return false;
+  return !reverse && ntiles < AUTO32_FWD_BELOW_TILES_PER_CU * h->num_cus;
+}
+
 void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 0) {
   WsPlan& p = h->plan;
   flags = plan_flags(flags);
-  if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic) return;
+  if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic && p.chain_rows_opt == h->chain_rows_opt) return;
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
   const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
@@ -422,6 +442,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   p.bgN = bgN;
   p.bfw = bfw;
   p.elastic = elastic;
+  p.chain_rows_opt = h->chain_rows_opt;
   p.S[0] = d.num_coarse_samples;
   p.S[1] = d.num_coarse_samples + d.num_fine_samples;
   p.S[BG] = 1;
@@ -429,6 +450,12 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   for (int lv = 0; lv < 3; ++lv) {
     p.rows[lv] = lv == BG ? bgN : B * p.S[lv];
     p.ntiles[lv] = (p.rows[lv] + TILE_ROWS - 1) / TILE_ROWS;
+  }
+  {   // the reverse chain's tiling is part of the plan (the reduce table sums one bias partial per workgroup of that launch);
+      // the 32-row reverse kernel has no d-points path: models with a warp field keep the 64-row one
+    int nt_mlp = 0;
+    for (int q = 0; q < h->nlevels; ++q) nt_mlp += p.ntiles[q];
+    p.bwd32 = train && !bft && !h->warp && chain32_for(h, nt_mlp, true);
   }
   p.tg_tiles_per = jac ? p.ntiles[h->nlevels - 1] : elastic ? p.ntiles[0] : 0;   // Jacobian output: levels run one after the other
   p.ntiles[TG] = 3 * p.tg_tiles_per;
@@ -840,7 +867,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       L.b_dsmall = take(ng * 2 * BF_BLOCK_DW);
       L.d_raw4 = take(nt * TILE_ROWS * 4);
       L.dray = take((size_t)B * RGB_W);
-      L.small_part = take((size_t)2 * G * SMALL_PART);
+      L.small_part = take((size_t)4 * G * SMALL_PART);   // up to four workgroups per CU (32-row reverse chain)
       L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
     } else if (train) {
       L.st_pe = take(nt * PKS * TILE_ROWS);
@@ -854,7 +881,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       L.dy_bn = take(nt * FRAG_TILE_256);
       L.dy_rgbh = take(nt * FRAG_TILE_128);
       L.dray = take((size_t)B * RGB_W);
-      L.small_part = take((size_t)2 * G * SMALL_PART);
+      L.small_part = take((size_t)4 * G * SMALL_PART);   // up to four workgroups per CU (32-row reverse chain)
       L.cond_grad = take((size_t)(h->R > 0 ? h->R : 1) * RGB_W);
     }
     if (h->warp) alloc_warp(L, nt);
@@ -1027,7 +1054,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       const LevelWs& L = p.L[lv];
       int nt_mlp = 0;
       for (int q = 0; q < h->nlevels; ++q) nt_mlp += p.ntiles[q];
-      const int grid = nt_mlp < 2 * G ? nt_mlp : 2 * G;   // ONE dgrad launch over the tiles of all levels, two workgroups per CU
+      // ONE dgrad launch over the tiles of all levels: two workgroups per CU on 64-row tiles, four on 32-row half tiles
+      const int grid = p.bwd32 ? (2 * nt_mlp < 4 * G ? 2 * nt_mlp : 4 * G) : (nt_mlp < 2 * G ? nt_mlp : 2 * G);
       auto small = [&](int64_t dst, int cols, int sp_off) {
         if (bft) return;   // the bf16 wgrad kernel sums the bias columns itself
         ReduceDesc r;
@@ -1367,7 +1395,9 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
     }
     ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train, rnd, dyn);
     const int gmul = knobs().grid_mul;
-    const int grid = p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus;   // two workgroups per CU
+    const bool c32 = !bf16 && chain32_for(h, p.ntiles[lv]);   // 32-row half tiles, four workgroups per CU
+    const int grid = c32 ? (2 * p.ntiles[lv] < 4 * h->num_cus ? 2 * p.ntiles[lv] : 4 * h->num_cus)
+                         : (p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus);   // two workgroups per CU
     if (warp_on) {
       // the background-point batch of the fused train step rides in the coarse launch (its 256 tiles under-fill the chip)
       const bool with_bg = lv == 0 && train && bg && p.bgN > 0;
@@ -1408,7 +1438,8 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       const int nit = (p.rows[lv] + 255) / 256;
       launch_chain_fwd_bf16(a, nit < h->num_cus ? nit : h->num_cus, stream);
     } else {
-      launch_chain_fwd(a, train, grid, stream);
+      if (c32) launch_chain_fwd32(a, train, grid, stream);
+      else launch_chain_fwd(a, train, grid, stream);
     }
     pf.end(stream);
     pf.begin("composite_fwd", 0, stream);
@@ -1504,6 +1535,12 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     if (el_on) z.add(ws + p.el_sums, 64);
     if (bg_on) z.add(ws + p.bg_loss, 64);
     for (int lv = 0; lv < h->nlevels; ++lv) z.add(ws + p.L[lv].dray, (long long)B * RGB_W);
+    if (p.bwd32 && !warp_on && !bft) {   // the 32-row reverse chain ADDS its bias column sums into the workgroups' slices
+      int nt_all = 0;
+      for (int lv = 0; lv < h->nlevels; ++lv) nt_all += p.ntiles[lv];
+      const long long g32 = 2 * nt_all < 4 * h->num_cus ? 2 * nt_all : 4 * h->num_cus;
+      for (int lv = 0; lv < h->nlevels; ++lv) z.add(ws + p.L[lv].small_part, g32 * SMALL_PART);
+    }
     if (z.overflow) return fail(NRF_E_STATE, "zero_ranges table full: an accumulator would stay unzeroed");
     launch_zero_ranges(z, stream);
   }
@@ -1565,7 +1602,13 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       nt_all += p.ntiles[lv];
     }
     h->prof.begin("mlp_dgrad", dgrad_flops_row(h, warp_on) * mlp_rows, stream);
-    launch_chain_bwd(ca[0], h->nlevels > 1 ? &ca[1] : nullptr, nt_all < G2 ? nt_all : G2, stream);
+    if (p.bwd32 && !warp_on) {
+      const int G4 = 4 * h->num_cus;
+      launch_chain_bwd32(ca[0], h->nlevels > 1 ? &ca[1] : nullptr, 2 * nt_all < G4 ? 2 * nt_all : G4, stream);
+    } else {
+      if (p.bwd32) return fail(NRF_E_STATE, "plan built for the 32-row reverse chain but the stashed forward ran the warp field");
+      launch_chain_bwd(ca[0], h->nlevels > 1 ? &ca[1] : nullptr, nt_all < G2 ? nt_all : G2, stream);
+    }
     h->prof.end(stream);
     (void)nt_all;
   }
@@ -2010,6 +2053,20 @@ int nrf_warp_points(nrf_handle h, const float* params, const float* points, cons
   e = hipMemcpyAsync(warped, ws + q.out_f, (size_t)num_points * 3 * sizeof(float), hipMemcpyDeviceToDevice, st);
   if (e != hipSuccess) return fail_hip(e, "copy warped points");
   return check_launch("nrf_warp_points");
+}
+
+int nrf_set_option(nrf_handle h, int32_t option, int64_t value) {
+  if (!h) return fail(NRF_E_NULL, "handle is null");
+  if (option == NRF_OPT_CHAIN_TILE_ROWS) {
+    if (value != 0 && value != 32 && value != 64) return fail(NRF_E_UNSUPPORTED, "NRF_OPT_CHAIN_TILE_ROWS: 0 (automatic), 32 or 64");
+    if (h->chain_rows_opt != (int)value) {
+      h->chain_rows_opt = (int)value;
+      h->stashed_ws = nullptr;   // a stash written under the old plan is not differentiated under the new one
+      h->uploaded_ws = nullptr;  // ... and the next call uploads the re-planned tables
+    }
+    return NRF_OK;
+  }
+  return fail(NRF_E_UNSUPPORTED, "unknown option");
 }
 
 int nrf_profile_enable(nrf_handle h, int32_t on) {

@@ -393,6 +393,10 @@ void launch_pack(const PackDesc* d_descs, int ndesc, const float* params, float*
 void launch_chain_fwd(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
 // a1 (optional): the fine level, run by the same launch (tiles [a0.ntiles, a0.ntiles + a1->ntiles))
 void launch_chain_bwd(const ChainBwdArgs& a0, const ChainBwdArgs* a1, int grid, hipStream_t stream);
+// the same chains on 32-row tiles, four workgroups per CU (mlp_chain32.hip); same arguments, same HBM images.  The reverse
+// kernel has no d-points path yet: warp-on plans keep the 64-row reverse pass
+void launch_chain_fwd32(const ChainFwdArgs& a, bool stash, int grid, hipStream_t stream);
+void launch_chain_bwd32(const ChainBwdArgs& a0, const ChainBwdArgs* a1, int grid, hipStream_t stream);
 // a1 (optional): a second level in the same launch (background points behind the coarse samples)
 void launch_warp_fwd(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int grid, hipStream_t stream);
 // a1, a2 (optional): further levels in the same launch; bias partials of all levels go to a.small_part
@@ -473,13 +477,13 @@ void launch_background_loss(const float* points, const float* warped, int N, int
                             float weight, float* d_points, float* loss_sum, hipStream_t stream);
 // zero-fills up to 8 float ranges in one launch (16-byte aligned pointers)
 struct ZeroArgs {
-  float* p[8];
-  long long n[8];
+  float* p[12];
+  long long n[12];
   int count;
-  bool overflow;   // a ninth range was offered: the caller must fail (an accumulator would stay unzeroed)
+  bool overflow;   // a thirteenth range was offered: the caller must fail (an accumulator would stay unzeroed)
   void add(float* ptr, long long nfloats) {
     if (nfloats <= 0) return;
-    if (count >= 8) { overflow = true; return; }
+    if (count >= 12) { overflow = true; return; }
     p[count] = ptr; n[count] = nfloats; ++count;
   }
 };

@@ -71,23 +71,54 @@ class GraphedChunkRenderer:
       def cp(dst, src):
         if isinstance(dst, dict):
           for k in dst:
-            cp(dst[k], (src or {}).get(k) if isinstance(dst[k], dict) else src[k])
+            cp(dst[k], src[k])
         else:
           dst.copy_(src)
+      _check_same_tree(slot[1], rays)   # same keys / shapes / dtypes as the captured chunk, or a clear NrfError
       cp(slot[1], rays)
     slot[0].replay()
     return slot[2]
 
 
+def _check_same_tree(dst, src, path='rays'):
+  """The replay path copies new rays into the captured static buffers: same keys, same shapes, same dtypes -- or a clear error
+  (a missing sub-dict used to surface as a TypeError on None)."""
+  from nerfies_amd import lib as L
+  if isinstance(dst, dict):
+    if not isinstance(src, dict) or set(dst) != set(src):
+      have = sorted(src) if isinstance(src, dict) else type(src).__name__
+      raise L.NrfError(f'GraphedChunkRenderer: {path} has keys {have}, the captured chunk had {sorted(dst)}; render with the same '
+                       'ray tree or use a new renderer')
+    for k in dst:
+      _check_same_tree(dst[k], src[k], f'{path}/{k}')
+  elif tuple(dst.shape) != tuple(src.shape) or dst.dtype != src.dtype:
+    raise L.NrfError(f'GraphedChunkRenderer: {path} is {tuple(src.shape)} {src.dtype}, the captured chunk had {tuple(dst.shape)} {dst.dtype}')
+
+
+def _pack(ret, rows):
+  """Every output key of a rendered chunk side by side in one (rows, sum of widths) float32 buffer: one collective carries all."""
+  keys = list(ret.keys())
+  cols = [ret[k].reshape(rows, -1).to(torch.float32) for k in keys]
+  return keys, cols, [c.shape[1] for c in cols]
+
+
 def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_count: int = 1, rng=0,
-                 chunk: int = 8192, default_ret_key: Optional[str] = None):
+                 chunk: int = 8192, default_ret_key: Optional[str] = None, tile_parallel: str = 'band'):
   """Renders all pixels of an (H,W) ray image in chunks (evaluation.py:62-99).
 
   model_fn(key_0, key_1, params, chunk_rays_dict, warp_extra) -> {'coarse': {...}, 'fine': {...}}.
-  With torch.distributed initialised each rank renders a contiguous slice of every chunk (image
-  tiles are disjoint, so the reference's all_gather (eval.py:339) becomes one all_gather of the
-  rendered slices); the last chunk is edge-padded to a multiple of the world size
-  (evaluation.py:71-78)."""
+  With torch.distributed initialised the frame is split over the ranks (image tiles are disjoint: no reduction, the
+  reference all_gathers and keeps replica 0, eval.py:339, evaluation.py:92):
+    tile_parallel='band' (default): every rank renders a contiguous BAND of whole chunks -- full-size launches, the shape the
+      kernels are tuned for -- into a band buffer, and ONE all_gather per frame assembles it (BASELINE configs[4]: "8-GPU
+      image-tile parallel");
+    tile_parallel='chunk': the reference's own order -- every chunk is cut `world` ways (evaluation.py:61-92), one packed
+      all_gather per chunk (64 latency-bound collectives and 1/world-size launches for a 960x540 frame on 8 GPUs).
+  Both give the single-rank frame bit for bit (rows are rendered independently of their position in a launch).  The last
+  chunk is edge-padded (evaluation.py:71-78): to the full chunk for a graph-replaying renderer, to a multiple of the world
+  size in 'chunk' mode."""
+  if tile_parallel not in ('band', 'chunk'):
+    raise ValueError("tile_parallel must be 'band' or 'chunk'")
   h, w = rays_dict['origins'].shape[:2]
   flat = _tree_map(lambda x: x.reshape(h * w, -1), rays_dict)
   num_rays = h * w
@@ -95,32 +126,64 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
   world = dist.get_world_size() if dist_on else 1
   rank = dist.get_rank() if world > 1 else 0
   del device_count
-  frame = None          # output key -> (num_rays, ...) buffer, filled chunk by chunk at the chunk's offset
   call = getattr(model_fn, 'call_static', model_fn)   # a graph renderer hands out its static output buffers (no per-chunk clone)
   num_chunks = int(math.ceil(num_rays / chunk))
   # a graph-replaying renderer wants ONE chunk size per frame: the tail is edge-padded to the full chunk (rendered and
   # dropped) instead of being a second shape; otherwise it is padded to a multiple of the world size only
   fixed = bool(getattr(model_fn, 'wants_fixed_chunks', False)) and num_chunks > 1
-  for batch_idx in range(num_chunks):
+
+  def padded_chunk(batch_idx, multiple):
     i0 = batch_idx * chunk
-    chunk_rays = _tree_map(lambda x: x[i0:i0 + chunk], flat)
-    n = chunk_rays['origins'].shape[0]
-    full = -(-chunk // world) * world if fixed else n
-    pad = max(full - n, 0) + (world - max(full, n) % world) % world
+    rays = _tree_map(lambda x: x[i0:i0 + chunk], flat)
+    n = rays['origins'].shape[0]
+    full = -(-chunk // multiple) * multiple if fixed else n
+    pad = max(full - n, 0) + (multiple - max(full, n) % multiple) % multiple
     if pad:
-      chunk_rays = _tree_map(lambda x: torch.cat([x, x[-1:].expand(pad, *x.shape[1:])], 0), chunk_rays)
-    per = (n + pad) // world
+      rays = _tree_map(lambda x: torch.cat([x, x[-1:].expand(pad, *x.shape[1:])], 0), rays)
+    return i0, n, n + pad, rays
+
+  if dist_on and tile_parallel == 'band':
+    cpr = -(-num_chunks // world)                     # chunks per rank; the last ranks may own fewer (or none)
+    band_rows = cpr * chunk
+    band, meta = None, None
+    for c in range(rank * cpr, min((rank + 1) * cpr, num_chunks)):
+      i0, n, _, rays = padded_chunk(c, 1)
+      out = call(rng, rng + 1, state.optimizer.target, rays, state.warp_extra)
+      ret = out[default_ret_key or ('fine' if 'fine' in out else 'coarse')]
+      keys, cols, widths = _pack(ret, rays['origins'].shape[0])
+      if band is None:
+        band = torch.zeros(band_rows, sum(widths), dtype=torch.float32, device=cols[0].device)
+        meta = (keys, widths, [tuple(ret[k].shape[1:]) for k in keys], [ret[k].dtype for k in keys])
+      at, col = i0 - rank * band_rows, 0
+      for cdata, wd in zip(cols, widths):
+        band[at:at + n, col:col + wd].copy_(cdata[:n])
+        col += wd
+    # a rank without a chunk (more ranks than chunks) still joins the collective: it learns the layout from rank 0
+    lay = [meta]
+    if world > 1:
+      dist.broadcast_object_list(lay, src=0)
+    keys, widths, shapes, dtypes = lay[0]
+    if band is None:
+      band = torch.zeros(band_rows, sum(widths), dtype=torch.float32, device=flat['origins'].device)
+    gathered = torch.empty(world * band_rows, band.shape[1], dtype=band.dtype, device=band.device)
+    dist.all_gather_into_tensor(gathered, band)     # ONE collective per frame
+    split = torch.split(gathered[:num_rays], widths, 1)
+    return {k: split[i].reshape(h, w, *shapes[i]).to(dtypes[i]) for i, k in enumerate(keys)}
+
+  frame = None          # output key -> (num_rays, ...) buffer, filled chunk by chunk at the chunk's offset
+  for batch_idx in range(num_chunks):
+    i0, n, total, chunk_rays = padded_chunk(batch_idx, world)
+    per = total // world
     mine = _tree_map(lambda x: x[rank * per:(rank + 1) * per], chunk_rays) if world > 1 else chunk_rays
     out = call(rng, rng + 1, state.optimizer.target, mine, state.warp_extra)
     ret_key = default_ret_key or ('fine' if 'fine' in out else 'coarse')
     ret = out[ret_key]
     if dist_on:   # ONE all_gather per chunk: every output key packed side by side into a (per, sum of widths) buffer
-      keys = list(ret.keys())
-      cols = [ret[k].reshape(per, -1).to(torch.float32) for k in keys]
+      keys, cols, widths = _pack(ret, per)
       packed = torch.cat(cols, 1).contiguous()
       gathered = torch.empty(world * per, packed.shape[1], dtype=packed.dtype, device=packed.device)
       dist.all_gather_into_tensor(gathered, packed)
-      split = torch.split(gathered, [c.shape[1] for c in cols], 1)
+      split = torch.split(gathered, widths, 1)
       ret = {k: split[i].reshape(world * per, *ret[k].shape[1:]).to(ret[k].dtype) for i, k in enumerate(keys)}
     if frame is None:
       frame = {k: torch.empty(num_rays, *v.shape[1:], dtype=v.dtype, device=v.device) for k, v in ret.items()}

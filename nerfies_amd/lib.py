@@ -106,6 +106,8 @@ class ProfileEntry(C.Structure):
               ('flops_per_launch', C.c_double)]
 
 
+NRF_OPT_CHAIN_TILE_ROWS = 1
+
 EXPORTS = [
     'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',
     'nrf_workspace_bytes', 'nrf_forward', 'nrf_backward', 'nrf_train_step_loss_grad', 'nrf_adam_step',
@@ -113,7 +115,7 @@ EXPORTS = [
     'nrf_debug_wgrad_segments', 'nrf_debug_ws_offset', 'nrf_train_step_loss_grad_ex', 'nrf_workspace_bytes_ex',
     'nrf_warp_points_workspace_bytes', 'nrf_warp_points',
     'nrf_camera_pixels_to_rays', 'nrf_camera_pixels_to_points', 'nrf_camera_project',
-    'nrf_dynamic_scalars_write', 'nrf_adam_step_dynamic',
+    'nrf_dynamic_scalars_write', 'nrf_adam_step_dynamic', 'nrf_set_option',
 ]
 
 _lib = None
@@ -157,6 +159,7 @@ def load_library(path=None):
       'nrf_profile_read': [vp, C.POINTER(ProfileEntry), C.POINTER(i32)],
       'nrf_debug_wgrad_segments': [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)],
       'nrf_debug_ws_offset': [vp, C.c_char_p, i32, C.POINTER(i64)],
+      'nrf_set_option': [vp, i32, i64],
       'nrf_train_step_loss_grad_ex': [vp, vp, C.POINTER(Rays), vp, C.POINTER(StepScalars), C.POINTER(Rand),
                                       C.POINTER(Background), C.POINTER(Elastic), C.POINTER(WarpReg), u32, vp, vp, vp,
                                       C.c_size_t, vp],

@@ -8,6 +8,7 @@ library through the C-ABI (include/nerfies_amd.h).  Differences forced by the mi
     nested dict (copied into a flat buffer per call).
 """
 import ctypes as C
+import os
 import dataclasses
 from typing import Any, Dict, Mapping, Optional, Sequence, Tuple
 
@@ -189,7 +190,16 @@ class NerfModel:
       d = self.desc()
       L.check(self.lib.nrf_create(C.byref(d), C.byref(h)), self.lib)
       self._handle = h
+      rows = os.environ.get('NRF_CHAIN_TILE_ROWS')   # experiments / the A-B tests: 32 or 64 for every model of the process
+      if rows:
+        self.set_chain_tile_rows(int(rows))
     return self._handle
+
+  def set_chain_tile_rows(self, rows: int):
+    """NRF_OPT_CHAIN_TILE_ROWS: rows per workgroup tile of the float32 NeRF chain kernels -- 64 (two workgroups per CU), 32
+    (four per CU) or 0 = automatic (the default).  A tuning knob without a reference counterpart; results agree to float32
+    summation order."""
+    L.check(self.lib.nrf_set_option(self.handle, L.NRF_OPT_CHAIN_TILE_ROWS, int(rows)), self.lib)
 
   @property
   def layout(self) -> P.ParamLayout:

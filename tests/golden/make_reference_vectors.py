@@ -486,6 +486,168 @@ def general_loss_branches():
   save('general_loss_branches', **out)
 
 
+# ---- round 5: NerfModel.apply at the BASELINE shapes (every earlier ref_nerf_* case is 3 rays x <= 10+7 samples) ----
+BASELINE_CASES = {
+    # configs[1] gpu_quarterhd as measured: 64 + 128 samples, F_p = 8, stratified, warp off (bench.py's headline workload)
+    'cfgA': (dict(num_coarse_samples=64, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=True), 0.0, 64),
+    # configs[2] gpu_vrig_paper: 128 + 128, F_p = 8, SE3 warp F_w = 6, G = 8, camera code
+    'cfgC': (dict(num_coarse_samples=128, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=True, use_warp=True,
+                  num_warp_freqs=6, num_warp_features=8, use_camera_metadata=True), 6.0, 16),
+    # configs[3] gpu_fullhd: 256 + 256, F_p = 10, SE3 warp F_w = 8, appearance ids
+    'cfgD': (dict(num_coarse_samples=256, num_fine_samples=256, num_nerf_point_freqs=10, use_stratified_sampling=True, use_warp=True,
+                  num_warp_freqs=8, num_warp_features=8, use_appearance_metadata=True), 8.0, 8),
+}
+
+
+def nerf_model_baseline_shapes():
+  """models.NerfModel.apply (models.py:289-375) by the unmodified reference at the sample counts / posenc widths BASELINE.json
+  names.  No Jacobian output (the shim's jacfwd is 6 warp evaluations per sample); float32 storage keeps the fixtures small --
+  the consumers compare float32 kernels with 1e-4 tolerances."""
+  for name, (kw, alpha, B) in BASELINE_CASES.items():
+    spec = O.ModelSpec(**kw)
+    seed = 500 + sum(ord(c) for c in name)
+    params = O.init_params(spec, seed=seed, trained_like=True)
+    batch = O.synthetic_batch(B, seed=seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    t_rand = rng.uniform(0, 1, (B, spec.num_coarse_samples)).astype(np.float32).astype(np.float64)
+    u = rng.uniform(0, 1, (B, spec.num_fine_samples)).astype(np.float32).astype(np.float64)
+    model = build_ref_model(spec)
+    rays = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(),
+            'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}}
+    ret = model.apply({'params': tree_np(params)}, rays, {'alpha': alpha, 'time_alpha': 0.0}, return_points=spec.use_warp,
+                      return_weights=True, rngs={'coarse': jrandom.Key(uniform=t_rand), 'fine': jrandom.Key(uniform=u)})
+    out = dict(t_rand=t_rand.astype(np.float32), u=u.astype(np.float32), alpha=alpha, seed=seed, num_rays=B)
+    for lv, d in ret.items():
+      for k, v in d.items():
+        if k in ('rgb', 'depth', 'med_depth', 'acc', 'weights', 'warped_points'):
+          out[f'{lv}/{k}'] = np.asarray(v, dtype=np.float32)
+    save('nerf_' + name, **out)
+
+
+# ---- round 5: a REFERENCE-side gradient (VERDICT r4 item 7).  jax.value_and_grad cannot run under the NumPy shim; what can is the
+#      reference's own _loss_fn (training.py:229-262, the closure train_step differentiates), evaluated in float64 at
+#      params +- eps * v: a central-difference directional derivative.  lax.stop_gradient (model_utils.py:187 on the fine
+#      z samples, training.py:181 / :200 on the weights) must then keep its meaning -- value passes, derivative does not --
+#      so the base evaluation RECORDS what flows through every stop_gradient call and the perturbed evaluations REPLAY those
+#      values in call order. ----
+LOSS_DIR_CASES = {
+    # the headline workload's model, warp off (only the two MSE terms)
+    'nowarp': dict(spec=dict(num_coarse_samples=64, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=True),
+                   B=12, alpha=0.0, bg=0, eps=1e-6),
+    # SE3 warp + camera code + background regulariser (training.py:117-135); no elastic term here: its Jacobian is a central
+    # difference under the shim and a difference of differences is noise
+    'warp_bg': dict(spec=dict(num_coarse_samples=24, num_fine_samples=24, num_nerf_point_freqs=6, use_stratified_sampling=True, use_warp=True,
+                              num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True), B=8, alpha=3.25, bg=9, eps=1e-7),
+}
+# eps: the warped points enter a posenc of 2^(F_p-1) x their value, so the loss curves ~30x faster along a direction that moves the
+# warp field: the central difference's truncation error is 1e-3 of the slope at eps = 1e-6 and 1e-6 of it at 1e-7 (measured at
+# 1e-5 / 1e-6 / 1e-7: the values converge quadratically), while float64 cancellation at 1e-7 is still ~1e-9
+LOSS_DIR_NDIR = 8
+
+
+def loss_directions(params_np, seed, ndir=LOSS_DIR_NDIR):
+  """The seeded parameter directions (shared with the tests): per direction one standard-normal array per leaf, leaves in
+  sorted path order, each scaled by the leaf's rms (so eps * v is a RELATIVE perturbation of every leaf)."""
+  leaves = []
+
+  def walk(t, path):
+    for k in sorted(t):
+      (walk(t[k], path + (k,)) if isinstance(t[k], dict) else leaves.append((path + (k,), np.asarray(t[k]))))
+  walk(params_np, ())
+  rng = np.random.default_rng(seed)
+  dirs = []
+  for _ in range(ndir):
+    d = {}
+    for path, a in leaves:
+      d[path] = rng.standard_normal(a.shape) * (np.sqrt(np.mean(a * a)) + 1e-3)
+    dirs.append(d)
+  return dirs
+
+
+def _tree_axpy(t, d, c, path=()):
+  return {k: (_tree_axpy(v, d, c, path + (k,)) if isinstance(v, dict) else np.asarray(v) + c * d[path + (k,)]) for k, v in t.items()}
+
+
+def loss_directional():
+  import types
+  import jax
+  from jax import lax as jlax
+  for name, case in LOSS_DIR_CASES.items():
+    spec = O.ModelSpec(**case['spec'])
+    B, nbg, alpha = case['B'], case['bg'], case['alpha']
+    seed = 700 + sum(ord(c) for c in name)
+    params = tree_np(O.init_params(spec, seed=seed, trained_like=True))
+    batch = O.synthetic_batch(B, seed=seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    t_rand = rng.uniform(0, 1, (B, spec.num_coarse_samples)).astype(np.float32).astype(np.float64)
+    u = rng.uniform(0, 1, (B, spec.num_fine_samples)).astype(np.float32).astype(np.float64)
+    rb = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(), 'rgb': batch['rgb'].numpy(),
+          'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}}
+    eps = case['eps']
+    out = dict(t_rand=t_rand.astype(np.float32), u=u.astype(np.float32), alpha=alpha, seed=seed, num_rays=B, eps=eps)
+    keys = [jrandom.Key(), jrandom.Key(uniform=u), jrandom.Key(uniform=t_rand), jrandom.Key()]
+    if nbg:
+      bg_pts = rng.uniform(-0.4, 0.4, (nbg, 3)).astype(np.float32).astype(np.float64)
+      bg_ids = rng.integers(0, 4, (nbg, 1)); bg_noise = rng.normal(size=(nbg, 3)).astype(np.float32).astype(np.float64)
+      rb['background_points'] = bg_pts
+      keys[3] = jrandom.Key(normal=bg_noise, choice=bg_ids)
+      out.update(bg_points=bg_pts.astype(np.float32), bg_ids=bg_ids, bg_noise=bg_noise.astype(np.float32), background_loss_weight=1.5)
+    sp = ref_training.ScalarParams(learning_rate=1e-3, background_loss_weight=1.5, background_noise_std=0.001)
+    model = build_ref_model(spec)
+
+    class Opt:
+      target = {'model': params}
+
+      def apply_gradient(self, grad, learning_rate):
+        return self
+    state = types.SimpleNamespace(optimizer=Opt(), warp_extra={'alpha': alpha, 'time_alpha': 0.0}, replace=lambda **kw: None)
+    bundle = jrandom.Key()
+    bundle.parts = keys
+    captured = []
+    split0, vag0, sg0 = jrandom.split, jax.value_and_grad, jlax.stop_gradient
+    jrandom.split = lambda key, num=2: key.parts if hasattr(key, 'parts') and num == 4 else split0(key, num)
+
+    def vag(fn, has_aux=False):
+      captured.append(fn)          # the reference's own _loss_fn closure (training.py:229-262)
+      return lambda p: (fn(p), None)
+    jax.value_and_grad = vag
+    tape = {'mode': 'off', 'vals': [], 'at': 0}
+
+    def stop_gradient(x):
+      if tape['mode'] == 'record':
+        tape['vals'].append(np.array(x, copy=True))
+        return x
+      if tape['mode'] == 'replay':
+        v = tape['vals'][tape['at']]
+        tape['at'] += 1
+        assert np.shape(v) == np.shape(x)
+        return v
+      return x
+    jlax.stop_gradient = stop_gradient
+    try:
+      ref_training.train_step(model, bundle, state, rb, sp, use_elastic_loss=False, use_background_loss=bool(nbg))
+      loss_fn = captured[0]
+      tape['mode'] = 'record'
+      base = loss_fn(state.optimizer.target)
+      base = float(base[0] if isinstance(base, tuple) else base)
+      nstop = len(tape['vals'])
+      tape['mode'] = 'replay'
+      dd = []
+      for d in loss_directions(params, seed + 3):
+        vals = []
+        for sgn in (+1.0, -1.0):
+          tape['at'] = 0
+          r = loss_fn({'model': _tree_axpy(params, d, sgn * eps)})
+          assert tape['at'] == nstop
+          vals.append(float(r[0] if isinstance(r, tuple) else r))
+        dd.append((vals[0] - vals[1]) / (2 * eps))
+    finally:
+      jrandom.split, jax.value_and_grad, jlax.stop_gradient = split0, vag0, sg0
+    out.update(loss=base, directional=np.array(dd), dir_seed=seed + 3, num_stop_gradient_calls=nstop)
+    print(name, 'loss', base, 'stop_gradient calls', nstop, 'directional', np.array(dd))
+    save('loss_directional_' + name, **out)
+
+
 if __name__ == '__main__':
   if len(sys.argv) > 1:   # only the named generators (fixtures of earlier rounds stay byte-identical either way)
     for name in sys.argv[1:]:
@@ -507,3 +669,5 @@ if __name__ == '__main__':
   train_step_stats()
   elastic_types_and_noise()
   nerf_model_r4()
+  nerf_model_baseline_shapes()
+  loss_directional()

@@ -313,3 +313,47 @@ def bf16_stash(model, ws, name, level, nlayers, nblocks, rows, as_float32=False,
 
 def bf16_round(t):
   return t.float().to(torch.bfloat16).double()
+
+
+# ---------------------------------------------------------------------------------------------
+# tests/golden/make_reference_vectors.py::loss_directional -- the seeded parameter directions and the cases, shared by the CPU
+# (oracle autograd vs the reference's finite difference) and the GPU test (HIP gradient vs the same numbers)
+# ---------------------------------------------------------------------------------------------
+LOSS_DIR_CASES = {
+    'nowarp': dict(spec=dict(num_coarse_samples=64, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=True),
+                   B=12, alpha=0.0, bg=0),
+    'warp_bg': dict(spec=dict(num_coarse_samples=24, num_fine_samples=24, num_nerf_point_freqs=6, use_stratified_sampling=True, use_warp=True,
+                              num_warp_freqs=5, num_warp_features=8, use_camera_metadata=True), B=8, alpha=3.25, bg=9),
+}
+
+
+def loss_directions(params, seed, ndir):
+  """[{path tuple: float64 array}] exactly as make_reference_vectors.loss_directions draws them: leaves in sorted path order,
+  standard normals scaled by the leaf's rms + 1e-3."""
+  leaves = []
+
+  def walk(t, path):
+    for k in sorted(t):
+      if isinstance(t[k], dict):
+        walk(t[k], path + (k,))
+      else:
+        leaves.append((path + (k,), np.asarray(t[k].detach().double().numpy() if torch.is_tensor(t[k]) else t[k], dtype=np.float64)))
+  walk(params, ())
+  rng = np.random.default_rng(seed)
+  dirs = []
+  for _ in range(ndir):
+    dirs.append({path: rng.standard_normal(a.shape) * (np.sqrt(np.mean(a * a)) + 1e-3) for path, a in leaves})
+  return dirs
+
+
+def tree_dot(grads, direction, path=()):
+  """<grad tree, direction> in float64."""
+  tot = 0.0
+  for k, v in grads.items():
+    if isinstance(v, dict):
+      tot += tree_dot(v, direction, path + (k,))
+    else:
+      g = v.detach().double().cpu().numpy() if torch.is_tensor(v) else np.asarray(v, dtype=np.float64)
+      tot += float((g * direction[path + (k,)]).sum())
+  return tot
+

@@ -84,12 +84,27 @@ def _worker(rank, port, tmp):
   assert n == WORLD and torch.equal(g2, g) and torch.allclose(st2, st)
   # ---- eval: rank-sliced chunks + all_gather reassemble the full image (evaluation.py:62-99) ----
   rays = {'origins': torch.linspace(-1, 1, 5 * 7 * 3).reshape(5, 7, 3), 'directions': torch.ones(5, 7, 3) * 0.1}
-  img = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=9)   # 35 px: ragged, needs padding
+  # the reference's order: every chunk cut `world` ways, one gather per chunk (evaluation.py:61-92)
+  img = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=9, tile_parallel='chunk')   # 35 px: ragged
   fixed = _FixedChunkFn()   # a graph-replaying renderer: every call must see the same per-rank slice length
-  img_fixed = evaluation.render_image(_State, rays, fixed, device_count=WORLD, chunk=9)
+  img_fixed = evaluation.render_image(_State, rays, fixed, device_count=WORLD, chunk=9, tile_parallel='chunk')
   assert fixed.sizes == {5}, fixed.sizes    # ceil(9 / 2) rays per rank in every chunk, the tail padded up to it
   for k in img:
     assert torch.equal(img[k], img_fixed[k])
+  # the default: every rank renders a contiguous band of WHOLE chunks (35 px = 4 chunks of 9 -> 2 per rank), ONE gather per frame
+  calls = []
+  counting = lambda k0, k1, p, r, e: (calls.append(r['origins'].shape[0]), _fake_model_fn(k0, k1, p, r, e))[1]
+  img_band = evaluation.render_image(_State, rays, counting, device_count=WORLD, chunk=9)
+  assert calls == ([9, 9] if rank == 0 else [9, 8]), calls       # whole chunks, the ragged tail on the last rank
+  fixed = _FixedChunkFn()
+  img_band_fixed = evaluation.render_image(_State, rays, fixed, device_count=WORLD, chunk=9)
+  assert fixed.sizes == {9}, fixed.sizes    # full-size launches only: the tail is edge-padded to the chunk
+  for k in img:
+    assert torch.equal(img[k], img_band[k]) and torch.equal(img[k], img_band_fixed[k]), k
+  # more ranks than chunks: the idle rank still joins the frame's one collective
+  img_one = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=64)
+  for k in img:   # (torch's CPU sigmoid differs by an ulp between a 9-row and a 35-row call: vector body vs scalar tail)
+    assert torch.allclose(img[k], img_one[k], atol=1e-7, rtol=0), k
   # ---- data: every rank takes its own 1/world slice of each global batch (core.py:110-121) ----
   from nerfies_amd import datasets
   n = 50

@@ -97,7 +97,7 @@ def test_bf16_convergence_at_the_config_a_shape():
   em, _ = models.construct_nerf(7, type('E', (Cfg,), {'use_stratified_sampling': False}), 8192, [0], [0], [0], 0.05, 1.0, device=DEV)
   test = {'origins': o[NB * B:], 'directions': d[NB * B:], 'metadata': {}}
   res = {}
-  for mode, key0 in (('f32', 1), ('f32b', 1001), ('bf16', 1)):
+  for mode, key0 in (('f32', 1), ('f32b', 1001), ('bf16', 1), ('bf16b', 1001)):
     model, fp = models.construct_nerf(7, Cfg, B, [0], [0], [0], 0.05, 1.0, device=DEV)
     state = training.TrainState(optimizer=training.Optimizer(fp))
     key, curve = key0, []
@@ -105,24 +105,32 @@ def test_bf16_convergence_at_the_config_a_shape():
       sp = training.ScalarParams(learning_rate=1e-3 * (0.1 ** (k / K)))
       i0 = (k % NB) * B
       batch = {'origins': o[i0:i0 + B], 'directions': d[i0:i0 + B], 'rgb': rgb[i0:i0 + B], 'metadata': {}}
-      state, stats, key = training.train_step(model, key, state, batch, sp, bf16=(mode == 'bf16'))
+      state, stats, key = training.train_step(model, key, state, batch, sp, bf16=mode.startswith('bf16'))
       if (k + 1) % 20 == 0:
         curve.append(stats['fine']['loss/rgb'])
     res[mode] = (_psnr(em.apply({'params': fp}, test, {})['fine']['rgb'], rgb[NB * B:]), torch.stack(curve).cpu().numpy())
-  (pa, ca), (pb, cb), (p16, c16) = res['f32'], res['f32b'], res['bf16']
+  (pa, ca), (pb, cb), (p16, c16), (p16b, _) = res['f32'], res['f32b'], res['bf16'], res['bf16b']
   tail = slice(len(ca) // 2, None)
   gap32 = np.abs(ca[tail] - cb[tail]).max() / ca[tail].mean()
   gap16 = np.abs(c16[tail] - ca[tail]).max() / ca[tail].mean()
-  print(f'[bf16 convergence, config A shape, {K} steps] held-out PSNR fp32 {pa:.3f} / {pb:.3f} dB, bf16 {p16:.3f} dB ({p16 - pa:+.3f}); '
-        f'loss-curve gap over the second half: bf16 vs fp32 {100 * gap16:.1f} %, fp32 vs fp32 {100 * gap32:.1f} %')
+  print(f'[bf16 convergence, config A shape, {K} steps] held-out PSNR fp32 {pa:.3f} / {pb:.3f} dB, bf16 {p16:.3f} / {p16b:.3f} dB '
+        f'(means {0.5 * (p16 + p16b) - 0.5 * (pa + pb):+.3f}); loss-curve gap over the second half: bf16 vs fp32 {100 * gap16:.1f} %, '
+        f'fp32 vs fp32 {100 * gap32:.1f} %')
   assert min(pa, pb) > 30.0
-  # two training runs that differ only in rounding or sampling keys diverge chaotically.  Four seeds per precision on one box
-  # (profiles/r04_bf16_seed_spread.json): fp32 38.39 +- 0.19 dB (38.17 .. 38.67), bf16 38.26 +- 0.13 (round-3 bf16 kernels on the
-  # same seeds: 38.33 +- 0.16) -- the precisions' means differ by less than one standard deviation of either.  Two fp32 runs
-  # cannot estimate that spread, so the gate uses the measured one: the bf16 run within 3 sigma of the fp32 pair's mean (a 2.5 sigma
-  # gate would trip about once in a hundred runs of a suite that the driver runs with -x), where
-  # sigma = 0.19 * sqrt(1 + 1/2) is the spread of (one run - mean of two runs)
-  sigma = 0.19 * np.sqrt(1.5)
-  assert abs(pa - pb) <= 4 * 0.19 * np.sqrt(2.0), (pa, pb)           # the fp32 pair itself is inside the measured spread
-  assert abs(p16 - 0.5 * (pa + pb)) <= 3.0 * sigma, (pa, pb, p16)
+  # Two training runs that differ only in rounding or sampling keys diverge chaotically, so the gate is a statement about MEANS
+  # against the measured seed-to-seed spread, read from the committed record (not hard-coded): profiles/r04_bf16_seed_spread.json,
+  # four seeds per precision at THIS shape and step count: fp32 38.39 +- 0.19 dB, bf16 38.26 +- 0.13.  ONE-SIDED (round 4 accepted
+  # +-0.70 dB around one run: a real 0.5 dB regression passed): the mean of two bf16 runs may sit at most 2.5 sigma_d below the mean
+  # of two fp32 runs, sigma_d = sqrt(s32^2 / 2 + s16^2 / 2) = 0.16 dB -> 0.41 dB (false trip 0.6 %; a 0.5 dB regression is caught
+  # 7 times in 10, a 0.7 dB one 96 in 100).
+  import json
+  import os
+  rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r04_bf16_seed_spread.json')))
+  assert 'config-A shape' in rec['protocol'] and rec['round4_kernels']['steps'] == K, rec['protocol']
+  s32, s16 = rec['round4_kernels']['std']['f32'], rec['round4_kernels']['std']['bf16']
+  assert 0.05 < s32 < 0.5 and 0.05 < s16 < 0.5, (s32, s16)
+  sigma_d = float(np.sqrt(0.5 * s32 ** 2 + 0.5 * s16 ** 2))
+  assert abs(pa - pb) <= 4 * s32 * np.sqrt(2.0), (pa, pb)           # the fp32 pair itself is inside the measured spread
+  assert 0.5 * (p16 + p16b) >= 0.5 * (pa + pb) - 2.5 * sigma_d, (pa, pb, p16, p16b, sigma_d)
+  assert min(p16, p16b) >= 0.5 * (pa + pb) - 4.0 * float(np.sqrt(s16 ** 2 + 0.5 * s32 ** 2)), (pa, pb, p16, p16b)   # no single outlier run
   assert gap16 <= 2.0 * gap32 + 0.05

@@ -177,3 +177,60 @@ def test_two_rank_graphed_step_keeps_replicas_identical_and_equals_eager(tmp_pat
   assert travel > 0.1 * LR * STEPS * np.sqrt(got['flat'].numel())
   assert diff < 3e-2 * travel                       # float32 atomics order only (same bound as the one-rank comparison above)
   np.testing.assert_allclose(got['hist_g'], got['hist_e'], rtol=2e-4, atol=1e-7)
+
+
+# ---------------------------------------------------------------------------------------------
+# eval: frame-tile parallel render_image (BASELINE configs[4] "8-GPU image-tile parallel"; evaluation.py:61-99, eval.py:339)
+# ---------------------------------------------------------------------------------------------
+FRAME_H, FRAME_W, FRAME_CHUNK = 37, 29, 256    # 1073 rays = 4 full chunks + a ragged fifth: 3 chunks on rank 0, 2 on rank 1
+
+
+def _render_frames():
+  import helpers as H
+  from nerfies_amd import evaluation, training
+  spec, p, b, _ = _inputs()
+  model, fp = H.gpu_model(spec, p, FRAME_CHUNK)
+  g = torch.Generator().manual_seed(77)
+  n = FRAME_H * FRAME_W
+  d = torch.randn(n, 3, generator=g)
+  rays = {'origins': (torch.rand(n, 3, generator=g) - 0.5).reshape(FRAME_H, FRAME_W, 3).to(H.DEV),
+          'directions': (d / d.norm(dim=-1, keepdim=True)).reshape(FRAME_H, FRAME_W, 3).to(H.DEV),
+          'metadata': {'warp': torch.full((FRAME_H, FRAME_W, 1), 2, dtype=torch.int32, device=H.DEV),
+                       'camera': torch.full((FRAME_H, FRAME_W, 1), 1, dtype=torch.int32, device=H.DEV)}}
+  state = training.TrainState(optimizer=training.Optimizer(fp), warp_alpha=4.0)
+  out = {}
+  for mode in ('band', 'chunk'):
+    fn = evaluation.GraphedChunkRenderer(model)        # hipGraph replay: fixed-size chunks
+    img = evaluation.render_image(state, rays, fn, chunk=FRAME_CHUNK, tile_parallel=mode)
+    out[mode] = {k: v.cpu() for k, v in img.items()}
+    out[mode + '_captures'] = fn.captures
+  torch.cuda.synchronize()
+  return out
+
+
+def _frame_worker(rank, port, tmp):
+  import torch.distributed as dist
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  torch.cuda.set_device(0)
+  dist.init_process_group('gloo', rank=rank, world_size=WORLD)
+  out = _render_frames()
+  if rank == 1:      # any rank holds the whole frame after the gather (the reference keeps replica 0, evaluation.py:92)
+    torch.save(out, tmp)
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_band_parallel_frame_is_bit_identical_to_the_single_rank_frame(tmp_path):
+  """render_image on two ranks -- a contiguous band of whole chunks per rank and ONE all_gather per frame (default), or the
+  reference's per-chunk split -- against the single-process frame: rows are rendered independently of their position in a
+  launch, so all three frames must agree bit for bit (rgb, depth, med_depth, acc), with the warp field on."""
+  tmp = str(tmp_path / 'frame.pt')
+  mp.spawn(_frame_worker, args=(_free_port(), tmp), nprocs=WORLD, join=True)
+  got = torch.load(tmp, weights_only=False)
+  want = _render_frames()          # no process group in this process: the plain chunk loop
+  assert want['band_captures'] == 1 and got['band_captures'] == 1      # one graph serves the frame (tail padded to the chunk)
+  for mode in ('band', 'chunk'):
+    assert set(got[mode]) == set(want['band']) >= {'rgb', 'depth', 'acc'}
+    for k, v in want['band'].items():
+      assert v.shape[:2] == (FRAME_H, FRAME_W)
+      assert torch.equal(got[mode][k], v), (mode, k, (got[mode][k] - v).abs().max().item())

@@ -410,3 +410,34 @@ def test_elastic_loss_types_and_noise_regularize():
   close(torch.cat([raw[..., :3], O.noise_regularize(raw[..., 3:4], 0.4, True, nz)], -1), r['noised_strat'], 1e-15)
   close(torch.cat([raw[..., :3], O.noise_regularize(raw[..., 3:4], 0.4, False, nz)], -1), r['noised_det'], 0)
   close(torch.cat([raw[..., :3], O.noise_regularize(raw[..., 3:4], None, True, nz)], -1), r['noised_none'], 0)
+
+
+@pytest.mark.parametrize('name', ['nowarp', 'warp_bg'])
+def test_oracle_gradient_against_the_reference_side_directional_derivative(name):
+  """The one reference-side GRADIENT evidence the NumPy shim allows (jax.value_and_grad cannot run): central differences, in
+  float64, of the reference's own `_loss_fn` closure (training.py:229-262) along 8 seeded parameter directions, with
+  lax.stop_gradient replayed from the base evaluation (model_utils.py:187, training.py:181) so that it means what it means under
+  autodiff (tests/golden/make_reference_vectors.py::loss_directional).  The oracle's torch.autograd gradient -- what every GPU
+  gradient test is measured against -- must reproduce <grad, v> for every direction."""
+  import sys
+  sys.path.insert(0, HERE)
+  import helpers as H
+  r = ref('loss_directional_' + name)
+  case = H.LOSS_DIR_CASES[name]
+  spec = O.ModelSpec(**case['spec'])
+  seed, B = int(r['seed']), int(r['num_rays'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(B, seed=seed + 1)
+  kw = dict(warp_alpha=float(r['alpha']), t_rand=T(r['t_rand']), u=T(r['u']))
+  if case['bg']:
+    kw.update(use_background_loss=True, background_loss_weight=float(r['background_loss_weight']),
+              background={'points': T(r['bg_points']), 'warp_ids': torch.tensor(r['bg_ids']), 'noise': T(r['bg_noise']) * 0.001})
+  loss, _, grads, _ = O.loss_and_grad(params, spec, batch, **kw)
+  close(loss, r['loss'], 1e-9)
+  dirs = H.loss_directions(params, int(r['dir_seed']), len(r['directional']))
+  got = np.array([H.tree_dot(grads, d) for d in dirs])
+  want = r['directional']
+  # the reference side is a central difference (eps per case, see the generator): truncation + cancellation ~1e-6 of |f'|
+  np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-7, err_msg=name)
+  assert np.abs(want).min() > 1e-4      # every direction has a real slope: not a comparison of zeros
+

@@ -502,7 +502,10 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
                  int64_t bias_dst; int bias_cols;                     // bias leaf <- column sums [0:bias_cols], or -1
                  int64_t bias2_dst; int bias2_col0;                   // a second bias leaf (alpha: column 3; SE3 v head: columns 3..5), or -1
                  int bias2_cols = 1; int accu = 0; int ngroups = 0;   // reduce pass the leaf is added in; groups (0: the MLP level's)
-                 int64_t dst2 = -1; int col20 = 0; };                 // a second weight leaf from the same slab (SE3 v head), or -1
+                 int64_t dst2 = -1; int col20 = 0;                    // a second weight leaf from the same slab (SE3 v head), or -1
+                 int dst2_ld = 0, dst2_cols = 0;                      // ... of its own width (0: as the first leaf)
+                 // an operand assembled from two stash buffers (WgradGroup x2_off / dy2_off): the last Kb2 / Nb2 blocks
+                 size_t* x2off = nullptr; int Kb2 = 0, x2_blocks = 0; size_t* y2off = nullptr; int Nb2 = 0, y2_blocks = 0; };
   std::vector<BSpec> bspecs;
   if (bft) {
     for (int lv = 0; lv < h->nlevels; ++lv) {
@@ -518,17 +521,31 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         if (l == 0) {
           bpush(&L.b_pe, 0, 2, &L.b_dy, 0, 8, po.trunk_k[0], 256, h->P, 256, 0, po.trunk_b[0], 256);
         } else {
-          bpush(&L.b_h, (size_t)(l - 1) * layer, 8, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256, 256, 0, po.trunk_b[l], 256);
-          if (l == d.nerf_skip_layer)
-            bpush(&L.b_pe, 0, 2, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l] + 256 * 256, 256, h->P, 256, 0, -1, 0);
+          if (l == d.nerf_skip_layer) {
+            // the skip layer's kernel is [256 + P, 256]: rows 0..255 multiply h4, rows 256.. the posenc (modules.py:47-48).  ONE group,
+            // X = [h4 (8 blocks) | posenc (2 blocks)] against dpre_4, so dpre_4 is streamed once (rounds 2-4: two groups, twice)
+            bpush(&L.b_h, (size_t)(l - 1) * layer, 10, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256 + h->P, 256, 0, po.trunk_b[l], 256);
+            bspecs.back().x2off = &L.b_pe; bspecs.back().Kb2 = 2; bspecs.back().x2_blocks = 2;
+          } else {
+            bpush(&L.b_h, (size_t)(l - 1) * layer, 8, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256, 256, 0, po.trunk_b[l], 256);
+          }
         }
       }
-      bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dbn, 0, 8, po.bn_k, 256, 256, 256, 0, po.bn_b, 256);
+      if (h->A > 0) {
+        bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dbn, 0, 8, po.bn_k, 256, 256, 256, 0, po.bn_b, 256);
+      } else {
+        // the bottleneck AND the alpha head read h8 (modules.py:149-157): ONE group, dY = [d bottleneck (8 blocks) | d raw (block 0 of
+        // the small stash)], h8 streamed once; slab column 256 + 3 (d raw sigma) is the alpha kernel's gradient
+        bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dbn, 0, 9, po.bn_k, 256, 256, 256, 0, po.bn_b, 256);
+        BSpec& m = bspecs.back();
+        m.y2off = &L.b_dsmall; m.Nb2 = 1; m.y2_blocks = 2;
+        m.dst2 = po.alpha_k; m.col20 = 256 + 3; m.dst2_ld = 1; m.dst2_cols = 1;
+      }
       bpush(&L.b_bn, 0, 8, &L.b_drgbh, 0, 4, po.rgbh_k, 128, 256, 128, 0, po.rgbh_b, 128);
       // narrow heads against the "small" dY block: columns 0..2 = d rgb logits (X = rgb hidden), column 3 = d raw sigma (X = h8)
       bpush(&L.b_rgbh, 0, 4, &L.b_dsmall, 0, 2, po.logit_k, 3, 128, 3, 0, po.logit_b, 3, po.alpha_b, 3);
       if (h->A > 0) bpush(&L.b_bn, 0, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);   // use_alpha_condition: X = the bottleneck
-      else bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);
+      // (otherwise the alpha head rides in the bottleneck's group above)
     }
   }
   // bf16 SE3 trunk: every pass through the field (coarse / fine samples, background points, the 3 tangents per coarse sample)
@@ -1018,8 +1035,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       const BSpec& sp = bspecs[i];
       WgradGroup g;
       memset(&g, 0, sizeof(g));
-      g.x_off = (int64_t)(*sp.xoff + sp.xadd); g.x_tile_stride = sp.Kb * BF_BLOCK_DW; g.Kb = sp.Kb; g.x_kvalid = sp.rows;
-      g.dy_off = (int64_t)(*sp.yoff + sp.yadd); g.dy_tile_stride = sp.Nb * BF_BLOCK_DW; g.Nb = sp.Nb;
+      g.x_off = (int64_t)(*sp.xoff + sp.xadd); g.x_tile_stride = (sp.Kb - sp.Kb2) * BF_BLOCK_DW; g.Kb = sp.Kb; g.x_kvalid = sp.rows;
+      g.dy_off = (int64_t)(*sp.yoff + sp.yadd); g.dy_tile_stride = (sp.Nb - sp.Nb2) * BF_BLOCK_DW; g.Nb = sp.Nb;
+      g.Kb1 = sp.Kb - sp.Kb2; g.Nb1 = sp.Nb - sp.Nb2;
+      g.x2_off = sp.x2off ? (int64_t)*sp.x2off : g.x_off; g.x2_tile_stride = sp.x2off ? sp.x2_blocks * BF_BLOCK_DW : 0;
+      g.dy2_off = sp.y2off ? (int64_t)*sp.y2off : g.dy_off; g.dy2_tile_stride = sp.y2off ? sp.y2_blocks * BF_BLOCK_DW : 0;
       g.ntiles = sp.ngroups ? sp.ngroups : p.L[sp.lv].b_ngroups; g.nsplit = bnsplit[i]; g.vec_off = -1; g.vec2_off = -1;
       g.slab_off = (int64_t)take((size_t)g.nsplit * sp.Kb * 32 * sp.Nb * 32);
       g.vslab_off = sp.bias_dst >= 0 ? (int64_t)take((size_t)g.nsplit * sp.Nb * 32) : -1;
@@ -1036,6 +1056,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       if (sp.dst2 >= 0) {   // a second leaf out of the same slab (column window col20)
         ReduceDesc r2 = r;
         r2.dst_off = sp.dst2; r2.src_off = g.slab_off + sp.col20;
+        if (sp.dst2_cols > 0) { r2.dst_ld = sp.dst2_ld; r2.cols = sp.dst2_cols; }
         rpush(r2);
       }
       auto bias = [&](int64_t dst, int cols, int col0) {

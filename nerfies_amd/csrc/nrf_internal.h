@@ -348,6 +348,11 @@ struct WgradGroup {
   int x_kind, x_tile_stride, x_kvalid, Kb;
   int dy_kind, dy_tile_stride, Nb;
   int ntiles, nsplit, tiles_per, first_task;
+  // bf16 kernel only: an operand assembled from TWO stash buffers, so that a buffer two weight matrices share is streamed once
+  // (X = [h4 | posenc] against dpre_4; dY = [d bottleneck | d raw] against h8).  Blocks [0, Kb1) of X come from x_off, blocks
+  // [Kb1, Kb) from x2_off (x2_tile_stride dwords per group); likewise Nb1 / dy2_off.  Kb1 == Kb, Nb1 == Nb: one source each.
+  int64_t x2_off, dy2_off;
+  int x2_tile_stride, dy2_tile_stride, Kb1, Nb1;
 };
 
 // Stream-K style partition of the wgrad work: workgroup w runs segments [seg_begin[w], seg_begin[w+1]).

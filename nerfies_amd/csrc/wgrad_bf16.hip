@@ -21,6 +21,10 @@
 // group); one workgroup of 8 waves holds a [Kb*32][Nb*32] fp32 partial in registers and flushes it to a slab per segment;
 // reduce_kernel (wgrad.hip) sums the slabs.  Operands arrive through a 128 KiB LDS ring of 4 (8 x 8 blocks) to 10 (narrow groups)
 // chunks, all but one of them in flight, one barrier per chunk.
+// Round 5: an operand may be assembled from two stash buffers (WgradGroup x2_off / dy2_off), so the buffers two weight matrices
+// share are streamed ONCE: the skip layer runs X = [h4 | posenc] (10 blocks) against dpre_4, the bottleneck runs h8 against
+// dY = [d bottleneck | d raw] (9 blocks; column 259 of the slab is the alpha head's kernel gradient) -- rounds 2-4 read dpre_4
+// and h8 twice (1.16 x the algorithmic bytes, profiles/r04_train_bf16_pmc_fetch.md).
 #include "nrf_internal.h"
 #include "lds_dma.h"
 
@@ -34,7 +38,8 @@ typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 namespace {
 
-constexpr int WB_LDS = 128 * 1024;           // operand ring: RING chunks (one 32-sample group each) of (Kb + Nb) x 2 KiB, X then dY
+constexpr int WB_LDS = 144 * 1024;           // operand ring: RING chunks (one 32-sample group each) of (Kb + Nb) x 2 KiB, X then dY;
+                                             // 128 KiB for the one-source shapes, 4 x 34 / 4 x 36 KiB for the two merged ones
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { wait_vmcnt<N>(); }
@@ -61,16 +66,22 @@ __device__ __forceinline__ float frag_sum(const bf16x8& f) {
 // NRB x 2 output blocks per wave; CPW = global_load_lds instructions per wave and chunk (= ceil(2 (Kb + Nb) / 8)); RING =
 // chunks the LDS ring holds (128 KiB / chunk bytes: the BYTES in flight per CU stay the same for narrow groups, whose
 // chunks would otherwise be latency-bound: 2.2 us per chunk whatever its size)
-template <int NRB, int CPW, int RING>
+template <int NRB, int NCB, int CPW, int RING>
 __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const WgradSegment& sg, float* ws, char* lds, int kb0, int nb0,
                                                 bool active) {
-  const int tid = threadIdx.x, lane = tid & 63;
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));   // per-lane constants of the seven instantiations are computed per segment, not all at kernel entry
+                                  // (hoisted, 74 of them were spilled there and reloaded behind every segment's loop)
+  const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int Kb = G.Kb, Nb = G.Nb;
   const int npieces = 2 * (Kb + Nb);          // 1 KiB pieces per chunk: (operand, block, half of the samples)
   const int chunk_bytes = (Kb + Nb) * 2048;
   const char* xbase = reinterpret_cast<const char*>(ws + G.x_off);
   const char* ybase = reinterpret_cast<const char*>(ws + G.dy_off);
+  const char* x2base = reinterpret_cast<const char*>(ws + G.x2_off);     // second source of X / dY blocks (== the first when unused)
+  const char* y2base = reinterpret_cast<const char*>(ws + G.dy2_off);
+  const int Kb1 = G.Kb1, Nb1 = G.Nb1;
   // source granule of LDS slot `lane` of a 1 KiB piece (16 samples): n = n0 + 4 (lane >> 4) + (lane & 3), h = (lane >> 3) & 1,
   // jp = (lane >> 2) & 1; stash granule (n, h, jp) of a block sits at jp * 1024 + (n + 32 h) * 16
   const int src_lane = ((lane >> 2) & 1) * 1024 + (4 * (lane >> 4) + (lane & 3) + 32 * ((lane >> 3) & 1)) * 16;
@@ -82,6 +93,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
     const unsigned buf = lds_b + (unsigned)((ci % RING) * chunk_bytes);
     const char* xt = xbase + (size_t)t * G.x_tile_stride * 4;
     const char* yt = ybase + (size_t)t * G.dy_tile_stride * 4;
+    const char* x2t = x2base + (size_t)t * G.x2_tile_stride * 4;
+    const char* y2t = y2base + (size_t)t * G.dy2_tile_stride * 4;
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
       int p = wave + 8 * i;
@@ -89,19 +102,22 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
       const int isy = p >= 2 * Kb;
       const int pp = isy ? p - 2 * Kb : p;
       const int b = pp >> 1, half = pp & 1;
-      const char* src = (isy ? yt : xt) + b * 2048 + half * 256 + src_lane;   // half: samples 16..31 = 16 lanes x 16 B further
+      const char* blk = isy ? (b < Nb1 ? yt + b * 2048 : y2t + (b - Nb1) * 2048) : (b < Kb1 ? xt + b * 2048 : x2t + (b - Kb1) * 2048);
+      const char* src = blk + half * 256 + src_lane;   // half: samples 16..31 = 16 lanes x 16 B further
       lds_dma16<true>(src, buf + (unsigned)((isy ? Kb * 2048 : 0) + b * 2048 + half * 1024));
     }
   };
 
-  f32x16 acc[NRB][2];
+  f32x16 acc[NRB][NCB];
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rb][cb][r] = 0.f;
-  float bsum[2] = {0.f, 0.f};
+  float bsum[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) bsum[cb] = 0.f;
   const bool want_bias = G.vslab_off >= 0 && kb0 == 0 && active;
 
   // transposing-read base of this lane inside a block image: group (mhalf, kg) of 16 lanes, lane (r, q) in it
@@ -120,18 +136,23 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
     if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
     if (active) {
       const char* buf = lds + (ci % RING) * chunk_bytes + frag_lane;
-#pragma unroll
+      // 10 accumulator blocks per wave (the two merged shapes): the two k-steps stay a loop, so that only one k-step's operand
+      // fragments are live next to the 160 accumulator registers (unrolled, hipcc hoists both steps' reads and spills 117 VGPRs)
+#pragma unroll(NRB * NCB >= 9 ? 1 : 2)
       for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 a[NRB], b[2];
+        bf16x8 a[NRB], b[NCB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) a[rb] = read_frag(buf + (kb0 + rb) * 2048, ks);
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) b[cb] = read_frag(buf + (Kb + nb0 + cb) * 2048, ks);
-        if (want_bias) { bsum[0] += frag_sum(b[0]); bsum[1] += frag_sum(b[1]); }
+        for (int cb = 0; cb < NCB; ++cb) b[cb] = read_frag(buf + (Kb + nb0 + cb) * 2048, ks);
+        if (want_bias) {
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) bsum[cb] += frag_sum(b[cb]);
+        }
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
+          for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
       }
     }
   }
@@ -142,7 +163,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
 #pragma unroll
   for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
         const int k = 32 * (kb0 + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
@@ -151,7 +172,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
   if (want_bias) {   // lanes (n, kg = 0 / 1) hold different samples of column n
     float* bs = ws + G.vslab_off + (size_t)sg.slab_idx * ld;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
       const float t = bsum[cb] + __shfl_xor(bsum[cb], 32);
       if (h == 0) bs[32 * (nb0 + cb) + j] = t;
     }
@@ -168,7 +189,13 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const WgradGroup* __res
   for (int si = s0; si < s1; ++si) {
     const WgradSegment sg = segs[si];
     const WgradGroup G = groups[sg.group];
-    // 8 waves tile the [Kb][Nb] block grid: n-groups of 2 column blocks, the rest along k (as wgrad.hip)
+    // 8 waves tile the [Kb][Nb] block grid: n-groups of NCB column blocks, the rest along k (as wgrad.hip)
+    if (G.Kb == 10 && G.Nb == 8) {          // skip layer, X = [h4 | posenc]: 4 n-groups x 2 k-groups of 5 row blocks; 36 KiB chunks
+      const int wn = wave & 3, wk = wave >> 2;
+      wgrad_bf16_body<5, 2, 5, 4>(G, sg, ws, wb_lds, 5 * wk, 2 * wn, true);
+    } else if (G.Kb == 8 && G.Nb == 9) {    // bottleneck + alpha head, dY = [d bottleneck | d raw]: a wave = one row block x all 9; 34 KiB
+      wgrad_bf16_body<1, 9, 5, 4>(G, sg, ws, wb_lds, wave, 0, true);
+    } else {
     const int ngn = G.Nb / 2;            // 1, 2 or 4
     const int ngk = 8 / ngn;             // 8, 4 or 2
     const int wn = wave % ngn, wk = wave / ngn;
@@ -176,11 +203,12 @@ __global__ __launch_bounds__(512) void wgrad_bf16_kernel(const WgradGroup* __res
     const int kb0 = wk * nrb, nb0 = 2 * wn;
     const bool active = kb0 < G.Kb;
     const int cpw = (2 * (G.Kb + G.Nb) + 7) / 8;   // 4, 3 or 2
-    if (nrb == 4)                  wgrad_bf16_body<4, 4, 4>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 8 blocks: 32 KiB chunks
-    else if (nrb == 2)             wgrad_bf16_body<2, 3, 5>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 4: 24 KiB
-    else if (cpw == 3)             wgrad_bf16_body<1, 3, 6>(G, sg, ws, wb_lds, kb0, nb0, active);    // 2 x 8, 8 x 2: 20 KiB
-    else if (G.Kb + G.Nb > 6)      wgrad_bf16_body<1, 2, 8>(G, sg, ws, wb_lds, kb0, nb0, active);    // 4 x 4 (SE3 trunk): 16 KiB
-    else                           wgrad_bf16_body<1, 2, 10>(G, sg, ws, wb_lds, kb0, nb0, active);   // 4 x 2, 2 x 4: 12 KiB
+    if (nrb == 4)                  wgrad_bf16_body<4, 2, 4, 4>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 8 blocks: 32 KiB chunks
+    else if (nrb == 2)             wgrad_bf16_body<2, 2, 3, 5>(G, sg, ws, wb_lds, kb0, nb0, active);    // 8 x 4: 24 KiB
+    else if (cpw == 3)             wgrad_bf16_body<1, 2, 3, 6>(G, sg, ws, wb_lds, kb0, nb0, active);    // 2 x 8, 8 x 2: 20 KiB
+    else if (G.Kb + G.Nb > 6)      wgrad_bf16_body<1, 2, 2, 8>(G, sg, ws, wb_lds, kb0, nb0, active);    // 4 x 4 (SE3 trunk): 16 KiB
+    else                           wgrad_bf16_body<1, 2, 2, 10>(G, sg, ws, wb_lds, kb0, nb0, active);   // 4 x 2, 2 x 4: 12 KiB
+    }
     __syncthreads();   // the next segment restages LDS
   }
 }

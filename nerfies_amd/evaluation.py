@@ -95,6 +95,19 @@ def _check_same_tree(dst, src, path='rays'):
     raise L.NrfError(f'GraphedChunkRenderer: {path} is {tuple(src.shape)} {src.dtype}, the captured chunk had {tuple(dst.shape)} {dst.dtype}')
 
 
+def _all_gather_rows(gathered, packed):
+  """dist.all_gather_into_tensor of a rank's packed rows.  RCCL (backend 'nccl') is a stream operation and takes the device
+  buffers as they are.  gloo -- the transport of the tests that put several ranks on ONE GPU -- is a host collective: staged
+  through host tensors explicitly (the device-to-host copy is the synchronisation point), so that it never reads a device buffer
+  the stream has not finished writing."""
+  if packed.is_cuda and dist.get_backend() != 'nccl':
+    host = torch.empty(gathered.shape, dtype=gathered.dtype)
+    dist.all_gather_into_tensor(host, packed.cpu())
+    gathered.copy_(host)
+  else:
+    dist.all_gather_into_tensor(gathered, packed)
+
+
 def _pack(ret, rows):
   """Every output key of a rendered chunk side by side in one (rows, sum of widths) float32 buffer: one collective carries all."""
   keys = list(ret.keys())
@@ -166,7 +179,7 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
     if band is None:
       band = torch.zeros(band_rows, sum(widths), dtype=torch.float32, device=flat['origins'].device)
     gathered = torch.empty(world * band_rows, band.shape[1], dtype=band.dtype, device=band.device)
-    dist.all_gather_into_tensor(gathered, band)     # ONE collective per frame
+    _all_gather_rows(gathered, band)     # ONE collective per frame
     split = torch.split(gathered[:num_rays], widths, 1)
     return {k: split[i].reshape(h, w, *shapes[i]).to(dtypes[i]) for i, k in enumerate(keys)}
 
@@ -182,7 +195,7 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
       keys, cols, widths = _pack(ret, per)
       packed = torch.cat(cols, 1).contiguous()
       gathered = torch.empty(world * per, packed.shape[1], dtype=packed.dtype, device=packed.device)
-      dist.all_gather_into_tensor(gathered, packed)
+      _all_gather_rows(gathered, packed)
       split = torch.split(gathered, widths, 1)
       ret = {k: split[i].reshape(world * per, *ret[k].shape[1:]).to(ret[k].dtype) for i, k in enumerate(keys)}
     if frame is None:

@@ -33,7 +33,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, int b
 }
 // Cache policy of the stash / dY stores (aux immediate of the buffer store: 1 = sc0, 2 = nt, 16 = sc1).  The stash is
 // written once and next read by another kernel after > 1 GB of other traffic, so it is stored non-temporal: the lines
-// do not displace the packed weights every workgroup re-reads from L2 (scripts/exp_stash_policy.sh, config A: 135.6 ->
+// do not displace the packed weights every workgroup re-reads from L2 (round-2 experiment, config A: 135.6 ->
 // 137.9 k rays/s; with nt on the wgrad operand copies as well 138.6; write-through sc0 sc1: no change).
 #ifndef NRF_STASH_AUX
 #define NRF_STASH_AUX 2

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // per workgroup: every launch streams its code through a cold instruction cache (SQC_ICACHE_MISSES_DUPLICATE = 12 % of the
     // fetches, profiles/r04_train_bf16_pmc_icache.md; the 1-iteration coarse launch takes 80-120 us against 53 us per iteration in
     // steady state).  A third less code: coarse forward -13 %, dgrad -3 %.  INFERENCE (16+ iterations per workgroup, 0.9 % duplicate
-    // misses) keeps the unrolled form: rolled, hipcc spills 46 VGPRs there and the forward is 8 % slower (scripts/r4/gpu_l.sh).
+    // misses) keeps the unrolled form: rolled, hipcc spills 46 VGPRs there and the forward is 8 % slower (round-4 experiment, git history).
     if constexpr (STASH) {
 #pragma unroll 1
     for (int t = 0; t < 2; ++t) {

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
   const int PK = A.PK;
   const int PKS = (PK + 31) / 32 * 32;   // features per posenc stash tile (whole 32-feature blocks)
   const int nq_pe = PK / 16;
-  // in-kernel timeline (scripts/exp_timeline.py): compiled in only with -DNRF_TIMELINE_BUILD -- its counters and clock values
+  // in-kernel timeline (scripts/timeline_mlp.py): compiled in only with -DNRF_TIMELINE_BUILD -- its counters and clock values
   // are live across the whole kernel, in a kernel that is out of registers
 #ifdef NRF_TIMELINE_BUILD
   int stamp_i = 0;

@@ -110,7 +110,8 @@ struct WsPlan {
   int elastic = 0;       // plan built with the elastic regulariser's buffers
   bool bwd32 = false;    // training plan: the fp32 NeRF reverse chain runs on 32-row tiles (mlp_chain32.hip); decides the
                          // number of bias partials the reduce table sums
-  int chain_rows_opt = 0;   // the handle's option the plan was built under
+  int chain_rows_opt = 0;   // the handle's options the plan was built under
+  int bf16_wgrad_merge = 0;
   int tg_tiles_per = 0;  // primal tiles one tangent pass covers (elastic: coarse level; Jacobian output: the larger level)
   int bgN = 0;           // number of background points the plan was built for
   size_t total_floats;
@@ -203,6 +204,7 @@ struct nrf_handle_s {
   int num_cus = 256;
   bool cu_queried = false;
   int chain_rows_opt = 0;   // NRF_OPT_CHAIN_TILE_ROWS: 0 automatic, 32, 64
+  int bf16_wgrad_merge = 0; // NRF_OPT_BF16_WGRAD_MERGE: 1 = skip-layer / bottleneck+alpha groups of the bf16 wgrad merged (operands streamed once)
   WsPlan plan;
   // identity of the tables last uploaded to a workspace, and of the last stashed forward
   void* uploaded_ws = nullptr;
@@ -427,7 +429,8 @@ bool chain32_for(const nrf_handle_s* h, int ntiles, bool reverse = false) {
 void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 0) {
   WsPlan& p = h->plan;
   flags = plan_flags(flags);
-  if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic && p.chain_rows_opt == h->chain_rows_opt) return;
+  if (p.B == B && p.flags == flags && p.bgN == bgN && p.elastic == elastic && p.chain_rows_opt == h->chain_rows_opt &&
+      p.bf16_wgrad_merge == h->bf16_wgrad_merge) return;
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
   const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
@@ -443,6 +446,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   p.bfw = bfw;
   p.elastic = elastic;
   p.chain_rows_opt = h->chain_rows_opt;
+  p.bf16_wgrad_merge = h->bf16_wgrad_merge;
   p.S[0] = d.num_coarse_samples;
   p.S[1] = d.num_coarse_samples + d.num_fine_samples;
   p.S[BG] = 1;
@@ -521,17 +525,20 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
         if (l == 0) {
           bpush(&L.b_pe, 0, 2, &L.b_dy, 0, 8, po.trunk_k[0], 256, h->P, 256, 0, po.trunk_b[0], 256);
         } else {
-          if (l == d.nerf_skip_layer) {
-            // the skip layer's kernel is [256 + P, 256]: rows 0..255 multiply h4, rows 256.. the posenc (modules.py:47-48).  ONE group,
+          if (l == d.nerf_skip_layer && h->bf16_wgrad_merge) {
+            // (NRF_OPT_BF16_WGRAD_MERGE) the skip layer's kernel is [256 + P, 256]: rows 0..255 multiply h4, rows 256.. the posenc (modules.py:47-48).  ONE group,
             // X = [h4 (8 blocks) | posenc (2 blocks)] against dpre_4, so dpre_4 is streamed once (rounds 2-4: two groups, twice)
             bpush(&L.b_h, (size_t)(l - 1) * layer, 10, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256 + h->P, 256, 0, po.trunk_b[l], 256);
             bspecs.back().x2off = &L.b_pe; bspecs.back().Kb2 = 2; bspecs.back().x2_blocks = 2;
           } else {
             bpush(&L.b_h, (size_t)(l - 1) * layer, 8, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256, 256, 0, po.trunk_b[l], 256);
+            if (l == d.nerf_skip_layer)   // default: the posenc rows of the skip layer as a group of their own (dpre_4 read twice)
+              bpush(&L.b_pe, 0, 2, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l] + 256 * 256, 256, h->P, 256, 0, -1, 0);
           }
         }
       }
-      if (h->A > 0) {
+      const bool merge_alpha = h->bf16_wgrad_merge && h->A == 0;
+      if (!merge_alpha) {
         bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dbn, 0, 8, po.bn_k, 256, 256, 256, 0, po.bn_b, 256);
       } else {
         // the bottleneck AND the alpha head read h8 (modules.py:149-157): ONE group, dY = [d bottleneck (8 blocks) | d raw (block 0 of
@@ -545,7 +552,8 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
       // narrow heads against the "small" dY block: columns 0..2 = d rgb logits (X = rgb hidden), column 3 = d raw sigma (X = h8)
       bpush(&L.b_rgbh, 0, 4, &L.b_dsmall, 0, 2, po.logit_k, 3, 128, 3, 0, po.logit_b, 3, po.alpha_b, 3);
       if (h->A > 0) bpush(&L.b_bn, 0, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);   // use_alpha_condition: X = the bottleneck
-      // (otherwise the alpha head rides in the bottleneck's group above)
+      else if (!merge_alpha) bpush(&L.b_h, (size_t)7 * layer, 8, &L.b_dsmall, 0, 2, po.alpha_k, 1, 256, 1, 3, -1, 0);
+      // (merged: the alpha head rides in the bottleneck's group above)
     }
   }
   // bf16 SE3 trunk: every pass through the field (coarse / fine samples, background points, the 3 tangents per coarse sample)
@@ -682,11 +690,15 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   // ---- the same stream-K cut for the bf16 groups: HBM-bound, cost = blocks streamed per 32-sample group ----
   std::vector<int> bnsplit(bspecs.size(), 0);
   if (!bspecs.empty()) {
-    // measured on config A (scripts/exp_bf16_cost.sh): a chunk costs (Kb + Nb) + 12 block units -- the per-chunk barrier and
+    // measured on config A (round-2 experiment, git history): a chunk costs (Kb + Nb) + 12 block units -- the per-chunk barrier and
     // HBM latency are worth 24 KiB of streaming -- : wgrad 0.87 ms with a pure byte model, 0.61 ms with this one
     const double bc_seg = env_cost("NRF_BCOST_SEG", 16.0);   // opening a segment (pipeline fill + 256 KiB slab flush), in block units
     const double bc_chunk = env_cost("NRF_BCOST_CHUNK", 12.0);   // per-chunk fixed cost (barrier + issue), in block units
-    auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb) + bc_chunk; };
+    // the two merged shapes (10 x 8, 8 x 9: ten accumulator blocks per wave, five copies per wave and chunk) cost more per chunk
+    // than their bytes: round 5, first run with a byte-proportional cost: wgrad_bf16 0.51 -> 0.61 ms although it fetched 10 %
+    // less -- the workgroups inside the merged groups ran ~1.35 x their quota
+    const double bc_merged = env_cost("NRF_BCOST_MERGED", 10.0);
+    auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb) + bc_chunk + ((sp.Kb2 || sp.Nb2) ? bc_merged : 0.0); };
     double total = 0;
     auto bng = [&](const BSpec& sp) { return sp.ngroups ? sp.ngroups : p.L[sp.lv].b_ngroups; };
     for (auto& sp : bspecs) total += bcost(sp) * bng(sp);
@@ -1897,9 +1909,25 @@ int nrf_param_layout(nrf_handle h, nrf_tensor_info* out, int32_t* n) {
   return NRF_OK;
 }
 
+// The flag word of nrf_forward / nrf_workspace_bytes*: unknown bits and contradictory combinations are refused up front
+// (they used to pass through: NRF_FLAG_WARP_F32 without NRF_FLAG_BF16 was silently ignored, and TRAIN | WARP_JACOBIAN sized a
+// workspace for a plan no call can run).
+static int check_flags(uint32_t flags) {
+  const uint32_t known = NRF_FLAG_TRAIN | NRF_FLAG_NO_WARP | NRF_FLAG_BF16 | NRF_FLAG_WARP_JACOBIAN | NRF_FLAG_WARP_F32;
+  if (flags & ~known) return fail(NRF_E_UNSUPPORTED, "unknown bits in flags");
+  if ((flags & NRF_FLAG_WARP_F32) && !(flags & NRF_FLAG_BF16))
+    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_F32 only qualifies NRF_FLAG_BF16 (the float32 mode runs the warp trunk in float32 anyway)");
+  if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_WARP_JACOBIAN))
+    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_JACOBIAN is an inference output (training consumes the Jacobian through nrf_elastic)");
+  if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_NO_WARP))
+    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
+  return NRF_OK;
+}
+
 int nrf_workspace_bytes(nrf_handle h, int32_t num_rays, uint32_t flags, size_t* bytes) {
   if (!h || !bytes) return fail(NRF_E_NULL, "null");
   if (num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
+  CK(check_flags(flags));
   query_device(h);
   build_plan(h, num_rays, flags);
   *bytes = h->plan.total_floats * sizeof(float);
@@ -1910,6 +1938,7 @@ int nrf_forward(nrf_handle h, const float* params, const nrf_rays* rays, const n
                 const nrf_rand* rnd, const nrf_outputs* out, uint32_t flags, void* workspace, size_t workspace_bytes,
                 void* stream) {
   if (!h) return fail(NRF_E_NULL, "handle is null");
+  CK(check_flags(flags));
   return forward_impl(h, params, rays, scalars, rnd, out, flags, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1981,6 +2010,7 @@ int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32
   if (num_rays <= 0 || num_background_points < 0) return fail(NRF_E_SHAPE, "bad sizes");
   if ((num_background_points > 0 || use_elastic_loss) && !h->warp)
     return fail(NRF_E_UNSUPPORTED, "the background / elastic regularisers need the warp field");
+  CK(check_flags(flags));
   query_device(h);
   const bool tr = flags & NRF_FLAG_TRAIN;
   build_plan(h, num_rays, flags, tr ? num_background_points : 0, tr && use_elastic_loss ? 1 : 0);
@@ -2084,6 +2114,15 @@ int nrf_set_option(nrf_handle h, int32_t option, int64_t value) {
       h->chain_rows_opt = (int)value;
       h->stashed_ws = nullptr;   // a stash written under the old plan is not differentiated under the new one
       h->uploaded_ws = nullptr;  // ... and the next call uploads the re-planned tables
+    }
+    return NRF_OK;
+  }
+  if (option == NRF_OPT_BF16_WGRAD_MERGE) {
+    if (value != 0 && value != 1) return fail(NRF_E_UNSUPPORTED, "NRF_OPT_BF16_WGRAD_MERGE: 0 or 1");
+    if (h->bf16_wgrad_merge != (int)value) {
+      h->bf16_wgrad_merge = (int)value;
+      h->stashed_ws = nullptr;
+      h->uploaded_ws = nullptr;
     }
     return NRF_OK;
   }

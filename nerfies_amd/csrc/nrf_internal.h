@@ -380,7 +380,7 @@ struct PackDesc {
 };
 
 // Environment knobs, read ONCE per process (first use), never on a launch path.  The product build honours only the debugging
-// aid NRF_TRACE_REGIONS; the experiment knobs of scripts/exp_*.sh (tile hand-out, grid multipliers, timelines, occupancy print)
+// aid NRF_TRACE_REGIONS; the experiment knobs (tile hand-out, grid multipliers, timelines, occupancy print)
 // exist only in builds compiled with -DNRF_EXPERIMENT (scripts/build_variant.py NAME -DNRF_EXPERIMENT ...).
 struct Knobs {
   bool trace_regions = false;   // NRF_TRACE_REGIONS: name every kernel group on stderr and synchronise behind it

@@ -22,7 +22,7 @@ namespace nrf {
 // small_part layout (floats): db_trunk[6][128] | db_w[3] | db_v[3]
 constexpr int WSP_DB_TRUNK = 0, WSP_DB_W = 768, WSP_DB_V = 771;
 
-// In-kernel timeline (scripts/exp_warp_timeline.py), compiled in only with -DNRF_TIMELINE_BUILD: shader-clock stamps of the
+// In-kernel timeline (scripts/timeline_warp.py), compiled in only with -DNRF_TIMELINE_BUILD: shader-clock stamps of the
 // first tile of workgroup 0, per wave, of the LAST launch of each kernel flavour: [fwd primal, fwd tangent, bwd primal,
 // bwd tangent][wave][stamp].
 #ifdef NRF_TIMELINE_BUILD

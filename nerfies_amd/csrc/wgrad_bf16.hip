@@ -136,16 +136,24 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
     if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
     if (active) {
       const char* buf = lds + (ci % RING) * chunk_bytes + frag_lane;
-      // 10 accumulator blocks per wave (the two merged shapes): the two k-steps stay a loop, so that only one k-step's operand
+      // 10 accumulator blocks per wave (the merged skip-layer shape): the two k-steps stay a loop, so that only one k-step's operand
       // fragments are live next to the 160 accumulator registers (unrolled, hipcc hoists both steps' reads and spills 117 VGPRs)
-#pragma unroll(NRB * NCB >= 9 ? 1 : 2)
+#pragma unroll(NRB * NCB >= 10 ? 1 : 2)
       for (int ks = 0; ks < 2; ++ks) {
         bf16x8 a[NRB], b[NCB];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) a[rb] = read_frag(buf + (kb0 + rb) * 2048, ks);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) b[cb] = read_frag(buf + (Kb + nb0 + cb) * 2048, ks);
-        if (want_bias) {
+        if (NCB == 9) {
+          // a wave = one row block x ALL column blocks: every wave reads every dY fragment, so the column sums are dealt out -- wave w
+          // takes block w, wave 0 block 8 as well -- instead of piling all nine on the wave with kb0 == 0 (a chunk ends at a barrier)
+          if (G.vslab_off >= 0) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              if (cb == wave || (cb == 8 && wave == 0)) bsum[cb] += frag_sum(b[cb]);
+          }
+        } else if (want_bias) {
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) bsum[cb] += frag_sum(b[cb]);
         }
@@ -169,10 +177,11 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
         const int k = 32 * (kb0 + rb) + (reg & 3) + 8 * (reg >> 2) + 4 * h;
         slab[(size_t)k * ld + 32 * (nb0 + cb) + j] = acc[rb][cb][reg];
       }
-  if (want_bias) {   // lanes (n, kg = 0 / 1) hold different samples of column n
+  if (NCB == 9 ? G.vslab_off >= 0 : want_bias) {   // lanes (n, kg = 0 / 1) hold different samples of column n
     float* bs = ws + G.vslab_off + (size_t)sg.slab_idx * ld;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
+      if (NCB == 9 && !(cb == wave || (cb == 8 && wave == 0))) continue;   // the 1 x 9 shape: the wave that summed the block
       const float t = bsum[cb] + __shfl_xor(bsum[cb], 32);
       if (h == 0) bs[32 * (nb0 + cb) + j] = t;
     }

@@ -107,6 +107,7 @@ class ProfileEntry(C.Structure):
 
 
 NRF_OPT_CHAIN_TILE_ROWS = 1
+NRF_OPT_BF16_WGRAD_MERGE = 2
 
 EXPORTS = [
     'nrf_version', 'nrf_last_error', 'nrf_create', 'nrf_destroy', 'nrf_param_count', 'nrf_param_layout',

@@ -193,6 +193,8 @@ class NerfModel:
       rows = os.environ.get('NRF_CHAIN_TILE_ROWS')   # experiments / the A-B tests: 32 or 64 for every model of the process
       if rows:
         self.set_chain_tile_rows(int(rows))
+      if os.environ.get('NRF_BF16_WGRAD_MERGE'):   # experiments / the A-B record: merged bf16 wgrad groups (nerfies_amd.h)
+        L.check(self.lib.nrf_set_option(h, L.NRF_OPT_BF16_WGRAD_MERGE, int(os.environ['NRF_BF16_WGRAD_MERGE'])), self.lib)
     return self._handle
 
   def set_chain_tile_rows(self, rows: int):

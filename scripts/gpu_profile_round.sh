@@ -4,7 +4,7 @@
 # -> gpurun_out/<tag>_*.json|md ; scripts/collect_profiles.py <tag> r04 copies them into profiles/ (and merges the per-workload
 # HBM tables into profiles/hbm_traffic.json).
 # Then scripts/stamp_traffic.py r04 fills `roofline.traffic` of the copied bench lines from the PMC passes of the SAME run (the
-# bench line of a workload is written before its PMC passes exist) and scripts/fill_round_docs.py writes profiles/r04_summary.md.
+# bench line of a workload is written before its PMC passes exist) and scripts/fill_round4_docs.py writes profiles/r04_summary.md.
 # Passes are separate processes: bench line, rocprofv3 kernel trace, three PMC passes (SQ / FETCH_SIZE / WRITE_SIZE never
 # share a pass, never combined with a trace domain).
 TAG=${1:-r04}

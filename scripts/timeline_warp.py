@@ -1,6 +1,6 @@
 """Shader-clock timeline of the first tile of workgroup 0 of the SE3 chain kernels (last launch of each flavour in a step).
 Needs the timeline build:  python scripts/build_variant.py timeline -DNRF_TIMELINE_BUILD
-                           NRF_LIB_PATH=nerfies_amd/_lib/variants/libnerfies_amd_timeline.so python scripts/exp_warp_timeline.py [mode]"""
+                           NRF_LIB_PATH=nerfies_amd/_lib/variants/libnerfies_amd_timeline.so python scripts/timeline_warp.py [mode]"""
 import ctypes as C
 import io
 import os

@@ -301,3 +301,30 @@ def test_bf16_training_reaches_the_fp32_psnr():
   assert l16[-100:].mean() <= 1.05 * max(la[-100:].mean(), lb[-100:].mean())
   for psnr, _ in runs.values():                                  # inference-mode gate: bf16 rendering of given weights costs < 0.1 dB
     assert abs(psnr['bf16'] - psnr['f32']) <= 0.1
+
+
+@pytest.mark.parametrize('kw', [dict(), dict(use_warp=True, num_warp_freqs=4, use_camera_metadata=True)])
+def test_merged_wgrad_groups_give_the_same_gradient(kw):
+  """NRF_OPT_BF16_WGRAD_MERGE (round 5): the skip layer as ONE weight-gradient group (X = [h4 | posenc], ten row blocks) and the
+  bottleneck + alpha head as one (dY = [d bottleneck | d raw], nine column blocks) read the same bf16 stash as the default one
+  group per matrix: every leaf -- in particular trunk/hidden_4's posenc rows and the alpha head's kernel, which come out of other
+  slab windows -- must agree to float32 summation order (other segment boundaries), and the workspace is re-planned."""
+  from nerfies_amd import lib as L
+  spec = O.ModelSpec(num_coarse_samples=24, num_fine_samples=40, num_nerf_point_freqs=8, use_stratified_sampling=False, **kw)
+  oparams = O.init_params(spec, seed=5, trained_like=True, dtype=torch.float32)
+  B = 43
+  batch = H.gpu_batch(O.synthetic_batch(B, seed=6, dtype=torch.float32))
+  grads = []
+  for merge in (0, 1):
+    model, fp = H.gpu_model(spec, oparams, B)
+    L.check(model.lib.nrf_set_option(model.handle, L.NRF_OPT_BF16_WGRAD_MERGE, merge), model.lib)
+    g, st = model.loss_and_grad(fp, batch, warp_extra={'alpha': 2.0}, bf16=True)
+    grads.append((g.clone(), st.clone(), model))
+  (g0, s0, model), (g1, s1, _) = grads
+  assert torch.equal(s0, s1)       # the forward / reverse chains do not depend on the option
+  for name, off, shape in model.layout.entries:
+    n = int(np.prod(shape))
+    x, y = g0[off:off + n], g1[off:off + n]
+    assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item() + 1e-12, (name, (x - y).abs().max().item(), x.abs().max().item())
+  with pytest.raises(L.NrfError):
+    L.check(model.lib.nrf_set_option(model.handle, L.NRF_OPT_BF16_WGRAD_MERGE, 2), model.lib)

@@ -188,7 +188,11 @@ FRAME_H, FRAME_W, FRAME_CHUNK = 37, 29, 256    # 1073 rays = 4 full chunks + a r
 def _render_frames():
   import helpers as H
   from nerfies_amd import evaluation, training
-  spec, p, b, _ = _inputs()
+  from oracle import nerfies_oracle as O
+  # eval renders deterministically (eval.py:239 forces use_stratified_sampling off): with stratified draws a ray's uniforms are
+  # indexed by its position in the launch, and the per-chunk split moves rays to other positions
+  spec = O.ModelSpec(**dict(KW, use_stratified_sampling=False))
+  p = O.init_params(spec, seed=31, trained_like=True)
   model, fp = H.gpu_model(spec, p, FRAME_CHUNK)
   g = torch.Generator().manual_seed(77)
   n = FRAME_H * FRAME_W

@@ -144,3 +144,35 @@ def test_library_background_draw_matches_the_reference_distribution():
   assert abs(noise.mean()) < 5e-4 and abs(noise.std() - 0.01) < 3e-4
   counts = np.array([(i1.cpu().numpy() == v).sum() for v in ids])
   assert counts.sum() == NBG and (np.abs(counts / NBG - 1 / len(ids)) < 0.03).all(), counts
+
+
+def test_graph_replay_in_the_bf16_mode_with_warp_elastic_background():
+  """train.py --graph together with --bf16: GraphedTrainStep(bf16=True) captures and replays the bf16 chain kernels,
+  the bf16 SE3 forward / tangent / reverse kernels (per-launch hipFuncSetAttribute calls included) and the bf16 wgrad.  Three
+  replays with other schedules' values against eager train_step(bf16=True) from the same state: the bf16 kernels are
+  deterministic given their inputs, so the agreement is the float32 paths' atomics order, as in the fp32 test above."""
+  from nerfies_amd import training
+
+  class Cfg:
+    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 32, 32, 6
+    sigma_activation, use_stratified_sampling, use_viewdirs = 'softplus', True, True
+    use_warp, warp_field_type, num_warp_freqs, num_warp_features, use_camera_metadata = True, 'se3', 4, 8, True
+  B, NBG = 96, 256
+  (me, se), (mg, sg) = _pair(Cfg, B)
+  batch = _batch(B, 61, with_meta=True, nbg=NBG)
+  kw = dict(use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
+  sp0 = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, background_loss_weight=1.0)
+  gstep = training.GraphedTrainStep(mg, sg, batch, sp0, bf16=True, **kw)
+  assert torch.equal(sg.optimizer.target.flat, se.optimizer.target.flat) and sg.optimizer.step == 0
+  for k, (alpha, el_w, lr, key) in enumerate([(0.5, 0.01, 1e-3, 3), (2.25, 0.004, 5e-4, 99), (4.0, 1e-5, 1e-4, 12345)]):
+    sp = training.ScalarParams(learning_rate=lr, elastic_loss_weight=el_w, background_loss_weight=1.0)
+    se = se.replace(warp_alpha=alpha)
+    se, st_e, _ = training.train_step(me, key, se, batch, sp, bf16=True, **kw)
+    st_g = gstep(key, scalar_params=sp, warp_alpha=alpha)
+    for a, b in ((st_e['coarse']['loss/total'], st_g['coarse']['loss/total']), (st_e['coarse']['loss/elastic'], st_g['coarse']['loss/elastic']),
+                 (st_e['background_loss'], st_g['background_loss']), (st_e['fine']['loss/rgb'], st_g['fine']['loss/rgb'])):
+      assert abs(a.item() - b.item()) <= 1e-6 + 1e-5 * abs(a.item()), (k, a.item(), b.item())
+    _close(sg.optimizer.grad.cpu(), se.optimizer.grad.cpu(), mg.layout, 2e-4, f'bf16 gradient of step {k}')
+    for dst, src in ((sg.optimizer.target.flat, se.optimizer.target.flat), (sg.optimizer.m, se.optimizer.m), (sg.optimizer.v, se.optimizer.v)):
+      dst.copy_(src)
+  assert sg.optimizer.step == se.optimizer.step == 3

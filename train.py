@@ -26,13 +26,18 @@ def parse_flags(argv=None):
   p.add_argument('--gin_bindings', action='append', default=None, help='Gin parameter bindings.')
   p.add_argument('--gin_configs', action='append', default=[], help='Gin config files.')
   p.add_argument('--max_steps', type=int, default=None, help='stop early (smoke runs); default TrainConfig.max_steps')
-  p.add_argument('--bf16', action='store_true', help='bfloat16 MLP operands (NRF_FLAG_BF16; no reference counterpart): train.py trains '
-                 'with a bfloat16 activation / gradient stash (fp32 master weights, loss, Adam; ~3.5x the fp32 step), eval.py renders '
-                 'with them (~5x faster, ~1e-2 on colour)')
+  p.add_argument('--bf16', nargs='?', const='all', default=None, choices=['all', 'mlp'],
+                 help="bfloat16 MFMA operands (NRF_FLAG_BF16; no reference counterpart; fp32 master weights, posenc, exp_se3, compositing, "
+                      "loss, Adam).  --bf16 / --bf16 all: the NeRF MLPs AND the SE3 warp trunk (BASELINE configs[3]; a warped point moves by "
+                      "~5e-4 of its displacement); --bf16 mlp: the NeRF MLPs only, the warp trunk stays float32 (NRF_FLAG_WARP_F32).  train.py "
+                      "trains with a bfloat16 activation / gradient stash (~6x the fp32 step without the warp), eval.py renders with "
+                      "bfloat16 operands (~1e-2 on colour, < 0.01 dB held-out PSNR)")
   p.add_argument('--graph', action='store_true', help='replay the whole train step (loss + gradient, all-reduce, Adam) from ONE hipGraph '
                  '(training.GraphedTrainStep): the reference jits the step into one XLA executable (train.py:254-262); worth it for small '
                  'per-GPU batches, where the ~25 launches of a step take about as long as the kernels')
-  return p.parse_args(argv)
+  flags = p.parse_args(argv)
+  flags.bf16 = {'all': True, 'mlp': 'mlp', None: False}[flags.bf16]   # the value models / training take (False, True, 'mlp')
+  return flags
 
 
 def init_distributed():

@@ -612,13 +612,14 @@ def main(argv=None):
   ap.add_argument('--warp-f32', action='store_true', help='bf16 modes: keep the SE3 trunk in float32 (NRF_FLAG_WARP_F32; the round-3 behaviour)')
   ap.add_argument('--chain-rows', type=int, default=0, choices=[0, 32, 64],
                   help='rows per workgroup tile of the fp32 NeRF chain kernels (NRF_OPT_CHAIN_TILE_ROWS): 0 = the library\'s automatic choice')
-  ap.add_argument('--bf16-wgrad-merge', action='store_true',
-                  help='bf16 training modes: NRF_OPT_BF16_WGRAD_MERGE = 1 (skip-layer and bottleneck+alpha weight-gradient groups merged: operands streamed once)')
+  ap.add_argument('--bf16-wgrad-merge', type=int, default=None, choices=[0, 1],
+                  help='bf16 training modes: NRF_OPT_BF16_WGRAD_MERGE (1, the library default: skip-layer and bottleneck+alpha weight-gradient '
+                       'groups merged, operands streamed once; 0: one group per weight matrix, as rounds 2-4)')
   ap.add_argument('--frame', action='store_true', help='eval mode: also time evaluation.render_image on a whole 960x540 frame')
   args = ap.parse_args(argv)
 
-  if args.bf16_wgrad_merge:
-    os.environ['NRF_BF16_WGRAD_MERGE'] = '1'
+  if args.bf16_wgrad_merge is not None:
+    os.environ['NRF_BF16_WGRAD_MERGE'] = str(args.bf16_wgrad_merge)
   if args.chain_rows:
     os.environ['NRF_CHAIN_TILE_ROWS'] = str(args.chain_rows)   # read by models.NerfModel when it creates its handle
   if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -719,7 +720,7 @@ def main(argv=None):
         'grad_allreduce_exposed_frac': (r['allreduce_exposed_us'] / (1e3 * ms_per_step)) if r['allreduce_exposed_us'] is not None else None,
         'strong_scaling': strong,
         'oversubscribed': over,
-        'chain_tile_rows': args.chain_rows or 'auto', 'bf16_wgrad_merge': bool(args.bf16_wgrad_merge),
+        'chain_tile_rows': args.chain_rows or 'auto', 'bf16_wgrad_merge': 'default (1)' if args.bf16_wgrad_merge is None else args.bf16_wgrad_merge,
         'csrc_sha16': kernel_source_sha(),
     }
     if over:

@@ -365,11 +365,12 @@ int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* 
  *                            0 = automatic (default).  Results agree to float32 summation order; the workspace layout
  *                            does not depend on it. */
 #define NRF_OPT_CHAIN_TILE_ROWS 1
-/*   NRF_OPT_BF16_WGRAD_MERGE bf16 training mode: 1 = the weight-gradient GEMMs of the skip layer (X = [h4 | posenc]) and of the
- *                            bottleneck + alpha head (dY = [d bottleneck | d raw]) run as ONE group each, so dpre_4 and h8 are
- *                            streamed once (HBM fetch of the kernel 1.16 x -> 1.03 x its algorithmic bytes); 0 (default) = one
- *                            group per weight matrix, which measured faster (profiles/r05_wgrad_bf16_merge_ab.md).  Same results
- *                            to float32 summation order; changes the workspace size (query nrf_workspace_bytes* after setting). */
+/*   NRF_OPT_BF16_WGRAD_MERGE bf16 training mode: 1 (default) = the weight-gradient GEMMs of the skip layer (X = [h4 | posenc]) and of
+ *                            the bottleneck + alpha head (dY = [d bottleneck | d raw]) run as ONE group each, so dpre_4 and h8 are
+ *                            streamed once (HBM fetch of the kernel 1.16 x -> 1.03 x its algorithmic bytes; same-box A/B: the step
+ *                            1-2 % faster, profiles/r05_wgrad_bf16_merge_ab.md); 0 = one group per weight matrix (rounds 2-4).  Same
+ *                            results to float32 summation order; changes the workspace size (query nrf_workspace_bytes* after
+ *                            setting it). */
 #define NRF_OPT_BF16_WGRAD_MERGE 2
 int nrf_set_option(nrf_handle h, int32_t option, int64_t value);
 

@@ -33,7 +33,7 @@ namespace nrf {
 
 constexpr int HT_ROWS = 32;                       // rows per half tile
 constexpr int ACT32_FLOATS = TRUNK_W * HT_ROWS;   // LDS activation tile [256][32]
-constexpr int SCR32_ROWS = 24;                    // scratch rows the VALU heads need behind the activation tile (logit partials)
+constexpr int SCR32_ROWS = 12;                    // scratch rows the VALU heads need behind the activation tile (4 x 3 logit partials)
 
 // LDS address (floats) of granule (k, g): rows 4g..4g+3 of feature k, g = 0..7.  Swizzle with (k >> 1) & 7: the epilogue's
 // ds_write_b128 (16 lanes = 16 consecutive features, one granule: 128 (k & 1) + 16 (g ^ ((k >> 1) & 7)) bytes mod 256) and
@@ -108,10 +108,12 @@ __device__ __forceinline__ void k_loop32(f32x16 (&acc)[2], const float* lds_in, 
   for (int q = 1; q < nquads; ++q) quad();
 }
 
-// 32 columns per wave (NCB = 1 stream: float4 = ks0..ks3, 8 k per float4; quad = 2 float4).  Even / odd k-steps go to two
-// accumulators (a single one would be a chain of dependent MFMAs); the caller adds them.
+// 32 columns per wave (NCB = 1 stream: float4 = ks0..ks3, 8 k per float4; quad = 2 float4).  ONE accumulator, k-steps in order:
+// the same fmaf chain per output element as the 64-row kernel, so the two tilings agree bit for bit (a sub-batch of rays, which
+// may run on the other tiling, reproduces its rows exactly: tests/test_gpu_fullsize.py).  The chain of dependent MFMAs costs a
+// lone wave some issue slots; this layer is 5 % of a tile and the other waves of the SIMD fill them.
 template <bool SWZ>
-__device__ __forceinline__ void k_loop32_n1(f32x16 (&acc)[2], const float* lds_in, int nquads, const float4* __restrict__ wp, int lane,
+__device__ __forceinline__ void k_loop32_n1(f32x16& acc, const float* lds_in, int nquads, const float4* __restrict__ wp, int lane,
                                             const WQuad<1>& first) {
   constexpr int QUAD_FLOATS = 16 * HT_ROWS;
   asm volatile("" : "+v"(lane));
@@ -137,7 +139,7 @@ __device__ __forceinline__ void k_loop32_n1(f32x16 (&acc)[2], const float* lds_i
     for (int ks = 0; ks < 8; ++ks) {
       const float4 b = bc.b[ks >> 2];
       const float bv = (ks & 3) == 0 ? b.x : (ks & 3) == 1 ? b.y : (ks & 3) == 2 ? b.z : b.w;
-      acc[ks & 1] = mfma32(a[ks], bv, acc[ks & 1]);
+      acc = mfma32(a[ks], bv, acc);
     }
     bc = bn;
     ap += QUAD_FLOATS;
@@ -323,9 +325,10 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
     }
 
     // ---- alpha head: Dense(256->1) on the trunk output, or -- use_alpha_condition -- Dense(256+A->1) on
-    //      [bottleneck, appearance code] with the per-ray code term from ray_prep (modules.py:152-157).  A wave covers
-    //      k in [64 wave, 64 wave + 64): its weights are wave-uniform (s_load_dwordx16 per 16 k), lane half h takes the
-    //      k of parity h, and the 8 partials of a row are summed through the scratch ----
+    //      [bottleneck, appearance code] with the per-ray code term from ray_prep (modules.py:152-157).  The SAME four partial
+    //      sums as the 64-row kernel (wave w: the fmaf chain over k = 64 w .. 64 w + 63, weights wave-uniform -> s_load_dwordx16
+    //      per 16 k), combined in the same order, so the two tilings give the same bits; both lane halves run the chain (32 rows
+    //      fill half a wave), half 0 keeps the result ----
     float sigma_raw = 0.f;
     auto alpha_head = [&]() {
       const float4* __restrict__ wa4 = reinterpret_cast<const float4*>(prm + A.po.alpha_k) + wave * 16;
@@ -336,21 +339,19 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
         float4 w4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w4[i] = wa4[4 * kc + i];
-        const float* wf = reinterpret_cast<const float*>(w4);
-        float a[8];
+        float a[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = act[act32_elem(k0 + 16 * kc + 2 * i + h, p)];
+        for (int i = 0; i < 16; ++i) a[i] = act[act32_elem(k0 + 16 * kc + i, p)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s = fmaf(a[i], h ? wf[2 * i + 1] : wf[2 * i], s);
+        for (int i = 0; i < 4; ++i) {
+          s = fmaf(a[4 * i], w4[i].x, s); s = fmaf(a[4 * i + 1], w4[i].y, s);
+          s = fmaf(a[4 * i + 2], w4[i].z, s); s = fmaf(a[4 * i + 3], w4[i].w, s);
+        }
       }
-      pe[part * HT_ROWS + p] = s;
+      if (h == 0) pe[wave * HT_ROWS + p] = s;
       __syncthreads();
-      if (part == 0) {
-        float t = prm[A.po.alpha_b];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) t += pe[q * HT_ROWS + p];
-        sigma_raw = t;
-      }
+      if (part == 0)
+        sigma_raw = (pe[p] + pe[HT_ROWS + p]) + (pe[2 * HT_ROWS + p] + pe[3 * HT_ROWS + p]) + prm[A.po.alpha_b];
     };
     if (!A.alpha_ct) alpha_head();
 
@@ -371,8 +372,9 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
     // ---- rgb branch hidden: Dense(256+R -> 128)+ReLU; the R per-ray condition columns are folded into
     //      condterm[ray][n] (= cond . W[256:] + bias) by ray_prep ----
     {
-      f32x16 acc1[2];
-      zero32(acc1);
+      f32x16 acc1;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc1[q] = 0.f;
       const int n = wave * 32 + j;
       // rows visited by this lane increase with t: walk the ray boundaries instead of dividing
       int ray = row0 / A.S;
@@ -385,8 +387,7 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int g = 2 * t + h;
-        const float av[4] = {acc1[0][4 * t] + acc1[1][4 * t], acc1[0][4 * t + 1] + acc1[1][4 * t + 1],
-                             acc1[0][4 * t + 2] + acc1[1][4 * t + 2], acc1[0][4 * t + 3] + acc1[1][4 * t + 3]};
+        const float av[4] = {acc1[4 * t], acc1[4 * t + 1], acc1[4 * t + 2], acc1[4 * t + 3]};
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -404,8 +405,8 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
       __syncthreads();
     }
 
-    // ---- rgb logits Dense(128->3), sigmoid; sigma activation (models.py:276-277).  Wave covers k in [32 wave, 32 wave + 32)
-    //      (96 wave-uniform weights), lane half h the k of parity h ----
+    // ---- rgb logits Dense(128->3), sigmoid; sigma activation (models.py:276-277).  As the alpha head: the 64-row kernel's four
+    //      partial sums (wave w: k = 32 w .. 32 w + 31 in order, 96 wave-uniform weights) and its order of combining them ----
     {
       const float4* __restrict__ wl4 = reinterpret_cast<const float4*>(prm + A.po.logit_k) + wave * 24;
       float sc[3] = {0.f, 0.f, 0.f};
@@ -416,27 +417,25 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
 #pragma unroll
         for (int i = 0; i < 12; ++i) w4[i] = wl4[12 * kc + i];
         const float* wf = reinterpret_cast<const float*>(w4);
-        float a[8];
+        float a[16];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = act[act32_elem(k0 + 16 * kc + 2 * i + h, p)];
+        for (int i = 0; i < 16; ++i) a[i] = act[act32_elem(k0 + 16 * kc + i, p)];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-#pragma unroll
-          for (int c = 0; c < 3; ++c) sc[c] = fmaf(a[i], h ? wf[3 * (2 * i + 1) + c] : wf[3 * (2 * i) + c], sc[c]);
+        for (int i = 0; i < 16; ++i) {
+          sc[0] = fmaf(a[i], wf[3 * i], sc[0]); sc[1] = fmaf(a[i], wf[3 * i + 1], sc[1]); sc[2] = fmaf(a[i], wf[3 * i + 2], sc[2]);
         }
       }
+      if (h == 0) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) pe[(3 * part + c) * HT_ROWS + p] = sc[c];
+        for (int c = 0; c < 3; ++c) pe[(3 * wave + c) * HT_ROWS + p] = sc[c];
+      }
       __syncthreads();
       if (part == 0) {
         float t[3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float s = prm[A.po.logit_b + c];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) s += pe[(3 * q + c) * HT_ROWS + p];
-          t[c] = s;
-        }
+        for (int c = 0; c < 3; ++c)
+          t[c] = (pe[c * HT_ROWS + p] + pe[(3 + c) * HT_ROWS + p]) + (pe[(6 + c) * HT_ROWS + p] + pe[(9 + c) * HT_ROWS + p]) +
+                 prm[A.po.logit_b + c];
         float4 o;
         o.x = 1.f / (1.f + expf(-t[0])); o.y = 1.f / (1.f + expf(-t[1])); o.z = 1.f / (1.f + expf(-t[2]));
         if (A.noise_std > 0.f) {   // model_utils.noise_regularize (model_utils.py:266-282)

@@ -204,7 +204,8 @@ struct nrf_handle_s {
   int num_cus = 256;
   bool cu_queried = false;
   int chain_rows_opt = 0;   // NRF_OPT_CHAIN_TILE_ROWS: 0 automatic, 32, 64
-  int bf16_wgrad_merge = 0; // NRF_OPT_BF16_WGRAD_MERGE: 1 = skip-layer / bottleneck+alpha groups of the bf16 wgrad merged (operands streamed once)
+  int bf16_wgrad_merge = 1; // NRF_OPT_BF16_WGRAD_MERGE: 1 (default) = skip-layer / bottleneck+alpha groups of the bf16 wgrad merged (operands
+                            // streamed once: -10 % HBM fetch, +1..2 % step rate in the same-box A/B, profiles/r05_wgrad_bf16_merge_ab.md)
   WsPlan plan;
   // identity of the tables last uploaded to a workspace, and of the last stashed forward
   void* uploaded_ws = nullptr;
@@ -532,7 +533,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
             bspecs.back().x2off = &L.b_pe; bspecs.back().Kb2 = 2; bspecs.back().x2_blocks = 2;
           } else {
             bpush(&L.b_h, (size_t)(l - 1) * layer, 8, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l], 256, 256, 256, 0, po.trunk_b[l], 256);
-            if (l == d.nerf_skip_layer)   // default: the posenc rows of the skip layer as a group of their own (dpre_4 read twice)
+            if (l == d.nerf_skip_layer)   // merge off: the posenc rows of the skip layer as a group of their own (dpre_4 read twice)
               bpush(&L.b_pe, 0, 2, &L.b_dy, (size_t)l * layer, 8, po.trunk_k[l] + 256 * 256, 256, h->P, 256, 0, -1, 0);
           }
         }
@@ -695,8 +696,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     const double bc_seg = env_cost("NRF_BCOST_SEG", 16.0);   // opening a segment (pipeline fill + 256 KiB slab flush), in block units
     const double bc_chunk = env_cost("NRF_BCOST_CHUNK", 12.0);   // per-chunk fixed cost (barrier + issue), in block units
     // the two merged shapes (10 x 8, 8 x 9: ten accumulator blocks per wave, five copies per wave and chunk) cost more per chunk
-    // than their bytes: round 5, first run with a byte-proportional cost: wgrad_bf16 0.51 -> 0.61 ms although it fetched 10 %
-    // less -- the workgroups inside the merged groups ran ~1.35 x their quota
+    // than their bytes: with a byte-proportional cost the kernel was 10 % SLOWER although it fetched 10 % less (the workgroups
+    // inside the merged groups ran ~1.35 x their quota); swept on the GPU at +0 / 6 / 10 / 16 / 24 / 32 units: 0.555 / 0.508 /
+    // 0.500 / 0.520 / 0.527 / 0.543 ms
     const double bc_merged = env_cost("NRF_BCOST_MERGED", 10.0);
     auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb) + bc_chunk + ((sp.Kb2 || sp.Nb2) ? bc_merged : 0.0); };
     double total = 0;

@@ -1,10 +1,11 @@
 """The float32 NeRF chain on 32-row tiles (csrc/mlp_chain32.hip, NRF_OPT_CHAIN_TILE_ROWS = 32) against the 64-row kernels
 (csrc/mlp_chain.hip) on the same inputs (modules.py:26-62, 65-169; models.py:270-277).
 
-Both tilings write the SAME HBM images (64-row fragment-order stash, sign-bit words, d raw / out4 rows), and every trunk
-output element is the same fmaf chain in both (bias, then k = 0, 1, ... through the same MFMA k-steps), so the trunk /
-bottleneck stashes and the ReLU bits must agree BIT FOR BIT; the rgb hidden layer (two accumulators per wave here), the
-alpha head and the logits (8 partial sums per row instead of 4) agree to float32 summation order.  Shapes are chosen so
+Both tilings write the SAME HBM images (64-row fragment-order stash, sign-bit words, d raw / out4 rows), and every output
+element is the same fmaf chain in both (bias, then k = 0, 1, ... through the same MFMA k-steps; the alpha head and the logits
+as the same four partial sums), so stashes, ReLU bits, rendered values and the stashed gradients must agree BIT FOR BIT --
+which is what lets the library pick the tiling per launch without a ray's result depending on the size of the launch it
+rides in (tests/test_gpu_fullsize.py).  Only float atomics (bias / per-ray condition sums) differ in order.  Shapes are chosen so
 that the last 64-row tile is ragged in both ways: more than 32 valid rows (second half partly padding) and fewer (second
 half all padding)."""
 import ctypes as C
@@ -50,31 +51,16 @@ def test_stash_bits_and_gradients_match_the_64_row_kernels(B, nc, nf):
              'out4': 64 * 4, 'dy_trunk': 8 * 256 * 64, 'dy_bn': 256 * 64, 'dy_rgbh': 128 * 64}
   a, _ = _train_once(64, spec, oparams, batch, B, regions)
   b, _ = _train_once(32, spec, oparams, batch, B, regions)
-  def bit_diff(x, y):
-    d = x.view(torch.int32) ^ y.view(torch.int32)
-    return sum(int(((d >> k) & 1).sum()) for k in range(32)) / (d.numel() * 32)
+  # every stashed activation, every sign bit, the kernel outputs and every stashed pre-activation gradient: the same fmaf chains in
+  # both tilings (trunk / bottleneck / rgb hidden: bias, then k = 0, 1, ... through the same MFMA k-steps; alpha head and logits: the
+  # same four partial sums combined in the same order) -> the same bits, at both levels (the fine depths derive from the coarse
+  # weights, which are therefore the same too)
   for lv in (0, 1):
-    # st_h is [layer][tile][...]: the debug offset is the level's base and the level's layers are contiguous behind it
-    for name in ('st_pe', 'st_h', 'st_bn', 'bits_trunk'):
-      x, y = a[(name, lv)], b[(name, lv)]
-      if lv == 0:     # coarse level: same sample points in both runs -> the same fmaf chains -> the same bits
-        assert torch.equal(x.view(torch.int32), y.view(torch.int32)), (name, lv)
-      elif name == 'bits_trunk':
-        # fine level: the fine depths come from the coarse weights, which differ in the last place between the tilings (alpha head /
-        # logits: 8 partial sums per row instead of 4), so the fine points and everything behind them agree to rounding only
-        assert bit_diff(x, y) <= 1e-3, (name, lv, bit_diff(x, y))
-      else:
-        assert (x - y).abs().max().item() <= 2e-3 * max(x.abs().max().item(), 1.0), (name, lv, (x - y).abs().max().item())
-    x, y = a[('st_rgbh', lv)], b[('st_rgbh', lv)]
-    assert (x - y).abs().max().item() <= (1e-5 if lv == 0 else 2e-3) * max(x.abs().max().item(), 1.0), ('st_rgbh', lv)
-    # sign bits of the rgb hidden layer: equal except where the pre-activation is within summation-order rounding of zero
-    assert bit_diff(a[('bits_rgbh', lv)], b[('bits_rgbh', lv)]) <= 1e-3, ('bits_rgbh', lv)
-    x, y = a[('out4', lv)], b[('out4', lv)]
-    assert (x - y).abs().max().item() <= (2e-6 if lv == 0 else 1e-3) * max(x.abs().max().item(), 1.0), ('out4', lv)
-    for name in ('dy_rgbh', 'dy_bn', 'dy_trunk'):
-      x, y = a[(name, lv)], b[(name, lv)]
-      assert (x - y).abs().max().item() <= (1e-4 if lv == 0 else 5e-3) * x.abs().max().item() + 1e-12, (name, lv)
-  assert torch.allclose(a['stats'], b['stats'], rtol=1e-5, atol=1e-7)
+    # st_h / dy_trunk are [layer][tile][...]: the debug offset is the level's base and the level's layers are contiguous behind it
+    for name in regions:
+      assert torch.equal(a[(name, lv)].view(torch.int32), b[(name, lv)].view(torch.int32)), (name, lv)
+  assert torch.equal(a['stats'][:5], b['stats'][:5])
+  # gradients: the reverse tilings differ in the ORDER of their float atomics only (bias column sums, per-ray condition sums)
   ga, gb = a['grad'], b['grad']
   model, _ = H.gpu_model(spec, oparams, B)
   for name, off, shape in model.layout.entries:

@@ -528,7 +528,8 @@ def train_workload(args, M, cfg, rays_per_gpu, bf16, graph, ctx, profile=True):
   state, stats, key = box['state'], box['stats'], box['key']
   loss = stats['fine']['loss/rgb'].item()
   # every rank applied the same all-reduced gradient to the same initial parameters: the replicas must be BIT-identical.
-  # Checked on a checksum of the parameter bits (and the per-rank losses are reported: they differ, every rank has its own rays)
+  # Checked on a checksum of the parameter bits (the per-rank losses are reported too: the step's statistics are pmean'ed over the
+  # ranks, training.py:267, so they agree as well)
   per_rank_loss, replicas_agree = [loss], True
   if dist_on:
     flat = state.optimizer.target.flat

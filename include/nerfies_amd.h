@@ -362,8 +362,10 @@ int nrf_debug_ws_offset(nrf_handle h, const char* name, int32_t level, int64_t* 
  * NRF_E_UNSUPPORTED.
  *   NRF_OPT_CHAIN_TILE_ROWS  rows per workgroup tile of the float32 NeRF-MLP chain kernels (modules.py:95-169):
  *                            64 = two workgroups per CU (csrc/mlp_chain.hip), 32 = four per CU (csrc/mlp_chain32.hip),
- *                            0 = automatic (default).  Results agree to float32 summation order; the workspace layout
- *                            does not depend on it. */
+ *                            0 = automatic (default: half tiles for forward launches that under-fill the 64-row grid).  The
+ *                            forward results (and the stashes) are bit-identical under both tilings -- a ray's result does not
+ *                            depend on the launch it rides in --, gradients agree to the order of float atomics; the workspace
+ *                            layout does not depend on it. */
 #define NRF_OPT_CHAIN_TILE_ROWS 1
 /*   NRF_OPT_BF16_WGRAD_MERGE bf16 training mode: 1 (default) = the weight-gradient GEMMs of the skip layer (X = [h4 | posenc]) and of
  *                            the bottleneck + alpha head (dY = [d bottleneck | d raw]) run as ONE group each, so dpre_4 and h8 are

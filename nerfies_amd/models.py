@@ -199,8 +199,8 @@ class NerfModel:
 
   def set_chain_tile_rows(self, rows: int):
     """NRF_OPT_CHAIN_TILE_ROWS: rows per workgroup tile of the float32 NeRF chain kernels -- 64 (two workgroups per CU), 32
-    (four per CU) or 0 = automatic (the default).  A tuning knob without a reference counterpart; results agree to float32
-    summation order."""
+    (four per CU) or 0 = automatic (the default).  A tuning knob without a reference counterpart; forward results are bit-identical
+    under both tilings, gradients agree to the order of float atomics."""
     L.check(self.lib.nrf_set_option(self.handle, L.NRF_OPT_CHAIN_TILE_ROWS, int(rows)), self.lib)
 
   @property

@@ -139,7 +139,8 @@ def test_bench_gpus_2_launches_itself_and_checks_itself():
   import torch
   assert d['n_gpus'] == 2 and d['rccl_ranks'] == 2 and d['replica_param_checksums_agree'] is True
   assert d['config']['global_batch'] == 2048 and d['scaling'] == 'weak' and d['value'] > 0
-  assert len(d['per_rank_final_loss_fine']) == 2 and d['per_rank_final_loss_fine'][0] != d['per_rank_final_loss_fine'][1]
+  # the statistics a step returns are pmean'ed over the ranks (training.py:267): every rank reports the same mean loss
+  assert len(d['per_rank_final_loss_fine']) == 2 and d['per_rank_final_loss_fine'][0] == d['per_rank_final_loss_fine'][1] > 0
   assert d['grad_allreduce_us'] > 0 and d['grad_allreduce_exposed_us'] is not None
   s = d['strong_scaling']
   assert s['global_batch'] == 1024 and s['rays_per_gpu'] == 512

@@ -26,14 +26,15 @@ def _psnr(a, b):
   return float(-10.0 * np.log10(((a - b) ** 2).mean().item()))
 
 
-def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread():
+@pytest.mark.parametrize('fp,fw', [(6, 4), (8, 6)])   # a small shape, and the vrig preset's posenc widths (F_p = 8, F_w = 6, G = 8: ADVICE r4)
+def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread(fp, fw):
   from nerfies_amd import models, training
   B, K, NB, NID = 256, 600, 32, 4
 
   class Cfg:
-    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 32, 32, 6
+    num_coarse_samples, num_fine_samples, num_nerf_point_freqs = 32, 32, fp
     sigma_activation, use_stratified_sampling, use_viewdirs = 'softplus', True, True
-    use_warp, warp_field_type, num_warp_freqs, num_warp_features = True, 'se3', 4, 8
+    use_warp, warp_field_type, num_warp_freqs, num_warp_features = True, 'se3', fw, 8
   g = torch.Generator().manual_seed(0)
   n_train, n_test = NB * B, 2048
   o = (torch.rand(n_train + n_test, 3, generator=g) - 0.5).to(DEV)
@@ -46,12 +47,12 @@ def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread():
   test = {'origins': o[n_train:], 'directions': d[n_train:], 'metadata': {'warp': ids[n_train:]}}
   runs = {}
   for mode, key0 in (('f32', 1), ('f32b', 1001), ('f32c', 2002), ('bf16', 1)):
-    model, fp = models.construct_nerf(7, Cfg, B, [0], [0], list(range(NID)), 0.05, 1.0, device=DEV)
-    state = training.TrainState(optimizer=training.Optimizer(fp))
+    model, fpar = models.construct_nerf(7, Cfg, B, [0], [0], list(range(NID)), 0.05, 1.0, device=DEV)
+    state = training.TrainState(optimizer=training.Optimizer(fpar))
     key, losses = key0, []
     for k in range(K):
       sp = training.ScalarParams(learning_rate=1e-3 * 0.1 ** (k / K), elastic_loss_weight=1e-3)   # exponential decay (defaults.gin)
-      state = state.replace(warp_alpha=4.0 * min(1.0, k / (0.5 * K)))   # linear schedule 0 -> F_w (warp_defaults.gin)
+      state = state.replace(warp_alpha=float(fw) * min(1.0, k / (0.5 * K)))   # linear schedule 0 -> F_w (warp_defaults.gin)
       i0 = (k % NB) * B
       batch = {'origins': o[i0:i0 + B], 'directions': d[i0:i0 + B], 'rgb': rgb[i0:i0 + B], 'metadata': {'warp': ids[i0:i0 + B]}}
       state, stats, key = training.train_step(model, key, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight',
@@ -59,7 +60,7 @@ def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread():
       losses.append(stats['fine']['loss/rgb'])
     losses = torch.stack(losses).cpu().numpy()
     assert np.isfinite(losses).all()
-    psnr = {tag: _psnr(em.apply({'params': fp}, test, {'alpha': 4.0}, **kw)['fine']['rgb'], rgb[n_train:])
+    psnr = {tag: _psnr(em.apply({'params': fpar}, test, {'alpha': float(fw)}, **kw)['fine']['rgb'], rgb[n_train:])
             for tag, kw in (('f32', {}), ('bf16', dict(bf16=True)))}   # the same weights rendered by both inference modes
     runs[mode] = (psnr, losses)
   f32 = [runs[m] for m in ('f32', 'f32b', 'f32c')]
@@ -67,7 +68,7 @@ def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread():
   ps = [p['f32'] for p, _ in f32]
   lo, hi = min(ps), max(ps)
   m32 = [l[-100:].mean() for _, l in f32]
-  print(f'[bf16 training, warp on] held-out PSNR: fp32 runs {ps[0]:.3f} / {ps[1]:.3f} / {ps[2]:.3f} dB, bf16-trained {p16["f32"]:.3f} dB; bf16 '
+  print(f'[bf16 training, warp on, F_p = {fp}, F_w = {fw}] held-out PSNR: fp32 runs {ps[0]:.3f} / {ps[1]:.3f} / {ps[2]:.3f} dB, bf16-trained {p16["f32"]:.3f} dB; bf16 '
         f'rendering of the same weights {f32[0][0]["bf16"] - ps[0]:+.3f} / {p16["bf16"] - p16["f32"]:+.3f} dB; mean loss of the last 100 '
         f'steps {m32[0]:.5f} / {m32[1]:.5f} / {m32[2]:.5f} / {l16[-100:].mean():.5f}')
   assert lo > 18.0                                                   # the scene is learnt at all

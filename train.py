@@ -29,7 +29,7 @@ def parse_flags(argv=None):
   p.add_argument('--bf16', nargs='?', const='all', default=None, choices=['all', 'mlp'],
                  help="bfloat16 MFMA operands (NRF_FLAG_BF16; no reference counterpart; fp32 master weights, posenc, exp_se3, compositing, "
                       "loss, Adam).  --bf16 / --bf16 all: the NeRF MLPs AND the SE3 warp trunk (BASELINE configs[3]; a warped point moves by "
-                      "~5e-4 of its displacement, which cost 0.3-0.4 dB of held-out PSNR at the vrig preset's posenc widths in a 600-step test); --bf16 mlp: the NeRF MLPs only, the warp trunk stays float32 (NRF_FLAG_WARP_F32; no measurable PSNR cost, about half the speed with the warp on).  train.py "
+                      "~5e-4 of its displacement; no systematic held-out-PSNR cost at the vrig preset's posenc widths over a 6000-step schedule, profiles/r05_bf16_warp_gap.json); --bf16 mlp: the NeRF MLPs only, the warp trunk stays float32 (NRF_FLAG_WARP_F32; about half the speed with the warp on; for captures whose deformation is large against the scene).  train.py "
                       "trains with a bfloat16 activation / gradient stash (~6x the fp32 step without the warp), eval.py renders with "
                       "bfloat16 operands (~1e-2 on colour, < 0.01 dB held-out PSNR)")
   p.add_argument('--graph', action='store_true', help='replay the whole train step (loss + gradient, all-reduce, Adam) from ONE hipGraph '

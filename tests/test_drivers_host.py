@@ -104,3 +104,24 @@ def test_eval_loop_with_a_stand_in_renderer(tmp_path):
     os.makedirs(tmp_path / 'renders' / step)
   eval_driver.delete_old_renders(str(tmp_path / 'renders'), 2)
   assert sorted(os.listdir(tmp_path / 'renders')) == ['00000120', '00000130']
+
+
+def test_replayed_ray_tree_must_match_the_captured_one():
+  """evaluation.GraphedChunkRenderer copies new rays into the static buffers of its captured chunk: another key set, shape or
+  dtype is refused with a message that says which (a missing sub-dict used to surface as a TypeError on None)."""
+  import pytest
+  import torch
+  from nerfies_amd import evaluation
+  from nerfies_amd import lib as L
+  cap = {'origins': torch.zeros(8, 3), 'directions': torch.zeros(8, 3), 'metadata': {'warp': torch.zeros(8, 1, dtype=torch.int32)}}
+  evaluation._check_same_tree(cap, {'origins': torch.ones(8, 3), 'directions': torch.ones(8, 3), 'metadata': {'warp': torch.ones(8, 1, dtype=torch.int32)}})
+  with pytest.raises(L.NrfError, match='rays/metadata'):
+    evaluation._check_same_tree(cap, {'origins': torch.ones(8, 3), 'directions': torch.ones(8, 3), 'metadata': {}})
+  with pytest.raises(L.NrfError, match='rays has keys'):
+    evaluation._check_same_tree(cap, {'origins': torch.ones(8, 3), 'directions': torch.ones(8, 3)})
+  with pytest.raises(L.NrfError, match='rays/origins'):
+    evaluation._check_same_tree(cap, {'origins': torch.ones(4, 3), 'directions': torch.ones(8, 3), 'metadata': {'warp': torch.ones(8, 1, dtype=torch.int32)}})
+  with pytest.raises(L.NrfError, match='rays/metadata/warp'):
+    evaluation._check_same_tree(cap, {'origins': torch.ones(8, 3), 'directions': torch.ones(8, 3), 'metadata': {'warp': torch.ones(8, 1)}})
+  with pytest.raises(ValueError):
+    evaluation.render_image(None, {'origins': torch.zeros(2, 2, 3)}, None, tile_parallel='rows')

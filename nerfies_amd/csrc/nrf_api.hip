@@ -1980,6 +1980,7 @@ int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_ray
                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
   if (flags & ~(uint32_t)(NRF_FLAG_BF16 | NRF_FLAG_WARP_F32)) return fail(NRF_E_UNSUPPORTED, "nrf_train_step_loss_grad_ex flags: 0, NRF_FLAG_BF16 [| NRF_FLAG_WARP_F32]");
+  CK(check_flags(NRF_FLAG_TRAIN | flags));   // the same word nrf_workspace_bytes_ex validated (WARP_F32 without BF16 is refused here too)
   int bgN = 0;
   if (el) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the elastic regulariser needs the warp field");

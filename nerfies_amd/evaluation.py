@@ -25,6 +25,10 @@ class GraphedChunkRenderer:
   the full chunk when the renderer asks for it (`wants_fixed_chunks`), so that one graph serves the whole frame."""
   wants_fixed_chunks = True
   MAX_GRAPHS = 8
+  # what NerfModel.apply reads of a ray tree (models.py:289-375).  Dataset items also carry 'rgb' / 'pixels' / 'depth'
+  # (datasets.item_rays) while camera-path frames do not (rays_from_camera): only the consumed keys are captured and copied, so
+  # one renderer serves both kinds of frame (eval.py renders val / train items and then test cameras through the same one)
+  CONSUMED = ('origins', 'directions', 'viewdirs', 'metadata')
 
   def __init__(self, model, use_warp=True, bf16=False):
     self.model = model
@@ -57,10 +61,11 @@ class GraphedChunkRenderer:
     """As __call__, but returns the graph's own output buffers (valid until the next replay): render_image copies each chunk
     straight into the frame at its offset, so a chunk's outputs are moved once instead of cloned and then concatenated."""
     del key_0, key_1               # eval is deterministic (eval.py:239 forces use_stratified_sampling off)
+    rays = {k: rays[k] for k in self.CONSUMED if rays.get(k) is not None}
     n = rays['origins'].shape[0]
     # every scalar of lib.StepScalars is part of the key: a replay would otherwise render with the captured value
     scalars = tuple(float((warp_extra or {}).get(k, 0.0)) for k in ('alpha', 'time_alpha'))
-    key = (n, params.flat.data_ptr(), scalars, tuple(sorted((rays.get('metadata') or {}).keys())))
+    key = (n, params.flat.data_ptr(), scalars, 'viewdirs' in rays, tuple(sorted((rays.get('metadata') or {}).keys())))
     slot = self._slots.get(key)
     if slot is None:
       # every chunk size has its own workspace (descriptor tables included), so graphs of different sizes coexist
@@ -156,10 +161,16 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
     return i0, n, n + pad, rays
 
   if dist_on and tile_parallel == 'band':
-    cpr = -(-num_chunks // world)                     # chunks per rank; the last ranks may own fewer (or none)
-    band_rows = cpr * chunk
+    # balanced bands: rank r renders base (+ 1 for the first `rem` ranks) whole chunks starting at r * base + min(r, rem) --
+    # 9 chunks on 8 ranks are 2 + 1 x 7, not 2 x 4 + 1 + 0 x 3.  all_gather wants equal pieces, so every band buffer holds
+    # cmax chunks and the frame is assembled from each rank's leading rows
+    base, rem = divmod(num_chunks, world)
+    cmax = base + (1 if rem else 0)
+    first = lambda r: r * base + min(r, rem)
+    count = lambda r: base + (1 if r < rem else 0)
+    band_rows = cmax * chunk
     band, meta = None, None
-    for c in range(rank * cpr, min((rank + 1) * cpr, num_chunks)):
+    for c in range(first(rank), first(rank) + count(rank)):
       i0, n, _, rays = padded_chunk(c, 1)
       out = call(rng, rng + 1, state.optimizer.target, rays, state.warp_extra)
       ret = out[default_ret_key or ('fine' if 'fine' in out else 'coarse')]
@@ -167,19 +178,23 @@ def render_image(state, rays_dict: Dict[str, Any], model_fn: Callable, device_co
       if band is None:
         band = torch.zeros(band_rows, sum(widths), dtype=torch.float32, device=cols[0].device)
         meta = (keys, widths, [tuple(ret[k].shape[1:]) for k in keys], [ret[k].dtype for k in keys])
-      at, col = i0 - rank * band_rows, 0
+      at, col = i0 - first(rank) * chunk, 0
       for cdata, wd in zip(cols, widths):
         band[at:at + n, col:col + wd].copy_(cdata[:n])
         col += wd
-    # a rank without a chunk (more ranks than chunks) still joins the collective: it learns the layout from rank 0
-    lay = [meta]
-    if world > 1:
+    # only when there are more ranks than chunks does a rank own none; it then learns the output layout from rank 0 (every rank
+    # sees base == 0 locally, so all of them join this broadcast or none does).  Otherwise: ONE collective per frame.
+    if world > 1 and base == 0:
+      lay = [meta]
       dist.broadcast_object_list(lay, src=0)
-    keys, widths, shapes, dtypes = lay[0]
+      meta = lay[0]
+    keys, widths, shapes, dtypes = meta
     if band is None:
       band = torch.zeros(band_rows, sum(widths), dtype=torch.float32, device=flat['origins'].device)
     gathered = torch.empty(world * band_rows, band.shape[1], dtype=band.dtype, device=band.device)
     _all_gather_rows(gathered, band)     # ONE collective per frame
+    if rem:   # bands of unequal length: keep each rank's leading count(r) chunks
+      gathered = torch.cat([gathered[r * band_rows:r * band_rows + count(r) * chunk] for r in range(world) if count(r)], 0)
     split = torch.split(gathered[:num_rays], widths, 1)
     return {k: split[i].reshape(h, w, *shapes[i]).to(dtypes[i]) for i, k in enumerate(keys)}
 

@@ -202,6 +202,18 @@ class NerfModel:
     (four per CU) or 0 = automatic (the default).  A tuning knob without a reference counterpart; forward results are bit-identical
     under both tilings, gradients agree to the order of float atomics."""
     L.check(self.lib.nrf_set_option(self.handle, L.NRF_OPT_CHAIN_TILE_ROWS, int(rows)), self.lib)
+    self._drop_workspaces()
+
+  def set_bf16_wgrad_merge(self, on: bool):
+    """NRF_OPT_BF16_WGRAD_MERGE: merged weight-gradient groups of the bf16 training mode (default on).  The option changes the
+    training workspace's SIZE and layout, so the cached workspaces (and the stash a pending `backward` would read) are dropped:
+    a live model picks the option up at its next step instead of running the new plan in a buffer sized for the old one."""
+    L.check(self.lib.nrf_set_option(self.handle, L.NRF_OPT_BF16_WGRAD_MERGE, int(bool(on))), self.lib)
+    self._drop_workspaces()
+
+  def _drop_workspaces(self):
+    self._ws = {}
+    self._train_ws = None
 
   @property
   def layout(self) -> P.ParamLayout:

@@ -98,3 +98,47 @@ def test_rank_count_must_match_gpus(monkeypatch):
     raise AssertionError('a launcher that started 4 ranks for --gpus 2 must be refused')
   except SystemExit as e:
     assert 'WORLD_SIZE=4' in str(e.code)
+
+
+def test_rccl_preflight_summary_parses_an_init_log(tmp_path, monkeypatch):
+  """What bench.py puts next to `rccl_ranks`: the transports RCCL connected its channels with, from the NCCL_DEBUG=INFO file
+  of rank 0 (a canned two-rank log here; the one-rank RCCL log of a real box is parsed by tests/test_gpu_rccl.py)."""
+  log = tmp_path / 'rank0.log'
+  log.write_text('\n'.join([
+      'box:101:101 [0] NCCL INFO NCCL_SOCKET_IFNAME set by environment to lo',
+      'box:101:101 [0] NCCL INFO RCCL version : 2.26.6-HEAD:abc',
+      'box:101:140 [0] NCCL INFO comm 0x55 rank 0 nranks 2 cudaDev 0 busId f4000 - Init START',
+      'box:101:140 [0] NCCL INFO === System : maxBw 48.0 totalBw 336.0 === GPU/F4000 + XGMI[48.0] - GPU/E4000',
+      'box:101:140 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC comm 0x55 nRanks 02',
+      'box:101:140 [0] NCCL INFO Channel 01/0 : 0[0] -> 1[1] via P2P/IPC comm 0x55 nRanks 02',
+      'box:101:140 [0] NCCL INFO Channel 00/0 : 1[1] -> 0[0] via SHM/direct/direct',
+      'box:101:140 [0] NCCL WARN something odd happened',
+      'box:101:140 [0] NCCL INFO 16 coll channels, 16 collnet channels, 0 nvls channels, 16 p2p channels',
+      'box:101:140 [0] NCCL INFO comm 0x55 rank 0 nranks 2 cudaDev 0 busId f4000 - Init COMPLETE']))
+  s = bench.rccl_preflight_summary(str(log))
+  assert s['connections_via'] == {'P2P/IPC': 2, 'SHM/direct/direct': 1} and s['coll_channels'] == [16] and s['nranks_seen'] == [2]
+  assert s['init_complete'] and s['xgmi_mentions'] == 1 and s['warnings'] == ['something odd happened']
+  assert 'RCCL version' in s['version_line'] and s['env_overrides'] == ['NCCL_SOCKET_IFNAME']
+  assert bench.rccl_preflight_summary(None) is None and bench.rccl_preflight_summary(str(tmp_path / 'none.log')) is None
+  # begin(): points RCCL's log of this rank at a file unless the user already asked for a console log
+  for k in ('NCCL_DEBUG', 'NCCL_DEBUG_FILE', 'NCCL_DEBUG_SUBSYS'):
+    monkeypatch.delenv(k, raising=False)
+  path = bench.rccl_preflight_begin(3)
+  assert path.endswith('rank3.log') and os.environ['NCCL_DEBUG'] == 'INFO' and os.environ['NCCL_DEBUG_FILE'] == path
+  monkeypatch.delenv('NCCL_DEBUG_FILE')
+  monkeypatch.setenv('NCCL_DEBUG', 'WARN')
+  assert bench.rccl_preflight_begin(0) is None
+
+
+def test_cpu_baseline_reports_every_candidate(monkeypatch):
+  """cpu_baseline times the SAME optimizer step three ways and reports the fastest with the thread counts it used (round 5
+  probed threads on 128 rays, timed one 1024-ray graph and understated the CPU by 2.3 x).  Shrunk here to 2 x 8 rays."""
+  monkeypatch.setattr(bench, 'RAYS_PER_GPU', 16)
+  monkeypatch.setattr(bench, 'N_COARSE', 8)
+  monkeypatch.setattr(bench, 'N_FINE', 8)
+  monkeypatch.setattr(bench, 'CPU_MICROBATCH', 8)
+  monkeypatch.setenv('BENCH_CPU_NO_PROCS', '1')
+  r = bench.cpu_baseline(0.5)
+  assert r['kind'] == 'port' and r['unit'] == 'rays/s' and r['value'] > 0 and r['cores'] == r['cores_used'] <= r['cores_available']
+  assert set(r['candidates']) == {'microbatch_grad_accumulation', 'full_batch_one_graph'}
+  assert r['value'] == max(c['rays_per_s'] for c in r['candidates'].values()) and r['variant'] in r['candidates']

@@ -101,6 +101,12 @@ def _worker(rank, port, tmp):
   assert fixed.sizes == {9}, fixed.sizes    # full-size launches only: the tail is edge-padded to the chunk
   for k in img:
     assert torch.equal(img[k], img_band[k]) and torch.equal(img[k], img_band_fixed[k]), k
+  # an odd chunk count (35 px = 5 chunks of 8: 3 + 2): balanced bands of unequal length, assembled from each rank's leading rows
+  calls = []
+  img_odd = evaluation.render_image(_State, rays, counting, device_count=WORLD, chunk=8)
+  assert calls == ([8, 8, 8] if rank == 0 else [8, 3]), calls
+  for k in img:
+    assert torch.allclose(img[k], img_odd[k], atol=1e-7, rtol=0), k
   # more ranks than chunks: the idle rank still joins the frame's one collective
   img_one = evaluation.render_image(_State, rays, _fake_model_fn, device_count=WORLD, chunk=64)
   for k in img:   # (torch's CPU sigmoid differs by an ulp between a 9-row and a 35-row call: vector body vs scalar tail)

@@ -317,7 +317,7 @@ def test_merged_wgrad_groups_give_the_same_gradient(kw):
   grads = []
   for merge in (0, 1):
     model, fp = H.gpu_model(spec, oparams, B)
-    L.check(model.lib.nrf_set_option(model.handle, L.NRF_OPT_BF16_WGRAD_MERGE, merge), model.lib)
+    model.set_bf16_wgrad_merge(merge)   # also drops the cached workspaces (the option changes their size)
     g, st = model.loss_and_grad(fp, batch, warp_extra={'alpha': 2.0}, bf16=True)
     grads.append((g.clone(), st.clone(), model))
   (g0, s0, model), (g1, s1, _) = grads
@@ -326,5 +326,9 @@ def test_merged_wgrad_groups_give_the_same_gradient(kw):
     n = int(np.prod(shape))
     x, y = g0[off:off + n], g1[off:off + n]
     assert (x - y).abs().max().item() <= 2e-5 * x.abs().max().item() + 1e-12, (name, (x - y).abs().max().item(), x.abs().max().item())
+  # switching the option on a LIVE model (one that has stepped: cached workspace of the other size) re-plans instead of reusing it
+  model.set_bf16_wgrad_merge(1)
+  g2, _ = model.loss_and_grad(fp, batch, warp_extra={'alpha': 2.0}, bf16=True)
+  assert torch.equal(g2, g1)
   with pytest.raises(L.NrfError):
     L.check(model.lib.nrf_set_option(model.handle, L.NRF_OPT_BF16_WGRAD_MERGE, 2), model.lib)

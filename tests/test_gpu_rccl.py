@@ -41,8 +41,17 @@ sp = training.ScalarParams(learning_rate=1e-3, elastic_loss_weight=0.01, backgro
 grad0, _ = model.loss_and_grad(state.optimizer.target, batch, warp_extra=state.warp_extra, rngs={'coarse': 5, 'fine': 6},
                                elastic={'weight': 0.01, 'reduce_method': 'weight'})
 grad_abs0 = float(grad0.double().abs().sum())
+# Every step starts from parameters BOTH runs can reproduce exactly (the initial ones, then seeded perturbations of them written
+# over the Adam-updated values): a step's reported losses are functions of the parameters it starts from, so the two processes are
+# compared step by step at float-atomic-order tolerance instead of along two trajectories that Adam's normalised update drives apart
+base = fp.flat.clone()
+pert = torch.randn(base.numel(), generator=torch.Generator().manual_seed(11)).to(dev)
+def resync(k):
+  fp.flat.copy_(base * (1.0 + 0.01 * k * pert))
 key, losses = 7, []
-for _ in range(3):
+for k in range(3):
+  if k:
+    resync(k)
   state, stats, key = training.train_step(model, key, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight',
                                           use_background_loss=True)
   losses.append([float(stats['coarse']['loss/total']), float(stats['fine']['loss/total']), float(stats['background_loss'])])
@@ -60,6 +69,7 @@ out['grad_abs'] = grad_abs0
 gstep = training.GraphedTrainStep(model, state, batch, sp, use_elastic_loss=True, elastic_reduce_method='weight', use_background_loss=True)
 glosses = []
 for k in (21, 22, 23):
+  resync(k - 17)
   st = gstep(k)
   glosses.append([float(st['coarse']['loss/total']), float(st['fine']['loss/total']), float(st['background_loss'])])
 out['graph_losses'] = glosses
@@ -97,22 +107,21 @@ def test_train_step_and_render_through_a_one_rank_rccl_communicator():
   assert rccl['backend'] == 'nccl' and rccl['rccl'], rccl
   assert rccl['allreduce_identity'] and rccl['allgather_identity']        # bitwise: a one-rank sum / gather is the identity
   assert plain['rgb_shape'] == rccl['rgb_shape'] == [5, 7, 3]
-  # the same three steps in two separate processes.  Step 0 starts from identical parameters: the two runs differ by the order of
-  # their float atomics only (1e-7-level).  From step 1 on Adam's normalised update turns rounding-level gradient entries into
-  # lr-sized parameter moves, and with the warp + elastic + background terms the two trajectories drift apart by percents within a
-  # few steps (round 5: this comparison at 5e-3 failed in 2 of 5 runs on unchanged kernels, 1 % at the sixth step)
+  # the same three steps in two separate processes, every step from parameters both runs reproduce exactly (the child re-syncs them:
+  # round 5 compared two free-running Adam trajectories and had to allow 5-10 %): the runs differ by the order of their float
+  # atomics only
   for k, (ra, rb) in enumerate(zip(plain['losses'], rccl['losses'])):
     for a, b in zip(ra, rb):
-      assert abs(a - b) <= 1e-6 + (5e-4 if k == 0 else 5e-2) * abs(a), (k, plain['losses'], rccl['losses'])
+      assert abs(a - b) <= 1e-6 + 5e-4 * abs(a), (k, plain['losses'], rccl['losses'])
   assert abs(plain['grad_abs'] - rccl['grad_abs']) <= 1e-4 * plain['grad_abs']     # at the initial parameters
-  assert abs(plain['params_abs'] - rccl['params_abs']) <= 1e-4 * plain['params_abs']
-  # three more steps replayed from the captured step: ONE graph in both runs (the RCCL all-reduce is inside it), same trajectory
+  assert abs(plain['params_abs'] - rccl['params_abs']) <= 2e-5 * plain['params_abs']
+  # three more steps replayed from the captured step: ONE graph in both runs (the RCCL all-reduce is inside it), re-synced likewise
   assert plain['graph_split'] is False and rccl['graph_split'] is False
   for a, b in zip(sum(plain['graph_losses'], []), sum(rccl['graph_losses'], [])):     # steps 4-6 of the two trajectories
-    assert abs(a - b) <= 1e-6 + 1e-1 * abs(a), (plain['graph_losses'], rccl['graph_losses'])
-  # six Adam steps behind the initial parameters: Adam's normalised update turns the float-atomic ordering noise of two runs into
-  # ~1e-5 of |params| (round 5: 1.3e-5 on one box with no code change); the losses above are the tight check
-  assert abs(plain['graph_params_abs'] - rccl['graph_params_abs']) <= 1e-4 * plain['graph_params_abs']
+    assert abs(a - b) <= 1e-6 + 5e-4 * abs(a), (plain['graph_losses'], rccl['graph_losses'])
+  # ONE Adam step behind re-synced parameters (the moments carry six steps of float-atomic ordering noise: lr-sized moves of the
+  # entries whose gradient is rounding-level)
+  assert abs(plain['graph_params_abs'] - rccl['graph_params_abs']) <= 2e-5 * plain['graph_params_abs']
 
 
 def test_bench_line_through_rccl(tmp_path):
@@ -125,6 +134,9 @@ def test_bench_line_through_rccl(tmp_path):
   d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
   assert d['dist_backend'] == 'nccl' and d['rccl_ranks'] == 1 and d['rccl_version'] and d['grad_allreduce_us'] > 0
   assert d['config']['rays_per_gpu'] == 128 and d['value'] > 0
+  # the pre-flight record: what RCCL logged while this (one-rank) communicator came up
+  pf = d['rccl_preflight']
+  assert pf and pf['log_lines'] > 0 and pf['init_complete'] and 1 in pf['nranks_seen'], pf
 
 
 def test_bench_gpus_2_launches_itself_and_checks_itself():
@@ -155,3 +167,26 @@ def test_bench_gpus_2_launches_itself_and_checks_itself():
     assert d['dist_backend'] == 'gloo' and '2 ranks on 1' in d['oversubscribed'] and 'OVERSUBSCRIBED' in d['config']['workload']
   else:
     assert d['dist_backend'] == 'nccl' and d['oversubscribed'] is None and d['rccl_version']
+
+
+def test_default_bench_line_carries_its_certificates():
+  """`python bench.py` as the driver runs it (fewer steps, no CPU baseline here): the ONE line carries the config-E parity record
+  (HIP vs float64 oracle, within the north star's 1e-3), the secondary lines of the other BASELINE configs and the sustained run,
+  top-level and as a compact copy inside `config` (the driver's record keeps `config` whole)."""
+  env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'BENCH_FORCE_DIST', 'BENCH_DIST_BACKEND', 'BENCH_SAME_DEVICE'):
+    env.pop(k, None)
+  r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup', '2', '--burn-in-s', '0.5', '--no-cpu-baseline',
+                      '--sustained-s', '1.0'], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+  assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+  d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+  ep = d['eval_parity']
+  assert ep['rays'] >= 256 and ep['pass'] and ep['max_abs_rgb'] <= 1e-3 and ep['max_abs_depth'] <= 1e-3 and ep['psnr_vs_oracle_db'] > 60, ep
+  modes = {(x['mode'], x['dtype']): x for x in d['secondary']}
+  assert set(modes) == {('vrig', 'f32'), ('fullhd', 'bf16'), ('eval_warp', 'f32')}, d['secondary']
+  for x in d['secondary']:
+    assert 'error' not in x and x['value'] > 0 and 0 < x['roofline']['frac'] < 1, x
+  assert d['sustained']['seconds'] >= 1.0 and 0.8 < d['sustained']['vs_headline'] < 1.25, d['sustained']
+  c = d['config']['certified_in_this_run']
+  assert c['eval_parity']['pass'] and len(c['secondary']) == 3 and c['sustained']['value'] > 0
+  assert list(d)[-3:] == ['eval_parity', 'secondary', 'sustained']     # the tail of the line

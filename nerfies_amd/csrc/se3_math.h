@@ -74,13 +74,46 @@ __device__ __forceinline__ Se3Coef<T> se3_coef(T t2) {
   return c;
 }
 
+// The same coefficients on Duals that share ONE value part (the warp Jacobian / its Hessian-vector products evaluate the closed
+// forms along three directions at the same (w, v, x): t2 = w.w has the same value and three tangents).  Every coefficient is a
+// function of t2 alone, so  X(Dual(t2, d)) = Dual(X, X'(t2) d):  values and t2-derivatives are formed ONCE (Se3CoefD) and each
+// direction costs six multiplies instead of a second evaluation of the divisions / sincos (round 6: the elastic kernel spent most
+// of its 6 k instructions re-deriving them six times).  From dX/dw = Xb w and dt2/dw = 2 w:
+//   A' = Ab / 2,  B' = Bb / 2,  C' = Cb / 2,  Ab' = (Cb - Bb) / 2,  Bb' = (Ab / 2 - 2 Bb) / t2,  Cb' = (Bb / 2 - 5 Cb / 2) / t2;
+// below t2 = 0.04 Bb' and Cb' are the derivatives of the Taylor polynomials above (no division by a small t2).
+struct Se3CoefD { Se3Coef<float> c; float dAb, dBb, dCb; };
+__device__ __forceinline__ Se3CoefD se3_coef_d(float t2) {
+  Se3CoefD r;
+  r.c = se3_coef<float>(t2);
+  r.dAb = 0.5f * (r.c.Cb - r.c.Bb);
+  if (t2 < 0.04f) {
+    r.dBb = 1.f / 180.f + t2 * (-1.f / 3360.f + t2 * (1.f / 151200.f));
+    r.dCb = 1.f / 1260.f + t2 * (-1.f / 30240.f + t2 * (1.f / 1663200.f));
+  } else {
+    const float it2 = 1.f / t2;
+    r.dBb = (0.5f * r.c.Ab - 2.f * r.c.Bb) * it2;
+    r.dCb = (0.5f * r.c.Bb - 2.5f * r.c.Cb) * it2;
+  }
+  return r;
+}
+// the Dual coefficients along a direction whose t2 tangent is t2d (= 2 w . wd)
+__device__ __forceinline__ Se3Coef<Dual> se3_coef_along(const Se3CoefD& k, float t2d) {
+  Se3Coef<Dual> c;
+  c.A = Dual(k.c.A, 0.5f * k.c.Ab * t2d); c.B = Dual(k.c.B, 0.5f * k.c.Bb * t2d); c.C = Dual(k.c.C, 0.5f * k.c.Cb * t2d);
+  c.Ab = Dual(k.c.Ab, k.dAb * t2d); c.Bb = Dual(k.c.Bb, k.dBb * t2d); c.Cb = Dual(k.c.Cb, k.dCb * t2d);
+  return c;
+}
+
 // x' - x = exp_se3([w; v]) x - x = A w*x + B w*(w*x) + v + B w*v + C w*(w*v)   (warping.py:330-344)
 template <typename T>
-__device__ __forceinline__ V3T<T> se3_delta(V3T<T> w, V3T<T> v, V3T<T> x) {
-  const Se3Coef<T> c = se3_coef<T>(dot(w, w));
+__device__ __forceinline__ V3T<T> se3_delta_c(const Se3Coef<T>& c, V3T<T> w, V3T<T> v, V3T<T> x) {
   const V3T<T> wx = cross(w, x), wv = cross(w, v);
   const V3T<T> wwx = cross(w, wx), wwv = cross(w, wv);
   return c.A * wx + c.B * wwx + v + c.B * wv + c.C * wwv;
+}
+template <typename T>
+__device__ __forceinline__ V3T<T> se3_delta(V3T<T> w, V3T<T> v, V3T<T> x) {
+  return se3_delta_c<T>(se3_coef<T>(dot(w, w)), w, v, x);
 }
 __device__ __forceinline__ V3 se3_apply(V3 w, V3 v, V3 x) { return x + se3_delta<float>(w, v, x); }
 
@@ -88,8 +121,7 @@ __device__ __forceinline__ V3 se3_apply(V3 w, V3 v, V3 x) { return x + se3_delta
 // carry no parameters).  On Duals the value parts are the VJP, the tangent parts its directional
 // derivative = the Hessian-vector product of g . exp_se3(w, v) x along the Dual direction.
 template <typename T>
-__device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, V3T<T>& dw, V3T<T>& dv) {
-  const Se3Coef<T> c = se3_coef<T>(dot(w, w));
+__device__ __forceinline__ void se3_vjp_c(const Se3Coef<T>& c, V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, V3T<T>& dw, V3T<T>& dv) {
   const V3T<T> gw = cross(g, w);            // g x w
   const V3T<T> wgw = cross(w, cross(w, g)); // w x (w x g)
   dv = g + c.B * gw + c.C * wgw;            // V^T g
@@ -99,6 +131,10 @@ __device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, 
   auto D = [&](V3T<T> y) { return wg * y + dot(w, y) * g - (T(2.f) * dot(y, g)) * w; };
   const T sa = c.Ab * dot(g, wx) + c.Bb * (dot(g, wwx) + dot(g, wv)) + c.Cb * dot(g, wwv);
   dw = c.A * cross(x, g) + c.B * (D(x) + cross(v, g)) + c.C * D(v) + sa * w;
+}
+template <typename T>
+__device__ __forceinline__ void se3_vjp(V3T<T> w, V3T<T> v, V3T<T> x, V3T<T> g, V3T<T>& dw, V3T<T>& dv) {
+  se3_vjp_c<T>(se3_coef<T>(dot(w, w)), w, v, x, g, dw, dv);
 }
 
 }  // namespace nrf

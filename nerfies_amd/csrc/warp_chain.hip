@@ -517,20 +517,29 @@ void launch_warp_bwd(const WarpBwdArgs& a, const WarpBwdArgs* a1, const WarpBwdA
 // elastic regulariser (training.compute_elastic_loss, training.py:71-114, 177-197; loss_type 'log_svals')
 // ---------------------------------------------------------------------------------------------
 // Symmetric 3x3 eigen-decomposition (cyclic Jacobi): D = V diag(mu) V^T.
+// Four sweeps: on 2e5 random J^T J - I of every scale the off-diagonal is <= 5e-12 |D| after the fourth (3e-5 after the third;
+// rounds 1-5 ran six, the last two on a diagonal matrix).  The rotation ANGLE only steers the convergence -- any (c, s) with
+// c^2 + s^2 = 1 is an exact similarity -- so theta and t = tan come from the hardware reciprocal / square root (1 ulp, no
+// IEEE division sequences: 3 of the 4 per rotation), and only c = rsqrt(1 + t^2) is refined to float accuracy (one Newton step).
 __device__ __forceinline__ void jacobi3(float (&D)[3][3], float (&V)[3][3]) {
 #pragma unroll
   for (int i = 0; i < 3; ++i)
 #pragma unroll
     for (int k = 0; k < 3; ++k) V[i][k] = i == k ? 1.f : 0.f;
-  for (int sweep = 0; sweep < 6; ++sweep) {
+#pragma unroll 1
+  for (int sweep = 0; sweep < 4; ++sweep) {
 #pragma unroll
     for (int pq = 0; pq < 3; ++pq) {
       const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
       const float apq = D[p][q];
-      if (fabsf(apq) < 1e-30f) continue;
-      const float theta = (D[q][q] - D[p][p]) / (2.f * apq);
-      const float t = (theta >= 0.f ? 1.f : -1.f) / (fabsf(theta) + sqrtf(theta * theta + 1.f));
-      const float c = 1.f / sqrtf(t * t + 1.f), s = t * c;
+      const bool live = fabsf(apq) >= 1e-30f;
+      const float theta = (D[q][q] - D[p][p]) * __builtin_amdgcn_rcpf(2.f * (live ? apq : 1.f));
+      const float t = copysignf(__builtin_amdgcn_rcpf(fabsf(theta) + __builtin_amdgcn_sqrtf(fmaf(theta, theta, 1.f))), theta);
+      const float u = fmaf(t, t, 1.f);
+      float c = __builtin_amdgcn_rsqf(u);
+      c = c * fmaf(-0.5f * u, c * c, 1.5f);          // Newton: c <- c (3 - u c^2) / 2
+      c = live ? c : 1.f;
+      const float s = live ? t * c : 0.f;
 #pragma unroll
       for (int k = 0; k < 3; ++k) {   // D <- D J
         const float dkp = D[k][p], dkq = D[k][q];
@@ -552,13 +561,14 @@ __device__ __forceinline__ void jacobi3(float (&D)[3][3], float (&V)[3][3]) {
 
 // E = J - I of one sample: column c = d/dx_c [exp_se3(w, v) x - x], from the raw head outputs (w, v), their tangents
 // (wd_c, vd_c) along x_c and the point x (Dual evaluation of se3_delta).
-__device__ __forceinline__ void warp_jacobian_minus_identity(V3 w, V3 v, V3 x, const V3 (&wd)[3], const V3 (&vd)[3], float (&E)[3][3]) {
+__device__ __forceinline__ void warp_jacobian_minus_identity(const Se3CoefD& kc, V3 w, V3 v, V3 x, const V3 (&wd)[3], const V3 (&vd)[3],
+                                                             float (&E)[3][3]) {
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
     const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
     const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
     const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
-    const V3T<Dual> dl = se3_delta<Dual>(W, Vv, X);
+    const V3T<Dual> dl = se3_delta_c<Dual>(se3_coef_along(kc, 2.f * dot(w, wd[c])), W, Vv, X);   // the coefficients: once per sample (se3_math.h)
     E[0][c] = dl.x.d; E[1][c] = dl.y.d; E[2][c] = dl.z.d;
   }
 }
@@ -572,13 +582,16 @@ __device__ __forceinline__ void warp_jacobian_minus_identity(V3 w, V3 v, V3 x, c
 // through exp_se3 comes from se3_vjp on Duals: value parts -> adjoints of (wd_c, vd_c), tangent parts (Hessian-vector
 // products) -> adjoints of the primal (w, v).  Also the Jacobian statistics of training.py:214-222.
 __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
+  // Per-thread 3x3 scratch (column = threadIdx.x: no two threads share a word, no barrier): E, later gs * d sq/dJ.  The three
+  // Dual evaluations of each phase run as a ROLLED loop over the column c -- a third of the straight-line code (the kernel
+  // executes every instruction once per wave, i.e. it streams its own text through the instruction cache), no 36 registers
+  // of (wd, vd, wdb, vdb) arrays; the tangents are re-read from L2 in the second loop instead.
+  __shared__ float e_s[9][256];
+  const int tid = threadIdx.x;
   const int row = blockIdx.x * blockDim.x + threadIdx.x;
   float rho_c = 0.f, res = 0.f, jdet = 0.f, jdiv = 0.f, jcurl = 0.f;
   if (row < A.rows_pad) {
     V3 wbar = v3(0.f, 0.f, 0.f), vbar = wbar;
-    V3 wdb[3], vdb[3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) wdb[c] = vdb[c] = v3(0.f, 0.f, 0.f);
     if (row < A.rows) {
       V3 x;
       if (A.x_rows) {   // bf16 trunk: the points are kept as plain fp32 rows
@@ -590,15 +603,22 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
       }
       const float4 w4 = A.prim_wv[2 * (size_t)row], v4 = A.prim_wv[2 * (size_t)row + 1];
       const V3 w = v3(w4.x, w4.y, w4.z), v = v3(v4.x, v4.y, v4.z);
-      V3 wd[3], vd[3];
+      const Se3CoefD kc = se3_coef_d(dot(w, w));   // shared by the three Jacobian columns and the three pull-backs below
       float E[3][3];
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
+#pragma unroll 1
+      for (int c = 0; c < 3; ++c) {   // E = J - I, column c = d/dx_c [exp_se3(w, v) x - x]  (Dual evaluation of se3_delta)
         const size_t tr = (size_t)c * A.rows_pad + row;
         const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
-        wd[c] = v3(a.x, a.y, a.z); vd[c] = v3(b.x, b.y, b.z);
+        const V3T<Dual> W = v3t<Dual>(Dual(w.x, a.x), Dual(w.y, a.y), Dual(w.z, a.z));
+        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, b.x), Dual(v.y, b.y), Dual(v.z, b.z));
+        const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
+        const V3T<Dual> dl = se3_delta_c<Dual>(se3_coef_along(kc, 2.f * (w.x * a.x + w.y * a.y + w.z * a.z)), W, Vv, X);
+        e_s[c][tid] = dl.x.d; e_s[3 + c][tid] = dl.y.d; e_s[6 + c][tid] = dl.z.d;
       }
-      warp_jacobian_minus_identity(w, v, x, wd, vd, E);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) E[i][k] = e_s[3 * i + k][tid];
       // det J - 1 = tr E + (principal 2x2 minors of E) + det E: no cancellation near the identity
       const float trE = E[0][0] + E[1][1] + E[2][2];
       const float m2 = (E[0][0] * E[1][1] - E[0][1] * E[1][0]) + (E[0][0] * E[2][2] - E[0][2] * E[2][0]) + (E[1][1] * E[2][2] - E[1][2] * E[2][1]);
@@ -686,22 +706,30 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
       res = (A.res_selected && coef == 0.f) ? 0.f : sqrtf(sq);
       const float gs = coef * (A.dyn ? A.dyn->elastic_loss_weight * A.inv_rays : A.gscale) * drho;
 #pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) e_s[3 * i + k][tid] = gs * Gd[i][k];
+#pragma unroll 1
       for (int c = 0; c < 3; ++c) {
-        const V3T<Dual> W = v3t<Dual>(Dual(w.x, wd[c].x), Dual(w.y, wd[c].y), Dual(w.z, wd[c].z));
-        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, vd[c].x), Dual(v.y, vd[c].y), Dual(v.z, vd[c].z));
+        const size_t tr = (size_t)c * A.rows_pad + row;
+        const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
+        const V3T<Dual> W = v3t<Dual>(Dual(w.x, a.x), Dual(w.y, a.y), Dual(w.z, a.z));
+        const V3T<Dual> Vv = v3t<Dual>(Dual(v.x, b.x), Dual(v.y, b.y), Dual(v.z, b.z));
         const V3T<Dual> X = v3t<Dual>(Dual(x.x, c == 0 ? 1.f : 0.f), Dual(x.y, c == 1 ? 1.f : 0.f), Dual(x.z, c == 2 ? 1.f : 0.f));
-        const V3T<Dual> g = v3t<Dual>(Dual(gs * Gd[0][c]), Dual(gs * Gd[1][c]), Dual(gs * Gd[2][c]));
+        const V3T<Dual> g = v3t<Dual>(Dual(e_s[c][tid]), Dual(e_s[3 + c][tid]), Dual(e_s[6 + c][tid]));
         V3T<Dual> dw, dv;
-        se3_vjp<Dual>(W, Vv, X, g, dw, dv);
-        wdb[c] = v3(dw.x.v, dw.y.v, dw.z.v); vdb[c] = v3(dv.x.v, dv.y.v, dv.z.v);
+        se3_vjp_c<Dual>(se3_coef_along(kc, 2.f * (w.x * a.x + w.y * a.y + w.z * a.z)), W, Vv, X, g, dw, dv);
+        A.tan_dw4[tr] = make_float4(dw.x.v, dw.y.v, dw.z.v, 0.f);
+        A.tan_dv4[tr] = make_float4(dv.x.v, dv.y.v, dv.z.v, 0.f);
         wbar = wbar + v3(dw.x.d, dw.y.d, dw.z.d); vbar = vbar + v3(dv.x.d, dv.y.d, dv.z.d);
       }
-    }
+    } else {   // padding rows of the last 256-row iteration: the reverse tangent pass reads them
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      const size_t tr = (size_t)c * A.rows_pad + row;
-      A.tan_dw4[tr] = make_float4(wdb[c].x, wdb[c].y, wdb[c].z, 0.f);
-      A.tan_dv4[tr] = make_float4(vdb[c].x, vdb[c].y, vdb[c].z, 0.f);
+      for (int c = 0; c < 3; ++c) {
+        const size_t tr = (size_t)c * A.rows_pad + row;
+        A.tan_dw4[tr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        A.tan_dv4[tr] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     A.prim_dw4[row] = make_float4(wbar.x, wbar.y, wbar.z, 0.f);
     A.prim_dv4[row] = make_float4(vbar.x, vbar.y, vbar.z, 0.f);
@@ -741,7 +769,8 @@ __global__ __launch_bounds__(256) void jacobian_kernel(const JacobianArgs A) {
     wd[c] = v3(a.x, a.y, a.z); vd[c] = v3(b.x, b.y, b.z);
   }
   float E[3][3];
-  warp_jacobian_minus_identity(v3(w4.x, w4.y, w4.z), v3(v4.x, v4.y, v4.z), x, wd, vd, E);
+  const V3 wj = v3(w4.x, w4.y, w4.z);
+  warp_jacobian_minus_identity(se3_coef_d(dot(wj, wj)), wj, v3(v4.x, v4.y, v4.z), x, wd, vd, E);
   float* o = A.out + (size_t)row * 9;
 #pragma unroll
   for (int i = 0; i < 3; ++i)

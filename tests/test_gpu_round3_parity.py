@@ -254,3 +254,31 @@ def test_graphed_renderer_keys_on_time_alpha():
   assert (a['fine']['rgb'] - c['fine']['rgb']).abs().max().item() > 1e-5   # the window does change the render
   again = fn(0, 1, fp, rays, {'alpha': 2.0, 'time_alpha': 0.25})              # ... and the first graph is still there
   assert fn.captures == 2 and torch.equal(again['fine']['rgb'], a['fine']['rgb'])
+
+
+def test_graphed_renderer_serves_dataset_items_and_camera_frames():
+  """eval.py shares ONE renderer between val / train items (datasets.item_rays: 'rgb' and 'pixels' ride along) and
+  test-camera frames (rays_from_camera: neither); the replay used to refuse the second kind ("rays has keys ...").  Only the
+  keys NerfModel.apply consumes are captured and copied, so both replay the same graph; a ray tree that lacks a consumed key
+  the capture had is still refused."""
+  from nerfies_amd import evaluation, lib as L
+  spec = O.ModelSpec(num_coarse_samples=16, num_fine_samples=16, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                     num_warp_freqs=4)
+  p = O.init_params(spec, seed=7, trained_like=True, dtype=torch.float64)
+  gb = H.gpu_batch(O.synthetic_batch(40, seed=8, dtype=torch.float64))
+  model, fp = H.gpu_model(spec, p, 40)
+  md = {'warp': gb['metadata']['warp']}
+  item = {'origins': gb['origins'], 'directions': gb['directions'], 'rgb': gb['rgb'], 'pixels': gb['origins'][:, :2].clone(), 'metadata': md}
+  frame = {'origins': gb['origins'].flip(0).contiguous(), 'directions': gb['directions'].flip(0).contiguous(),
+           'metadata': {'warp': md['warp'].flip(0).contiguous()}}
+  fn = evaluation.GraphedChunkRenderer(model)
+  a = fn(0, 1, fp, item, {'alpha': 2.0})
+  b = fn(0, 1, fp, frame, {'alpha': 2.0})       # no 'rgb' / 'pixels': same slot, a replay
+  assert fn.captures == 1
+  assert torch.equal(a['fine']['rgb'], b['fine']['rgb'].flip(0))
+  direct = model.apply({'params': fp}, frame, {'alpha': 2.0})
+  assert torch.equal(b['fine']['rgb'], direct['fine']['rgb'])
+  c = fn(0, 1, fp, dict(frame, viewdirs=frame['directions'].clone()), {'alpha': 2.0})   # another consumed key set: its own graph
+  assert fn.captures == 2 and torch.equal(c['fine']['rgb'], b['fine']['rgb'])
+  with pytest.raises(L.NrfError):                # same slot key, other shape of a consumed tensor
+    fn(0, 1, fp, dict(frame, metadata={'warp': md['warp'].reshape(-1)}), {'alpha': 2.0})

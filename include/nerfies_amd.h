@@ -37,7 +37,13 @@
 extern "C" {
 #endif
 
-#define NRF_VERSION 500 /* 0.5.0: nrf_set_option (NRF_OPT_CHAIN_TILE_ROWS: 32-row tiling of the fp32 chains).
+#define NRF_VERSION 600 /* 0.6.0: nrf_model_desc grows warp_trunk_depth / warp_trunk_width (SE3Field / TranslationField trunk_depth <= 6,
+                           trunk_width <= 128 of ModelConfig.warp_kwargs); nerf_skip_layer accepts any single index 1..7 (float32
+                           mode; the bfloat16 mode where the trunk can be laid out around the chains' layer 4).  Behaviour change
+                           since 0.5.0: the flag word is validated on every entry point -- NRF_FLAG_TRAIN | NRF_FLAG_NO_WARP is refused
+                           also for models without a warp field (it used to be a no-op there), NRF_FLAG_WARP_F32 without NRF_FLAG_BF16
+                           is refused by nrf_train_step_loss_grad_ex as well.
+                           0.5.0: nrf_set_option (NRF_OPT_CHAIN_TILE_ROWS: 32-row tiling of the fp32 chains).
                            0.4.0: NRF_FLAG_BF16 also runs the SE3 trunk in bfloat16 (NRF_FLAG_WARP_F32 opts out).
                            0.3.0: device-resident per-step scalars (a whole train step replays from one hipGraph), background ids /
                            noise drawn by the library, `points` output without the warp field.
@@ -70,7 +76,10 @@ typedef struct nrf_model_desc {
   int32_t nerf_trunk_width;        /* <= 256; the kernels are 256 wide, narrower trunks run zero-padded (test_vrig.gin: 128) */
   int32_t nerf_rgb_branch_depth;   /* 1   */
   int32_t nerf_rgb_branch_width;   /* <= 128 (same) */
-  int32_t nerf_skip_layer;         /* nerf_skips = (4,)  -> 4; -1 = none (or any index >= nerf_trunk_depth: never reached) */
+  int32_t nerf_skip_layer;         /* nerf_skips = (s,) -> s in 1..7 (modules.py:47-48: layer s reads [h, posenc]); -1 = none (or any index
+                                      >= nerf_trunk_depth: never reached).  s <= 4 with nerf_trunk_depth - s <= 4 is laid out around the chains'
+                                      own skip at layer 4 (identity layers in between: exact) and runs in every mode; any other s runs
+                                      the float32 chains with the skip GEMM at layer s (NRF_FLAG_BF16 -> NRF_E_UNSUPPORTED) */
   int32_t use_stratified_sampling; /* models.py:88; eval.py:239 forces 0 */
   int32_t num_nerf_point_freqs;    /* models.py:89  */
   int32_t num_nerf_viewdir_freqs;  /* models.py:90  */
@@ -100,6 +109,13 @@ typedef struct nrf_model_desc {
   int32_t warp_metadata_encoder_type; /* NRF_META_GLO (every preset) or NRF_META_TIME: modules.TimeEncoder on
                                       metadata['time'] (modules.py:297-322, warping.py:256-259, models.py:252-254) */
   int32_t num_time_encoder_freqs;  /* metadata_encoder_num_freqs (warping.py:234): 1 */
+  /* ModelConfig.warp_kwargs (configs.py:105) that reach the trunk of SE3Field / TranslationField (warping.py:225-227, 80-82):
+   * 0 = the field's default.  A shallower / narrower trunk runs on the 6 x 128 kernels with identity layers behind its last one and
+   * zero padding (exact); `skips` stays (4,) -- a trunk of <= 4 layers never reaches it.  The other warp_kwargs (rotation /
+   * pivot / translation branch depths, use_pivot, use_translation, activation, min / max_freq_log2) are not built: the Python
+   * host refuses them unless they equal the field's defaults. */
+  int32_t warp_trunk_depth;        /* 1..6, 0 -> 6   */
+  int32_t warp_trunk_width;        /* 1..128, 0 -> 128 */
 } nrf_model_desc;
 
 typedef struct nrf_handle_s* nrf_handle;

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void nerf_mlp_fwd_kernel(const ChainFwdArgs
         mfma_k_loop<2, false>(acc, pe, nq_pe, wL0, lane, wnext);
       } else {
         mfma_k_loop<2, true>(acc, act, 16, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane, wnext);
-        if (l == SKIP_LAYER) {
+        if (l == A.skip) {
           const float4* w4b = wpk4 + (A.pk.fwd_L4b / 4) + wave * (PK / 4) * 64;
           mfma_k_loop<2, false>(acc, pe, nq_pe, w4b, lane, prefetch_quad<2>(w4b, lane));
         }
@@ -494,9 +494,9 @@ __device__ __forceinline__ void bwd_tile(const ChainBwdArgs& A, const int tile, 
       // ---- warp on: d posenc = dpre_4 . W4[256:]^T + dpre_0 . W0^T  (256 -> PK columns).  Wave w owns
       //      MFMA row block w&1 (tile rows 2i + rb) x column block w>>1; the result goes to the dpe tile
       //      in LDS (aliases dr, dead since the l = 8 step), element (n, row) at n*64 + (row ^ (n & 31)). ----
-      if (A.d_points && (l - 1 == SKIP_LAYER || l == 1)) {
+      if (A.d_points && (l - 1 == A.skip || l == 1)) {
         float* dpe = dr;
-        const bool first = (l - 1 == SKIP_LAYER);
+        const bool first = (l - 1 == A.skip);
         int ln = lane;
         asm volatile("" : "+v"(ln));   // opaque: the per-lane constants of this section are recomputed here, not hoisted out of
                                        // the tile loop into registers that live (= spill) across the trunk layers

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256, 4) void nerf_mlp_fwd32_kernel(const ChainFwd32
         k_loop32<false>(acc, pe, nq_pe, wL0, lane, wnext);
       } else {
         k_loop32<true>(acc, act, 16, wpk4 + (A.pk.fwd_L[l] / 4) + wave * 64 * 64, lane, wnext);
-        if (l == SKIP_LAYER) {
+        if (l == A.skip) {
           const float4* w4b = wpk4 + (A.pk.fwd_L4b / 4) + wave * (PK / 4) * 64;
           k_loop32<false>(acc, pe, nq_pe, w4b, lane, prefetch_quad<2>(w4b, lane));
         }

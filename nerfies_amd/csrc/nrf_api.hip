@@ -209,7 +209,9 @@ struct nrf_handle_s {
   WsPlan plan;
   // identity of the tables last uploaded to a workspace, and of the last stashed forward
   void* uploaded_ws = nullptr;
-  int xdepth = TRUNK_DEPTH, xskip = SKIP_LAYER;   // the caller's trunk (<= 8 layers; skip 4 or none): nrf_create
+  int xdepth = TRUNK_DEPTH, xskip = SKIP_LAYER;   // the caller's trunk (<= 8 layers; its skip index or -1): nrf_create
+  int emap[TRUNK_DEPTH];                          // internal trunk layer -> the caller's layer, or -1 (identity layer)
+  int wxdepth = WARP_DEPTH, wxwidth = WARP_W;     // the caller's warp trunk (warp_kwargs trunk_depth / trunk_width)
   int uploaded_B = -1;
   uint32_t uploaded_flags = 0;
   int uploaded_bgN = 0;
@@ -268,18 +270,20 @@ void build_layout(nrf_handle h) {
     MlpParamOffsets& po = h->po[lv];
     for (int i = 0; i < TRUNK_DEPTH; ++i) {
       const int hid = i == 0 ? 0 : 1;                 // rows of the running activation, then (layer 0 / skip) the posenc rows
-      const int pe = (i == 0 || i == SKIP_LAYER) ? h->P : 0;
-      const int xpe = (i == 0 || i == h->xskip) ? h->P : 0;   // a skip the caller's trunk never reaches: zero posenc rows inside
+      const int e = h->emap[i];                       // the caller's layer that runs here, or -1: an identity layer
+      const int pe = (i == 0 || i == d.nerf_skip_layer) ? h->P : 0;
+      const int xpe = (e == 0 || (e >= 0 && e == h->xskip)) ? h->P : 0;   // a skip the caller's trunk never reaches: zero posenc rows inside
       const std::string kn = base + "/MLP_0/hidden_" + std::to_string(i) + "/kernel", bn = base + "/MLP_0/hidden_" + std::to_string(i) + "/bias";
-      if (i < h->xdepth) {
-        add_leaf(h, kn, hid * W + pe, W, &po.trunk_k[i], hid * XW + xpe, XW, hid * XW);
-        add_leaf(h, bn, 1, W, &po.trunk_b[i], 1, XW);
-      } else {   // behind the caller's last layer: internal-only identity (its gradient is dropped)
+      if (e >= 0) {
+        const std::string xkn = base + "/MLP_0/hidden_" + std::to_string(e) + "/kernel", xbn = base + "/MLP_0/hidden_" + std::to_string(e) + "/bias";
+        add_leaf(h, kn, hid * W + pe, W, &po.trunk_k[i], hid * XW + xpe, XW, hid * XW, nullptr, e != i ? xkn.c_str() : nullptr);
+        add_leaf(h, bn, 1, W, &po.trunk_b[i], 1, XW, -1, nullptr, e != i ? xbn.c_str() : nullptr);
+      } else {   // between / behind the caller's layers: internal-only identity (relu(h . I) = h for h >= 0; its gradient is dropped)
         add_leaf(h, kn, hid * W + pe, W, &po.trunk_k[i], -1, -1, -1, nullptr, "");
         add_leaf(h, bn, 1, W, &po.trunk_b[i], -1, -1, -1, nullptr, "");
-        EmbedDesc e;
-        e.ext_off = -1; e.int_off = po.trunk_k[i]; e.rows = XW; e.ext_cols = 1; e.int_cols = W; e.split = XW; e.shift = 0; e.pad_ = 0;
-        h->emb.push_back(e);
+        EmbedDesc e2;
+        e2.ext_off = -1; e2.int_off = po.trunk_k[i]; e2.rows = XW; e2.ext_cols = 1; e2.int_cols = W; e2.split = XW; e2.shift = 0; e2.pad_ = 0;
+        h->emb.push_back(e2);
       }
       if (xpe != pe) h->embed = true;
     }
@@ -324,18 +328,29 @@ void build_layout(nrf_handle h) {
     // theta^2 there).  Its leaves 'warp_field/mlp/hidden_i' / 'mlp/logit' map onto trunk / branches_v; branches_w
     // exists only internally and stays zero.
     const bool tr = d.warp_field_type == NRF_WARP_TRANSLATION;
+    // warp_kwargs trunk_depth / trunk_width (warping.py:225-227): a shallower / narrower trunk runs on the 6 x 128 kernels --
+    // identity layers behind the caller's last one (every trunk layer ends in a ReLU: modules.py:41-50), zero padding to 128
+    // columns, zero input rows in the skip layer when the caller's trunk (<= 4 layers) never reaches it
+    const int XD = h->wxdepth, XWw = h->wxwidth;
     for (int i = 0; i < WARP_DEPTH; ++i) {
-      int fin = i == 0 ? h->Win : WARP_W;
-      if (i == WARP_SKIP) fin += h->Win;
+      const int hid = i == 0 ? 0 : 1;
+      const int pe = (i == 0 || i == WARP_SKIP) ? h->Win : 0;
+      const std::string nk = "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", nb = "warp_field/trunk/hidden_" + std::to_string(i) + "/bias";
       const std::string xk = "warp_field/mlp/hidden_" + std::to_string(i) + "/kernel", xb = "warp_field/mlp/hidden_" + std::to_string(i) + "/bias";
-      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/kernel", fin, WARP_W, &w.trunk_k[i], -1, -1, -1, &x.trunk_k[i],
-               tr ? xk.c_str() : nullptr);
-      add_leaf(h, "warp_field/trunk/hidden_" + std::to_string(i) + "/bias", 1, WARP_W, &w.trunk_b[i], -1, -1, -1, &x.trunk_b[i],
-               tr ? xb.c_str() : nullptr);
+      if (i < XD) {
+        add_leaf(h, nk, hid * WARP_W + pe, WARP_W, &w.trunk_k[i], hid * XWw + pe, XWw, hid * XWw, &x.trunk_k[i], tr ? xk.c_str() : nullptr);
+        add_leaf(h, nb, 1, WARP_W, &w.trunk_b[i], 1, XWw, -1, &x.trunk_b[i], tr ? xb.c_str() : nullptr);
+      } else {
+        add_leaf(h, nk, hid * WARP_W + pe, WARP_W, &w.trunk_k[i], -1, -1, -1, nullptr, "");
+        add_leaf(h, nb, 1, WARP_W, &w.trunk_b[i], -1, -1, -1, nullptr, "");
+        EmbedDesc e;
+        e.ext_off = -1; e.int_off = w.trunk_k[i]; e.rows = XWw; e.ext_cols = 1; e.int_cols = WARP_W; e.split = XWw; e.shift = 0; e.pad_ = 0;
+        h->emb.push_back(e);
+      }
     }
-    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k, -1, -1, -1, &x.w_k, tr ? "" : nullptr);
+    add_leaf(h, "warp_field/branches_w/logit/kernel", WARP_W, 3, &w.w_k, XWw, 3, -1, &x.w_k, tr ? "" : nullptr);
     add_leaf(h, "warp_field/branches_w/logit/bias", 1, 3, &w.w_b, -1, -1, -1, &x.w_b, tr ? "" : nullptr);
-    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k, -1, -1, -1, &x.v_k, tr ? "warp_field/mlp/logit/kernel" : nullptr);
+    add_leaf(h, "warp_field/branches_v/logit/kernel", WARP_W, 3, &w.v_k, XWw, 3, -1, &x.v_k, tr ? "warp_field/mlp/logit/kernel" : nullptr);
     add_leaf(h, "warp_field/branches_v/logit/bias", 1, 3, &w.v_b, -1, -1, -1, &x.v_b, tr ? "warp_field/mlp/logit/bias" : nullptr);
   }
   if (d.use_appearance_metadata)
@@ -1248,7 +1263,7 @@ ChainFwdArgs fwd_args(nrf_handle h, int lv, const float* params, const nrf_rays*
   a.condterm = ws + L.condterm; a.zvals = ws + L.z; a.origins = rays->origins; a.directions = rays->directions;
   a.points = nullptr; a.out4 = reinterpret_cast<float4*>(ws + L.out4);
   a.S = p.S[lv]; a.B = p.B; a.rows = p.rows[lv]; a.ntiles = p.ntiles[lv];
-  a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation;
+  a.F = h->d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.sigma_act = h->d.sigma_activation; a.skip = h->d.nerf_skip_layer;
   a.tile_counter = tile_counter_or_null(ws + p.counters, CT_MLP_FWD + lv);
   a.timeline = knobs().timeline ? reinterpret_cast<unsigned long long*>(ws + p.timeline) + lv * (256 + 512 + 4 * 2048) : nullptr;
   a.alpha_ct = h->A > 0 ? ws + L.alpha_ct : nullptr;
@@ -1632,7 +1647,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
       a.dy_trunk = ws + L.dy_trunk; a.dy_bn = ws + L.dy_bn; a.dy_rgbh = ws + L.dy_rgbh; a.dray = ws + L.dray;
       a.small_part = ws + L.small_part;
       if (warp_on) { a.d_points = ws + L.d_points; a.st_pe = ws + L.st_pe; }
-      a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK;
+      a.F = d.num_nerf_point_freqs; a.P = h->P; a.PK = h->PK; a.skip = d.nerf_skip_layer;
       a.alpha_on_bn = h->A > 0 ? 1 : 0;
       nt_all += p.ntiles[lv];
     }
@@ -1833,12 +1848,18 @@ const char* nrf_last_error(void) { return g_err; }
 int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   if (!desc || !out) return fail(NRF_E_NULL, "desc / out is null");
   const nrf_model_desc& d = *desc;
-  // the chains are built for 8 trunk layers with the skip at layer 4.  A SHALLOWER trunk runs on them with internal identity layers
-  // behind its last one (relu(h . I) = h for h >= 0: exact), a trunk whose skip is never reached (nerf_skips = () or skip >= depth)
-  // with zero posenc rows in layer 4 -- modules.MLP (modules.py:41-62) concatenates the inputs in front of layer i for i in skips
+  // The chains run 8 trunk layers with ONE layer that reads [h, posenc] (modules.py:41-62 concatenates the inputs in front of layer i
+  // for i in skips).  The caller's trunk (depth xd <= 8, skip xs) is laid out on them:
+  //   * no skip reached (nerf_skips = () or xs >= xd): layers 0..xd-1, zero posenc rows in layer 4, identity layers behind;
+  //   * xs <= 4 and xd - xs <= 4: layers 0..xs-1, IDENTITY layers xs..3 (relu(h . I) = h for h >= 0: exact, also on the bf16 chain),
+  //     the caller's skip layer at 4, the rest behind it -- the kernels' own layout, every mode;
+  //   * any other xs in 1..7: layers in place, the skip GEMM moves to layer xs (float32 chains only: a run-time layer index there,
+  //     a compile-time position in the bf16 stream).
   const bool skip_reached = d.nerf_skip_layer >= 0 && d.nerf_skip_layer < d.nerf_trunk_depth;
-  if (d.nerf_trunk_depth < 1 || d.nerf_trunk_depth > TRUNK_DEPTH || (skip_reached && d.nerf_skip_layer != SKIP_LAYER))
-    return fail(NRF_E_UNSUPPORTED, "MFMA chain is built for a trunk of at most 8 layers with the skip at layer 4 (or none)");
+  if (d.nerf_trunk_depth < 1 || d.nerf_trunk_depth > TRUNK_DEPTH)
+    return fail(NRF_E_UNSUPPORTED, "nerf_trunk_depth must be in [1,8]");
+  if (skip_reached && d.nerf_skip_layer == 0)   // layer 0 would read [posenc, posenc]: two blocks of one leaf on the same rows
+    return fail(NRF_E_UNSUPPORTED, "nerf_skips = (0,) (the first layer reading its input twice) is not built");
   if (d.nerf_trunk_width < 1 || d.nerf_trunk_width > TRUNK_W)   // narrower trunks run zero-padded (test_vrig.gin: 128)
     return fail(NRF_E_UNSUPPORTED, "nerf_trunk_width must be in [1,256]");
   if (d.nerf_rgb_branch_depth != 1 || d.nerf_rgb_branch_width < 1 || d.nerf_rgb_branch_width > RGB_W)
@@ -1857,6 +1878,8 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
     if (d.num_warp_freqs < 0 || d.num_warp_freqs > 8) return fail(NRF_E_SHAPE, "num_warp_freqs must be in [0,8]");
     if (d.num_warp_features < 1 || d.num_warp_features > 8) return fail(NRF_E_SHAPE, "num_warp_features must be in [1,8]");
     if (d.num_warp_embeddings < 1 && d.warp_metadata_encoder_type != NRF_META_TIME) return fail(NRF_E_SHAPE, "num_warp_embeddings must be positive");
+    if (d.warp_trunk_depth < 0 || d.warp_trunk_depth > WARP_DEPTH) return fail(NRF_E_UNSUPPORTED, "warp_trunk_depth must be in [1,6] (0 = 6)");
+    if (d.warp_trunk_width < 0 || d.warp_trunk_width > WARP_W) return fail(NRF_E_UNSUPPORTED, "warp_trunk_width must be in [1,128] (0 = 128)");
   }
   if (d.num_coarse_samples < 3 || d.num_coarse_samples > 256) return fail(NRF_E_SHAPE, "num_coarse_samples must be in [3,256]");
   if (d.num_fine_samples < 0 || d.num_coarse_samples + d.num_fine_samples > 512)
@@ -1866,8 +1889,20 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
   if (d.sigma_activation != NRF_ACT_RELU && d.sigma_activation != NRF_ACT_SOFTPLUS) return fail(NRF_E_UNSUPPORTED, "sigma_activation");
   nrf_handle h = new nrf_handle_s();
   h->d = d;
-  h->xdepth = d.nerf_trunk_depth; h->xskip = skip_reached ? SKIP_LAYER : -1;   // what the caller's tree holds
-  h->d.nerf_trunk_depth = TRUNK_DEPTH; h->d.nerf_skip_layer = SKIP_LAYER;        // what the kernels run
+  {
+    const int xd = d.nerf_trunk_depth, xs = skip_reached ? d.nerf_skip_layer : -1;
+    h->xdepth = xd; h->xskip = xs;                                              // what the caller's tree holds
+    int imap[TRUNK_DEPTH], K = SKIP_LAYER;
+    for (int i = 0; i < TRUNK_DEPTH; ++i) imap[i] = i;
+    if (xs >= 0 && xs <= SKIP_LAYER && xd - xs <= TRUNK_DEPTH - SKIP_LAYER) {
+      for (int i = xs; i < xd; ++i) imap[i] = SKIP_LAYER + (i - xs);
+    } else if (xs >= 0) {
+      K = xs;
+    }
+    for (int i = 0; i < TRUNK_DEPTH; ++i) h->emap[i] = -1;
+    for (int i = 0; i < xd; ++i) h->emap[imap[i]] = i;
+    h->d.nerf_trunk_depth = TRUNK_DEPTH; h->d.nerf_skip_layer = K;                // what the kernels run
+  }
   h->nlevels = d.num_fine_samples > 0 ? 2 : 1;
   h->P = 3 + 6 * d.num_nerf_point_freqs;
   h->PK = (h->P + 15) / 16 * 16;                  // K of the posenc GEMMs: whole 16-k quads of the MFMA loop
@@ -1879,6 +1914,8 @@ int nrf_create(const nrf_model_desc* desc, nrf_handle* out) {
     h->time_enc = d.warp_metadata_encoder_type == NRF_META_TIME;
     h->Ft = d.num_time_encoder_freqs; h->Tin = 1 + 2 * h->Ft;   // AnnealedSinusoidalEncoder of the scalar time stamp
     h->Fw = d.num_warp_freqs; h->G = d.num_warp_features;
+    h->wxdepth = d.warp_trunk_depth ? d.warp_trunk_depth : WARP_DEPTH;
+    h->wxwidth = d.warp_trunk_width ? d.warp_trunk_width : WARP_W;
     h->Win = 3 + 6 * h->Fw + h->G;                 // [annealed posenc, GLO code] (warping.py:326-327)
     h->PKw = (h->Win + 15) / 16 * 16;
   }
@@ -1914,7 +1951,7 @@ int nrf_param_layout(nrf_handle h, nrf_tensor_info* out, int32_t* n) {
 // The flag word of nrf_forward / nrf_workspace_bytes*: unknown bits and contradictory combinations are refused up front
 // (they used to pass through: NRF_FLAG_WARP_F32 without NRF_FLAG_BF16 was silently ignored, and TRAIN | WARP_JACOBIAN sized a
 // workspace for a plan no call can run).
-static int check_flags(uint32_t flags) {
+static int check_flags(const nrf_handle_s* h, uint32_t flags) {
   const uint32_t known = NRF_FLAG_TRAIN | NRF_FLAG_NO_WARP | NRF_FLAG_BF16 | NRF_FLAG_WARP_JACOBIAN | NRF_FLAG_WARP_F32;
   if (flags & ~known) return fail(NRF_E_UNSUPPORTED, "unknown bits in flags");
   if ((flags & NRF_FLAG_WARP_F32) && !(flags & NRF_FLAG_BF16))
@@ -1923,13 +1960,16 @@ static int check_flags(uint32_t flags) {
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_JACOBIAN is an inference output (training consumes the Jacobian through nrf_elastic)");
   if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_NO_WARP))
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
+  if ((flags & NRF_FLAG_BF16) && h->d.nerf_skip_layer != SKIP_LAYER)
+    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16: the bfloat16 chains run the skip at trunk layer 4; this model's nerf_skips cannot be laid out "
+                                   "around it (needs skip <= 4 and depth - skip <= 4): use the float32 mode");
   return NRF_OK;
 }
 
 int nrf_workspace_bytes(nrf_handle h, int32_t num_rays, uint32_t flags, size_t* bytes) {
   if (!h || !bytes) return fail(NRF_E_NULL, "null");
   if (num_rays <= 0) return fail(NRF_E_SHAPE, "num_rays must be positive");
-  CK(check_flags(flags));
+  CK(check_flags(h, flags));
   query_device(h);
   build_plan(h, num_rays, flags);
   *bytes = h->plan.total_floats * sizeof(float);
@@ -1940,7 +1980,7 @@ int nrf_forward(nrf_handle h, const float* params, const nrf_rays* rays, const n
                 const nrf_rand* rnd, const nrf_outputs* out, uint32_t flags, void* workspace, size_t workspace_bytes,
                 void* stream) {
   if (!h) return fail(NRF_E_NULL, "handle is null");
-  CK(check_flags(flags));
+  CK(check_flags(h, flags));
   return forward_impl(h, params, rays, scalars, rnd, out, flags, (float*)workspace, workspace_bytes, (hipStream_t)stream);
 }
 
@@ -1980,7 +2020,7 @@ int nrf_train_step_loss_grad_ex(nrf_handle h, const float* params, const nrf_ray
                                 void* workspace, size_t workspace_bytes, void* stream) {
   if (!h || !target_rgb || !grad_params) return fail(NRF_E_NULL, "null argument");
   if (flags & ~(uint32_t)(NRF_FLAG_BF16 | NRF_FLAG_WARP_F32)) return fail(NRF_E_UNSUPPORTED, "nrf_train_step_loss_grad_ex flags: 0, NRF_FLAG_BF16 [| NRF_FLAG_WARP_F32]");
-  CK(check_flags(NRF_FLAG_TRAIN | flags));   // the same word nrf_workspace_bytes_ex validated (WARP_F32 without BF16 is refused here too)
+  CK(check_flags(h, NRF_FLAG_TRAIN | flags));   // the same word nrf_workspace_bytes_ex validated (WARP_F32 without BF16 is refused here too)
   int bgN = 0;
   if (el) {
     if (!h->warp) return fail(NRF_E_UNSUPPORTED, "the elastic regulariser needs the warp field");
@@ -2013,7 +2053,7 @@ int nrf_workspace_bytes_ex(nrf_handle h, int32_t num_rays, uint32_t flags, int32
   if (num_rays <= 0 || num_background_points < 0) return fail(NRF_E_SHAPE, "bad sizes");
   if ((num_background_points > 0 || use_elastic_loss) && !h->warp)
     return fail(NRF_E_UNSUPPORTED, "the background / elastic regularisers need the warp field");
-  CK(check_flags(flags));
+  CK(check_flags(h, flags));
   query_device(h);
   const bool tr = flags & NRF_FLAG_TRAIN;
   build_plan(h, num_rays, flags, tr ? num_background_points : 0, tr && use_elastic_loss ? 1 : 0);
@@ -2036,7 +2076,8 @@ WarpPointsPlan warp_points_plan(nrf_handle h, int n) {
   q.out_f = take((size_t)q.ntiles * TILE_ROWS * 3);
   q.ctr_f = take(16);
   q.emb_f = q.ip_f = 0;
-  if (h->d.warp_field_type == NRF_WARP_TRANSLATION) {   // no rotation head in the caller's tree: run on the padded image
+  if (h->d.warp_field_type == NRF_WARP_TRANSLATION || h->wxdepth != WARP_DEPTH || h->wxwidth != WARP_W) {
+    // no rotation head in the caller's tree, or a trunk shallower / narrower than the kernels': run on the padded image
     q.emb_f = take((h->emb.size() + 1) * sizeof(EmbedDesc) / 4);
     q.ip_f = take((size_t)h->nparams);
   }

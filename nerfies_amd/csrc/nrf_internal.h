@@ -179,6 +179,7 @@ struct ChainFwdArgs {
   float4* out4;              // [ntiles*128] (r,g,b,sigma) post-activation
   int S, B, rows, ntiles;
   int F, P, PK;              // point freqs, 3+6F, P rounded up to a multiple of 16
+  int skip;                  // trunk layer that reads [h, posenc] (modules.py:47-48): 4 unless the model asks for another (float32 chains)
   int sigma_act;
   int* tile_counter;         // zeroed before the launch: dynamic tile hand-out (chain_common.h next_tile)
   int k_old;                 // > 0: uneven static split, tiles of the older workgroup of a CU (chain_common.h tile_iter)
@@ -222,6 +223,7 @@ struct ChainBwdArgs {
   float* d_points;           // [ntiles*128][3] or nullptr
   const float* st_pe;        // posenc stash of the forward pass
   int F, P, PK;
+  int skip;                  // as ChainFwdArgs
   int* tile_counter;
   int k_old;                 // as ChainFwdArgs
   int alpha_on_bn;           // use_alpha_condition: d raw sigma enters at the bottleneck instead of the trunk output

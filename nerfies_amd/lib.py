@@ -39,6 +39,7 @@ class ModelDesc(C.Structure):
       ('use_warp', C.c_int32), ('num_warp_freqs', C.c_int32), ('num_warp_embeddings', C.c_int32),
       ('num_warp_features', C.c_int32), ('warp_field_type', C.c_int32),
       ('noise_std', C.c_float), ('warp_metadata_encoder_type', C.c_int32), ('num_time_encoder_freqs', C.c_int32),
+      ('warp_trunk_depth', C.c_int32), ('warp_trunk_width', C.c_int32),
   ]
 
 

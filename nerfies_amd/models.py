@@ -161,9 +161,7 @@ class NerfModel:
     d.use_trunk_condition = int(self.use_trunk_condition)
     if self.use_warp and self.warp_field_type not in L.WARP_FIELD:
       raise L.NrfError(f"warp_field_type must be one of {sorted(L.WARP_FIELD)} (warping.py:36-44)")
-    if self.use_warp and dict(self.warp_kwargs or {}):
-      raise L.NrfError(f'warp_kwargs {dict(self.warp_kwargs)} are not supported: the warp kernels are built for the '
-                       'default field (6 x 128 trunk, skip at 4; warping.py:228-239)')
+    wdepth, wwidth = self._warp_trunk_shape()
     if self.use_warp and self.warp_metadata_encoder_type not in L.META_ENCODER:
       raise L.NrfError(f"warp_metadata_encoder_type must be one of {sorted(L.META_ENCODER)} ('blend' exists only in the "
                        'TranslationField, warping.py:142-146, and no preset selects it)')
@@ -174,8 +172,46 @@ class NerfModel:
     d.warp_field_type = L.WARP_FIELD[self.warp_field_type] if self.use_warp else 0
     d.noise_std = float(self.noise_std or 0.0)
     d.warp_metadata_encoder_type = L.META_ENCODER[self.warp_metadata_encoder_type] if self.use_warp else 0
-    d.num_time_encoder_freqs = 1   # metadata_encoder_num_freqs (warping.py:234); warp_kwargs are rejected above
+    d.num_time_encoder_freqs = 1   # metadata_encoder_num_freqs (warping.py:234): the field's default (_warp_trunk_shape refuses others)
+    d.warp_trunk_depth, d.warp_trunk_width = (wdepth, wwidth) if self.use_warp else (0, 0)
     return d
+
+  # ModelConfig.warp_kwargs (configs.py:105) are passed through create_warp_field to the field's constructor
+  # (models.py:165-184, warping.py:29-59).  Built: the trunk's depth (<= 6) and width (<= 128) -- SE3Field trunk_depth / trunk_width
+  # (warping.py:225-226), TranslationField depth / hidden_channels (warping.py:90-91).  Every other attribute must keep the field's
+  # default: the kernels have the branches as bare 3-channel output layers (rotation / pivot / translation depth 0), no pivot or
+  # translation branch, relu, skips (4,), frequencies 2^0 .. 2^(F-1) with the identity map.
+  _WARP_KW_DEFAULTS = {
+      'se3': dict(skips=(4,), rotation_depth=0, pivot_depth=0, translation_depth=0, use_pivot=False, use_translation=False,
+                  min_freq_log2=0, max_freq_log2=None, use_identity_map=True, metadata_encoder_num_freqs=1),
+      'translation': dict(skips=(4,), min_freq_log2=0, max_freq_log2=None, use_identity_map=True, metadata_encoder_num_freqs=1),
+  }
+  _WARP_KW_TRUNK = {'se3': ('trunk_depth', 'trunk_width'), 'translation': ('depth', 'hidden_channels')}
+
+  def _warp_trunk_shape(self):
+    kw = dict(self.warp_kwargs or {})
+    if not self.use_warp or not kw:
+      return 0, 0
+    ft = self.warp_field_type
+    dk, wk = self._WARP_KW_TRUNK.get(ft, (None, None))
+    depth, width = int(kw.pop(dk, 6)), int(kw.pop(wk, 128))
+    if not (1 <= depth <= 6 and 1 <= width <= 128):
+      raise L.NrfError(f'warp_kwargs: {dk} must be in [1, 6] and {wk} in [1, 128] (the warp kernels are 6 x 128; got {depth} x {width})')
+    # widths of branches that do not exist at depth 0 are inert (modules.MLP builds no hidden layer), as is the activation name relu
+    for inert in ('rotation_width', 'pivot_width', 'translation_width'):
+      kw.pop(inert, None)
+    if 'activation' in kw and _act_name(kw['activation']) == 'relu':
+      kw.pop('activation')
+    if 'metadata_encoder_type' in kw and kw['metadata_encoder_type'] == self.warp_metadata_encoder_type:
+      kw.pop('metadata_encoder_type')
+    for k, dflt in self._WARP_KW_DEFAULTS.get(ft, {}).items():
+      if k in kw and (tuple(kw[k]) if k == 'skips' else kw[k]) == dflt:
+        kw.pop(k)
+    if kw:
+      raise L.NrfError(f'warp_kwargs {kw} are not supported: built are {dk} <= 6 and {wk} <= 128; every other attribute of the '
+                       f'{ft} field must keep its default (warping.py:216-243)')
+    return depth, width
+
 
   @property
   def lib(self):

@@ -233,7 +233,7 @@ def se3_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, alpha,
   """
   points_embed = annealed_sinusoidal_encode(points, num_warp_freqs, alpha)
   inputs = torch.cat([points_embed, metadata_embed], -1)
-  trunk = mlp(p['trunk'], inputs, 6, (4,), False, name)
+  trunk = mlp(p['trunk'], inputs, len(p['trunk']), (4,), False, name)   # trunk_depth (warping.py:225): 6 unless warp_kwargs say otherwise
   w = dense(p['branches_w']['logit'], trunk)
   v = dense(p['branches_v']['logit'], trunk)
   theta = torch.linalg.norm(w, dim=-1)
@@ -251,7 +251,7 @@ def translation_warp(p: Dict[str, Any], points: Tensor, metadata_embed: Tensor, 
   skip at 4 and a 3-channel 'logit' output layer (warping.py:129-137)."""
   points_embed = annealed_sinusoidal_encode(points, num_warp_freqs, alpha)
   inputs = torch.cat([points_embed, metadata_embed], -1)
-  return points + mlp(p['mlp'], inputs, 6, (4,), True, name)
+  return points + mlp(p['mlp'], inputs, len(p['mlp']) - 1, (4,), True, name)   # depth (warping.py:90): the hidden layers beside 'logit'
 
 
 def time_encode(p, time, num_freqs, alpha=None):
@@ -472,6 +472,8 @@ class ModelSpec:
     self.noise_std = None                # models.py:80; defaults.gin leaves it unset
     self.warp_metadata_encoder_type = 'glo'   # configs.py:101; 'time' = modules.TimeEncoder on metadata['time']
     self.num_time_encoder_freqs = 1      # metadata_encoder_num_freqs (warping.py:234)
+    self.warp_trunk_depth = 6            # ModelConfig.warp_kwargs (configs.py:105): SE3Field trunk_depth / TranslationField depth
+    self.warp_trunk_width = 128          # ... trunk_width / hidden_channels (warping.py:225-226, 90-91)
     for k, v in kw.items():
       if not hasattr(self, k):
         raise AttributeError(k)
@@ -552,11 +554,12 @@ def init_params(spec: ModelSpec, seed=0, trained_like=False, dtype=torch.float64
   if spec.use_warp:
     Ww = spec.warp_in
     trunk = {}
-    for i in range(6):
-      fin = Ww if i == 0 else 128
+    WD, WW = spec.warp_trunk_depth, spec.warp_trunk_width
+    for i in range(WD):
+      fin = Ww if i == 0 else WW
       if i == 4:
         fin += Ww
-      trunk[f'hidden_{i}'] = dense_p(fin, 128)
+      trunk[f'hidden_{i}'] = dense_p(fin, WW)
     head_scale = 0.3 if trained_like else 1e-4
     if spec.warp_metadata_encoder_type == 'time':   # modules.TimeEncoder: xavier hidden layers, uniform(0.05) output layer
       Tin = 1 + 2 * spec.num_time_encoder_freqs
@@ -569,14 +572,14 @@ def init_params(spec: ModelSpec, seed=0, trained_like=False, dtype=torch.float64
     if spec.warp_field_type == 'translation':     # warping.py:62-137: one MLP with a 3-channel output layer
       params['warp_field'] = {
           'metadata_encoder': meta_enc,
-          'mlp': dict(trunk, logit=dense_p(128, 3, rng.uniform(0, head_scale / 3, size=(128, 3)))),
+          'mlp': dict(trunk, logit=dense_p(WW, 3, rng.uniform(0, head_scale / 3, size=(WW, 3)))),
       }
     else:
       params['warp_field'] = {
           'metadata_encoder': meta_enc,
           'trunk': trunk,
-          'branches_w': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
-          'branches_v': {'logit': dense_p(128, 3, rng.uniform(0, head_scale, size=(128, 3)))},
+          'branches_w': {'logit': dense_p(WW, 3, rng.uniform(0, head_scale, size=(WW, 3)))},
+          'branches_v': {'logit': dense_p(WW, 3, rng.uniform(0, head_scale, size=(WW, 3)))},
       }
   if spec.use_appearance_metadata:
     params['appearance_encoder'] = {'embed': {'embedding': torch.tensor(

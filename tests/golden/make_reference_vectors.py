@@ -163,7 +163,7 @@ def build_ref_model(spec, **extra):
       camera_ids=tuple(range(spec.num_camera_embeddings)), warp_ids=tuple(range(spec.num_warp_embeddings)),
       num_appearance_features=spec.num_appearance_features, num_camera_features=spec.num_camera_features,
       num_warp_features=spec.num_warp_features, num_warp_freqs=spec.num_warp_freqs, sigma_activation=nn.softplus,
-      use_camera_metadata=spec.use_camera_metadata, use_warp=spec.use_warp, warp_field_type='se3',
+      use_camera_metadata=spec.use_camera_metadata, use_warp=spec.use_warp, warp_field_type=extra.pop('warp_field_type', 'se3'),
       use_appearance_metadata=spec.use_appearance_metadata, use_alpha_condition=spec.use_alpha_condition, **extra)
 
 
@@ -475,6 +475,62 @@ def nerf_model_r4():
         out[f'{lv}/{k}'] = v
     save('nerf_' + name, **out)
 
+# ---------------------------------------------------------------------------------------------
+# round 6: the Gin surface beside the presets -- nerf_skips at another layer (configs.py:63, modules.py:47-48) and the warp
+# field's trunk shape from ModelConfig.warp_kwargs (configs.py:105 -> models.py:165-184 -> warping.py:225-226 / 90-91)
+# ---------------------------------------------------------------------------------------------
+NERF_CASES_R6 = {
+    # skip at 5 in an 8-layer trunk: the skip GEMM moves to layer 5 (float32 chains)
+    'skip5': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_skips=(5,),
+                   use_camera_metadata=True), 0.0),
+    # skip at 2 in a 6-layer trunk: laid out around the kernels' own layer 4 with identity layers in between (every mode)
+    'skip2_depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, nerf_skips=(2,),
+                          nerf_trunk_depth=6), 0.0),
+    # skip at 1 with the warp field: d posenc through the moved skip layer (the Jacobian and the warped points are outputs)
+    'skip1_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_skips=(1,),
+                        use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.5),
+    # SE3Field(trunk_depth=5, trunk_width=96): the skip at 4 is the last layer
+    'warp_trunk5x96': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                            num_warp_freqs=5, num_warp_features=8, warp_trunk_depth=5, warp_trunk_width=96, use_camera_metadata=True), 3.25),
+    # SE3Field(trunk_depth=3, trunk_width=64): the skip is never reached
+    'warp_trunk3x64': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                            num_warp_freqs=4, num_warp_features=8, warp_trunk_depth=3, warp_trunk_width=64), 1.5),
+    # TranslationField(depth=4, hidden_channels=80)
+    'translation_trunk4x80': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True,
+                                   use_warp=True, warp_field_type='translation', num_warp_freqs=5, num_warp_features=8,
+                                   warp_trunk_depth=4, warp_trunk_width=80), 2.25),
+}
+
+
+def warp_kwargs_of(spec):
+  d, w = spec.warp_trunk_depth, spec.warp_trunk_width
+  if not spec.use_warp or (d, w) == (6, 128):
+    return {}
+  return {'depth': d, 'hidden_channels': w} if spec.warp_field_type == 'translation' else {'trunk_depth': d, 'trunk_width': w}
+
+
+def nerf_model_r6():
+  for name, (kw, alpha) in NERF_CASES_R6.items():
+    spec = O.ModelSpec(**kw)
+    seed = sum(ord(c) for c in name)
+    params = O.init_params(spec, seed=seed, trained_like=True)
+    batch = O.synthetic_batch(3, seed=seed + 1)
+    rng = np.random.default_rng(seed + 2)
+    t_rand = rng.uniform(0, 1, (3, spec.num_coarse_samples)); u = rng.uniform(0, 1, (3, spec.num_fine_samples))
+    # warp_kwargs reach the field exactly as NerfModel passes them on (models.py:165-184)
+    model = build_ref_model(spec, warp_field_type=spec.warp_field_type, warp_kwargs=warp_kwargs_of(spec))
+    rays = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(),
+            'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}}
+    ret = model.apply({'params': tree_np(params)}, rays, {'alpha': alpha, 'time_alpha': 0.0}, return_points=spec.use_warp,
+                      return_weights=True, return_warp_jacobian=spec.use_warp,
+                      rngs={'coarse': jrandom.Key(uniform=t_rand), 'fine': jrandom.Key(uniform=u)})
+    out = dict(t_rand=t_rand, u=u, alpha=alpha, seed=seed)
+    for lv, d in ret.items():
+      for k, v in d.items():
+        out[f'{lv}/{k}'] = v
+    save('nerf_' + name, **out)
+
+
 
 def general_loss_branches():
   sq = np.array([0.0, 1e-8, 1e-4, 0.01, 0.5, 3.0])
@@ -671,3 +727,4 @@ if __name__ == '__main__':
   nerf_model_r4()
   nerf_model_baseline_shapes()
   loss_directional()
+  nerf_model_r6()

@@ -24,7 +24,17 @@ def config_from_spec(spec):
       appearance_metadata_dims=spec.num_appearance_features, camera_metadata_dims=spec.num_camera_features,
       use_warp=spec.use_warp, num_warp_freqs=spec.num_warp_freqs, num_warp_features=spec.num_warp_features,
       warp_field_type=spec.warp_field_type, use_alpha_condition=spec.use_alpha_condition, use_rgb_condition=spec.use_rgb_condition,
-      noise_std=spec.noise_std, warp_metadata_encoder_type=spec.warp_metadata_encoder_type)
+      noise_std=spec.noise_std, warp_metadata_encoder_type=spec.warp_metadata_encoder_type, warp_kwargs=warp_kwargs_from_spec(spec))
+
+
+def warp_kwargs_from_spec(spec):
+  """ModelConfig.warp_kwargs (configs.py:105) as a Gin file would bind them: the trunk's depth / width under the field's own attribute
+  names (SE3Field trunk_depth / trunk_width, warping.py:225-226; TranslationField depth / hidden_channels, warping.py:90-91)."""
+  d, w = getattr(spec, 'warp_trunk_depth', 6), getattr(spec, 'warp_trunk_width', 128)
+  if not spec.use_warp or (d, w) == (6, 128):
+    return {}
+  dk, wk = ('depth', 'hidden_channels') if spec.warp_field_type == 'translation' else ('trunk_depth', 'trunk_width')
+  return {dk: d, wk: w}
 
 
 def gpu_model(spec, oparams, batch_size=0):
@@ -82,28 +92,42 @@ def _decode_bits(words, nlayers, ntiles, ncb, rows):
   return torch.from_numpy(out[:, :rows])
 
 
+def trunk_layer_map(spec):
+  """The chain layer (0..7) each of the caller's trunk layers runs on (csrc/nrf_api.hip nrf_create): in place, unless the trunk's skip
+  s <= 4 with depth - s <= 4 is laid out around the kernels' own skip layer 4 (identity layers s..3 in between); the layers behind
+  the caller's last one are identities as well and appear in no oracle hook."""
+  xd = spec.nerf_trunk_depth
+  xs = spec.nerf_skips[0] if (len(spec.nerf_skips) and spec.nerf_skips[0] < xd) else -1
+  imap = list(range(8))
+  if 0 <= xs <= 4 and xd - xs <= 4:
+    for i in range(xs, xd):
+      imap[i] = 4 + (i - xs)
+  return imap[:xd] + [l for l in range(8) if l not in imap[:xd]]
+
+
 def gpu_relu_masks(model, spec, num_rays, nbg=0, elastic=False):
   """{oracle hook name: [bool (rows, width) per layer]} read back from the training workspace of the last
   loss_and_grad / apply(train=True) call with these sizes."""
   ws = model.workspace(num_rays, True, DEV, nbg, elastic)
   torch.cuda.synchronize()
   masks = {}
+  WW = getattr(spec, 'warp_trunk_width', 128)
   levels = [('coarse', 0, num_rays * spec.num_coarse_samples)]
   if spec.num_fine_samples > 0:
     levels.append(('fine', 1, num_rays * (spec.num_coarse_samples + spec.num_fine_samples)))
   for name, lv, rows in levels:
     nt = (rows + 63) // 64
     m = _decode_bits(_ws_words(model, ws, 'bits_trunk', lv, nt * 4 * 128 * 8), 8, nt, 2, rows)
-    masks[f'{name}/MLP_0'] = [m[l][:, :spec.nerf_trunk_width] for l in range(8)]
+    masks[f'{name}/MLP_0'] = [m[l][:, :spec.nerf_trunk_width] for l in trunk_layer_map(spec)]
     m = _decode_bits(_ws_words(model, ws, 'bits_rgbh', lv, nt * 4 * 64), 1, nt, 1, rows)
     masks[f'{name}/MLP_1'] = [m[0][:, :spec.nerf_rgb_branch_width]]
     if spec.use_warp:
       m = _decode_bits(_ws_words(model, ws, 'w_bits', lv, nt * 4 * 64 * 6), 6, nt, 1, rows)
-      masks[f'{name}/warp'] = [m[l] for l in range(6)]
+      masks[f'{name}/warp'] = [m[l][:, :WW] for l in range(6)]
   if spec.use_warp and nbg > 0:
     nt = (nbg + 63) // 64
     m = _decode_bits(_ws_words(model, ws, 'w_bits', 2, nt * 4 * 64 * 6), 6, nt, 1, nbg)
-    masks['background/warp'] = [m[l] for l in range(6)]
+    masks['background/warp'] = [m[l][:, :WW] for l in range(6)]
   return masks
 
 

@@ -138,8 +138,25 @@ def test_create_validates_and_reports(lib):
   assert b'256' in lib.nrf_last_error()
   d = _desc(nerf_trunk_depth=9)                     # deeper than the kernels' 8 layers (shallower trunks run on identity layers)
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
-  d = _desc(nerf_trunk_depth=8, nerf_skip_layer=3)  # a skip the kernels do not have
+  d = _desc(nerf_trunk_depth=8, nerf_skip_layer=0)  # layer 0 reading its input twice: not built
   assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
+  d = _desc(use_warp=1, num_warp_freqs=4, num_warp_embeddings=2, num_warp_features=8, warp_trunk_depth=7)   # deeper than the warp kernels' 6
+  assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
+  d = _desc(use_warp=1, num_warp_freqs=4, num_warp_embeddings=2, num_warp_features=8, warp_trunk_width=129)
+  assert lib.nrf_create(C.byref(d), C.byref(h)) == -3
+  for skip, depth in ((3, 8), (7, 8), (2, 6)):      # a skip at another layer: the caller's tree has the posenc rows in THAT layer
+    hs = C.c_void_p()
+    d = _desc(nerf_trunk_depth=depth, nerf_skip_layer=skip)
+    assert lib.nrf_create(C.byref(d), C.byref(hs)) == 0, lib.nrf_last_error()
+    ns = C.c_int32(0)
+    assert lib.nrf_param_layout(hs, None, C.byref(ns)) == 0
+    infos = (L.TensorInfo * ns.value)()
+    assert lib.nrf_param_layout(hs, infos, C.byref(ns)) == 0
+    shp = {t.name.decode(): (t.rows, t.cols) for t in infos}
+    for i in range(depth):
+      assert shp[f'nerf_mlps_fine/MLP_0/hidden_{i}/kernel'] == ((51 if i == 0 else 256) + (51 if i == skip else 0), 256), (skip, i)
+    assert f'nerf_mlps_fine/MLP_0/hidden_{depth}/kernel' not in shp
+    lib.nrf_destroy(hs)
   d = _desc(nerf_trunk_depth=6)                     # 6 layers, skip at 4: the caller's tree has six trunk leaves per MLP
   h6 = C.c_void_p()
   assert lib.nrf_create(C.byref(d), C.byref(h6)) == 0

@@ -329,6 +329,7 @@ def test_merged_wgrad_groups_give_the_same_gradient(kw):
   # switching the option on a LIVE model (one that has stepped: cached workspace of the other size) re-plans instead of reusing it
   model.set_bf16_wgrad_merge(1)
   g2, _ = model.loss_and_grad(fp, batch, warp_extra={'alpha': 2.0}, bf16=True)
-  assert torch.equal(g2, g1)
+  # same plan as the second model's: equal up to the float32 summation order of the atomically accumulated leaves (warp field, codes)
+  assert (g2 - g1).abs().max().item() <= 2e-5 * g1.abs().max().item() + 1e-12
   with pytest.raises(L.NrfError):
     L.check(model.lib.nrf_set_option(model.handle, L.NRF_OPT_BF16_WGRAD_MERGE, 2), model.lib)

@@ -412,3 +412,89 @@ def test_shallow_trunk_forward_and_gradients(kw, B, alpha):
   assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
   cos = torch.nn.functional.cosine_similarity(g16.double().flatten(), g32.double().flatten(), dim=0).item()
   assert cos > 0.98, cos
+
+
+# ---------------------------------------------------------------------------------------------
+# round 6: nerf_skips at a layer other than 4 and ModelConfig.warp_kwargs trunk shapes (configs.py:63, 105; modules.py:47-48;
+# warping.py:225-226, 90-91): forward + every gradient leaf against the pinned float64 oracle, the caller's tree shapes, and what the
+# bfloat16 mode does with them
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kw,B,alpha,bf16_ok', [
+    (dict(nerf_skips=(5,), num_nerf_point_freqs=6, num_coarse_samples=16, num_fine_samples=16, use_camera_metadata=True), 40, 0.0, False),
+    (dict(nerf_skips=(7,), num_nerf_point_freqs=4, num_coarse_samples=16, num_fine_samples=8, use_warp=True, num_warp_freqs=4), 19, 2.0, False),
+    (dict(nerf_skips=(1,), num_nerf_point_freqs=8, num_coarse_samples=24, num_fine_samples=24, use_warp=True, num_warp_freqs=5), 21, 3.0, False),
+    (dict(nerf_skips=(2,), nerf_trunk_depth=6, num_nerf_point_freqs=6, num_coarse_samples=16, num_fine_samples=16, use_warp=True, num_warp_freqs=4), 23, 2.5, True),
+    (dict(nerf_skips=(3,), nerf_trunk_depth=5, num_nerf_point_freqs=4, num_coarse_samples=16, num_fine_samples=8, use_viewdirs=False), 17, 0.0, True)])
+def test_moved_skip_forward_and_gradients(kw, B, alpha, bf16_ok):
+  from nerfies_amd import lib as L
+  spec = O.ModelSpec(use_stratified_sampling=True, **kw)
+  r = H.run_pinned(spec, B, alpha, seed=31)
+  H.assert_pinned(r, f'nerf_skips {spec.nerf_skips} depth {spec.nerf_trunk_depth} B={B}')
+  H.assert_forward(r, spec)
+  shapes = {n: tuple(sh) for n, _, sh in r['model'].layout.entries}
+  s, P = spec.nerf_skips[0], 3 + 6 * spec.num_nerf_point_freqs
+  for lv in ('coarse', 'fine'):
+    for i in range(spec.nerf_trunk_depth):
+      want = (P if i == 0 else 256) + (P if i == s else 0)
+      assert shapes[f'nerf_mlps_{lv}/MLP_0/hidden_{i}/kernel'] == (want, 256), (lv, i, shapes[f'nerf_mlps_{lv}/MLP_0/hidden_{i}/kernel'])
+    assert f'nerf_mlps_{lv}/MLP_0/hidden_{spec.nerf_trunk_depth}/kernel' not in shapes
+  g32, s32 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'])
+  g32, s32 = g32.clone(), s32.clone()
+  if bf16_ok:    # laid out around the chains' own layer 4: the bf16 stream runs it
+    g16, s16 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'], bf16='mlp')
+    assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 2e-2 * abs(s32[4].item())
+    cos = torch.nn.functional.cosine_similarity(g16.double().flatten(), g32.double().flatten(), dim=0).item()
+    assert cos > 0.98, cos
+  else:          # a moved skip GEMM exists only in the float32 chains: refused, not silently run at layer 4
+    with pytest.raises(L.NrfError, match='bfloat16|BF16'):
+      r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'], bf16='mlp')
+
+
+@pytest.mark.parametrize('kw,B,alpha', [
+    (dict(warp_trunk_depth=5, warp_trunk_width=96, num_warp_freqs=5), 21, 3.25),
+    (dict(warp_trunk_depth=3, warp_trunk_width=64, num_warp_freqs=4), 19, 1.5),
+    (dict(warp_trunk_depth=1, warp_trunk_width=128, num_warp_freqs=6), 17, 4.0),
+    (dict(warp_trunk_depth=6, warp_trunk_width=40, num_warp_freqs=4, use_camera_metadata=True), 17, 2.0),
+    (dict(warp_trunk_depth=4, warp_trunk_width=80, num_warp_freqs=5, warp_field_type='translation'), 20, 2.25)])
+def test_warp_kwargs_trunk_shapes_forward_and_gradients(kw, B, alpha):
+  """SE3Field(trunk_depth, trunk_width) / TranslationField(depth, hidden_channels) from ModelConfig.warp_kwargs, with the elastic and
+  background regularisers on (the Jacobian tangents and the background warp run the same padded trunk)."""
+  spec = O.ModelSpec(use_stratified_sampling=True, use_warp=True, num_nerf_point_freqs=6, num_coarse_samples=16, num_fine_samples=16, **kw)
+  g = torch.Generator().manual_seed(5)
+  nbg = 37
+  bg = {'points': torch.rand(nbg, 3, generator=g).double() - 0.5, 'warp_ids': torch.randint(0, spec.num_warp_embeddings, (nbg,), generator=g),
+        'noise': 0.001 * torch.randn(nbg, 3, generator=g).double(), 'weight': 1.0}
+  se3 = spec.warp_field_type == 'se3'
+  r = H.run_pinned(spec, B, alpha, seed=37, elastic={'weight': 0.01, 'reduce_method': 'weight'} if se3 else None, background=bg)
+  H.assert_pinned(r, f'warp trunk {spec.warp_trunk_depth} x {spec.warp_trunk_width} ({spec.warp_field_type}) B={B}')
+  H.assert_forward(r, spec)
+  shapes = {n: tuple(sh) for n, _, sh in r['model'].layout.entries}
+  trunk = 'warp_field/trunk' if se3 else 'warp_field/mlp'
+  Win, W = 3 + 6 * spec.num_warp_freqs + spec.num_warp_features, spec.warp_trunk_width
+  for i in range(spec.warp_trunk_depth):
+    assert shapes[f'{trunk}/hidden_{i}/kernel'] == ((Win if i == 0 else W) + (Win if i == 4 else 0), W)
+  assert f'{trunk}/hidden_{spec.warp_trunk_depth}/kernel' not in shapes
+  assert shapes['warp_field/branches_v/logit/kernel' if se3 else 'warp_field/mlp/logit/kernel'] == (W, 3)
+  # the bf16 warp trunk runs the same padded image
+  g32, s32 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'])
+  g32, s32 = g32.clone(), s32.clone()
+  g16, s16 = r['model'].loss_and_grad(r['fp'], r['gb'], warp_extra={'alpha': alpha}, rngs=r['rngs'], bf16=True)
+  assert abs(s16[4].item() - s32[4].item()) < 1e-3 + 3e-2 * abs(s32[4].item())
+  cos = torch.nn.functional.cosine_similarity(g16.double().flatten(), g32.double().flatten(), dim=0).item()
+  assert cos > 0.95, cos
+
+
+def test_unsupported_warp_kwargs_are_refused_by_name():
+  from nerfies_amd import lib as L
+  for bad in (dict(use_pivot=True), dict(use_translation=True), dict(rotation_depth=2), dict(trunk_depth=7), dict(trunk_width=256),
+              dict(skips=(2,)), dict(min_freq_log2=1)):
+    spec = O.ModelSpec(use_warp=True)
+    cfg = H.config_from_spec(spec)
+    cfg.warp_kwargs = bad
+    from nerfies_amd import models
+    with pytest.raises(L.NrfError, match='warp_kwargs'):
+      models.construct_nerf(0, cfg, 8, [0, 1], [0, 1], [0, 1, 2, 3], spec.near, spec.far)
+  # defaults spelled out are accepted
+  cfg = H.config_from_spec(O.ModelSpec(use_warp=True))
+  cfg.warp_kwargs = dict(trunk_depth=6, trunk_width=128, skips=(4,), use_pivot=False, rotation_width=64)
+  models.construct_nerf(0, cfg, 8, [0, 1], [0, 1], [0, 1, 2, 3], spec.near, spec.far)

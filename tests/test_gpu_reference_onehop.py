@@ -9,6 +9,8 @@ generator, never as the expected value):
   ref_nerf_nowarp / ref_nerf_camera / ref_nerf_warp   NerfModel.apply end to end            models.py:289-375
   ref_nerf_nocond / ref_nerf_nocond_warp              ... without any condition (no bottleneck) modules.py:149-164
   ref_nerf_depth6 / ref_nerf_depth3                   ... with a 6- / 3-layer trunk                 modules.py:41-62
+  ref_nerf_skip5 / skip2_depth6 / skip1_warp          ... with nerf_skips at another layer          modules.py:47-48, configs.py:63
+  ref_nerf_warp_trunk5x96 / 3x64 / translation_4x80   ... with warp_kwargs trunk shapes             warping.py:225-226, 90-91
   ref_se3_field / ref_translation_field               SE3Field / TranslationField.warp      warping.py:62-199, 322-389
   ref_background_loss                                 training.compute_background_loss      training.py:117-135
   ref_train_step_stats                                training.train_step's forward half    training.py:168-262 (6 elastic types)
@@ -59,6 +61,22 @@ CASES = {
     'depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=6,
                     use_camera_metadata=True), 0.0),
     'depth3': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_trunk_depth=3), 0.0),
+    # round 6: nerf_skips at another layer (configs.py:63, modules.py:47-48) -- moved skip GEMM (skip5, skip1_warp) or the trunk laid
+    # out around the kernels' layer 4 with identity layers in between (skip2_depth6) ...
+    'skip5': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_skips=(5,),
+                   use_camera_metadata=True), 0.0),
+    'skip2_depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, nerf_skips=(2,),
+                          nerf_trunk_depth=6), 0.0),
+    'skip1_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_skips=(1,),
+                        use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.5),
+    # ... and ModelConfig.warp_kwargs (configs.py:105): SE3Field trunk_depth / trunk_width, TranslationField depth / hidden_channels
+    'warp_trunk5x96': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                            num_warp_freqs=5, num_warp_features=8, warp_trunk_depth=5, warp_trunk_width=96, use_camera_metadata=True), 3.25),
+    'warp_trunk3x64': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                            num_warp_freqs=4, num_warp_features=8, warp_trunk_depth=3, warp_trunk_width=64), 1.5),
+    'translation_trunk4x80': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True,
+                                   use_warp=True, warp_field_type='translation', num_warp_freqs=5, num_warp_features=8,
+                                   warp_trunk_depth=4, warp_trunk_width=80), 2.25),
 }
 
 

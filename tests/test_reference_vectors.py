@@ -168,6 +168,47 @@ def test_nerf_model_without_any_condition_and_shallow_trunks(name):
       close(ret[lv]['warp_jacobian'], r[f'{lv}/warp_jacobian'], 2e-6)
 
 
+NERF_CASES_R6 = {   # tests/golden/make_reference_vectors.py::nerf_model_r6 -- nerf_skips at another layer, warp_kwargs trunk shapes
+    'skip5': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_skips=(5,),
+                   use_camera_metadata=True), 0.0),
+    'skip2_depth6': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, nerf_skips=(2,),
+                          nerf_trunk_depth=6), 0.0),
+    'skip1_warp': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, nerf_skips=(1,),
+                        use_warp=True, num_warp_freqs=5, num_warp_features=8), 2.5),
+    'warp_trunk5x96': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True, use_warp=True,
+                            num_warp_freqs=5, num_warp_features=8, warp_trunk_depth=5, warp_trunk_width=96, use_camera_metadata=True), 3.25),
+    'warp_trunk3x64': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=False, use_warp=True,
+                            num_warp_freqs=4, num_warp_features=8, warp_trunk_depth=3, warp_trunk_width=64), 1.5),
+    'translation_trunk4x80': (dict(num_coarse_samples=8, num_fine_samples=6, num_nerf_point_freqs=4, use_stratified_sampling=True,
+                                   use_warp=True, warp_field_type='translation', num_warp_freqs=5, num_warp_features=8,
+                                   warp_trunk_depth=4, warp_trunk_width=80), 2.25),
+}
+
+
+@pytest.mark.parametrize('name', sorted(NERF_CASES_R6))
+def test_nerf_model_with_moved_skips_and_warp_kwargs(name):
+  """modules.MLP skips (modules.py:47-48) at a layer other than 4; SE3Field / TranslationField trunks of the depth and width
+  ModelConfig.warp_kwargs give them (configs.py:105, models.py:165-184, warping.py:225-226, 90-91): the reference was run with them."""
+  kw, alpha = NERF_CASES_R6[name]
+  r = ref('nerf_' + name)
+  spec = O.ModelSpec(**kw)
+  seed = int(r['seed'])
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  if spec.use_warp:
+    trunk = params['warp_field']['mlp' if spec.warp_field_type == 'translation' else 'trunk']
+    assert sum(k.startswith('hidden_') for k in trunk) == spec.warp_trunk_depth
+    assert trunk['hidden_0']['kernel'].shape[1] == spec.warp_trunk_width
+  batch = O.synthetic_batch(3, seed=seed + 1)
+  ret = O.nerf_model_apply(params, spec, batch, alpha, return_points=spec.use_warp, return_warp_jacobian=spec.use_warp,
+                           t_rand=T(r['t_rand']), u=T(r['u']))
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'med_depth', 'acc', 'weights'):
+      close(ret[lv][k], r[f'{lv}/{k}'], 1e-8, msg=f'{name} {lv}/{k}')
+    if spec.use_warp:
+      close(ret[lv]['warped_points'], r[f'{lv}/warped_points'], 1e-9)
+      close(ret[lv]['warp_jacobian'], r[f'{lv}/warp_jacobian'], 2e-6)
+
+
 def test_losses_psnr_elastic():
   r = ref('losses_schedules')
   sq = T(r['sq'])

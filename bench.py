@@ -478,12 +478,16 @@ def rccl_preflight_summary(path):
   """What RCCL logged while the communicator came up (parsed, bounded): transports of the channel connections, channel
   count, rank count, the warnings.  None when no log was captured."""
   import re
-  if not path or not os.path.exists(path):
+  if not path:
     return None
+  if not os.path.exists(path):   # say what is there instead (RCCL appends nothing to the name unless it holds %h / %p)
+    d = os.path.dirname(path)
+    return {'log_lines': 0, 'missing': path, 'dir': sorted(os.listdir(d))[:8] if os.path.isdir(d) else None,
+            'NCCL_DEBUG': os.environ.get('NCCL_DEBUG'), 'NCCL_DEBUG_FILE': os.environ.get('NCCL_DEBUG_FILE')}
   try:
     text = open(path, errors='replace').read()
-  except OSError:
-    return None
+  except OSError as e:
+    return {'log_lines': 0, 'error': str(e)[:200]}
   lines = text.splitlines()
   via = {}
   for m in re.finditer(r'\bvia\s+([A-Za-z0-9_/\-]+)', text):

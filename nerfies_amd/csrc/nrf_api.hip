@@ -96,7 +96,7 @@ struct WsPlan {
   size_t warp_wpk;      // packed SE3 trunk weights (shared by both levels)
   size_t bg_loss;       // [64] background-loss accumulator
   size_t bg_points = 0, bg_ids = 0;   // [bgN][3] noised points / [bgN] ids drawn by the library
-  size_t el_sums;       // [64] elastic-loss / residual accumulators
+  size_t el_sums;       // [5][rows_pad / 256] elastic_kernel's per-workgroup partial sums (loss, residual, det / div / curl J)
   size_t el_coef;       // [B][N_c] one-hot sample selector of elastic_reduce_method 'median'
   size_t wr_sums = 0;   // [64] warp_reg loss / residual accumulators (coarse: 0, 1; fine: 2, 3)
   size_t t_codes = 0, t_dcodes = 0, t_in = 0, t_h = 0, t_dpre = 0;   // TimeEncoder: codes [B][G], their gradient, stashes
@@ -715,7 +715,10 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     // inside the merged groups ran ~1.35 x their quota); swept on the GPU at +0 / 6 / 10 / 16 / 24 / 32 units: 0.555 / 0.508 /
     // 0.500 / 0.520 / 0.527 / 0.543 ms
     const double bc_merged = env_cost("NRF_BCOST_MERGED", 10.0);
-    auto bcost = [&](const BSpec& sp) { return (double)(sp.Kb + sp.Nb) + bc_chunk + ((sp.Kb2 || sp.Nb2) ? bc_merged : 0.0); };
+    const double bc_quad = env_cost("NRF_BCOST_QUAD", 0.0);   // per accumulator block (Kb x Nb): the MFMA / operand-read side of a chunk
+    auto bcost = [&](const BSpec& sp) {
+      return (double)(sp.Kb + sp.Nb) + bc_chunk + bc_quad * sp.Kb * sp.Nb + ((sp.Kb2 || sp.Nb2) ? bc_merged : 0.0);   // Kb / Nb include the second source's blocks
+    };
     double total = 0;
     auto bng = [&](const BSpec& sp) { return sp.ngroups ? sp.ngroups : p.L[sp.lv].b_ngroups; };
     for (auto& sp : bspecs) total += bcost(sp) * bng(sp);
@@ -953,7 +956,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     alloc_warp(p.L[TG], p.ntiles[TG]);
     p.L[0].el_dw4 = take((size_t)p.ntiles[0] * TILE_ROWS * 4);
     p.L[0].el_dv4 = take((size_t)p.ntiles[0] * TILE_ROWS * 4);
-    p.el_sums = take(64);
+    p.el_sums = take((size_t)5 * (p.ntiles[0] * TILE_ROWS / 256 + 1));
     p.el_coef = take((size_t)p.rows[0]);
   }
   if (h->warp) p.warp_wpk = take(h->wpk.total);
@@ -1582,7 +1585,6 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     z.add(grad, h->nparams);
     if (warp_on && h->time_enc) z.add(ws + p.t_dcodes, (long long)B * h->G);
     if (wr_on) z.add(ws + p.wr_sums, 64);
-    if (el_on) z.add(ws + p.el_sums, 64);
     if (bg_on) z.add(ws + p.bg_loss, 64);
     for (int lv = 0; lv < h->nlevels; ++lv) z.add(ws + p.L[lv].dray, (long long)B * RGB_W);
     if (p.bwd32 && !warp_on && !bft) {   // the 32-row reverse chain ADDS its bias column sums into the workgroups' slices
@@ -1676,7 +1678,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     }
     ea.tan_dw4 = reinterpret_cast<float4*>(ws + T.w_dw4); ea.tan_dv4 = reinterpret_cast<float4*>(ws + T.w_dv4);
     ea.prim_dw4 = reinterpret_cast<float4*>(ws + L.el_dw4); ea.prim_dv4 = reinterpret_cast<float4*>(ws + L.el_dv4);
-    ea.sums = ws + p.el_sums;
+    ea.part = ws + p.el_sums;
     ea.rows = p.rows[0]; ea.rows_pad = p.ntiles[0] * TILE_ROWS; ea.PKS = (h->PKw + 31) / 32 * 32;
     ea.eps = el->eps; ea.alpha = el->loss_alpha; ea.scale = el->loss_scale; ea.gscale = el->loss_weight / (float)B;
     ea.inv_rays = 1.0f / (float)B; ea.dyn = scalars ? scalars->dynamic : nullptr;
@@ -1827,7 +1829,7 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
     sa.mse_ray = ws + p.mse; sa.B = B; sa.nlevels = h->nlevels;
     if (bg_on) { sa.bg_sum = ws + p.bg_loss; sa.bgN = p.bgN; sa.bg_weight = bg->loss_weight; }
     if (el_on) {
-      sa.el_sums = ws + p.el_sums; sa.el_rows = el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]; sa.el_jac_rows = p.rows[0];
+      sa.el_part = ws + p.el_sums; sa.el_nwg = (p.ntiles[0] * TILE_ROWS + 255) / 256; sa.el_rows = el->reduce_method == NRF_ELASTIC_MEDIAN ? B : p.rows[0]; sa.el_jac_rows = p.rows[0];
       sa.el_weight = el->loss_weight;
     }
     if (wr_on) { sa.wr_sums = ws + p.wr_sums; sa.wr_weight = wr->loss_weight; }

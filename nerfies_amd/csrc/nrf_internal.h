@@ -307,7 +307,7 @@ struct ElasticArgs {
   float4* tan_dv4;
   float4* prim_dw4;          // out [rows_pad]: dL/dw, dL/dv through exp_se3's second derivatives
   float4* prim_dv4;
-  float* sums;               // [5] += sum coef*rho, sum residual, sum det J, sum div J, sum |curl J|
+  float* part;               // out [5][workgroups]: per-workgroup sums of coef*rho, residual, det J, div J, |curl J| (no atomics)
   int rows, rows_pad, PKS;
   float eps, alpha, scale;
   float gscale;              // elastic_loss_weight / num_rays
@@ -474,7 +474,8 @@ void launch_cond_embed_grad(const float* params, const float* dray0, const float
 struct StatsArgs {
   const float* mse_ray; int B, nlevels;    // [nlevels][B] squared error per ray
   const float* bg_sum; int bgN; float bg_weight;
-  const float* el_sums; int el_rows, el_jac_rows; float el_weight;
+  const float* el_part; int el_nwg;   // elastic_kernel's per-workgroup partial sums [5][el_nwg]
+  int el_rows, el_jac_rows; float el_weight;
   const float* wr_sums; float wr_weight;   // [4]: loss coarse, residual coarse, loss fine, residual fine
   float* stats;
   const nrf_dynamic_scalars* dyn;          // device-resident step scalars (overrides el_weight) or nullptr

@@ -552,12 +552,20 @@ __global__ __launch_bounds__(64) void finish_stats_kernel(const StatsArgs A) {
     if (A.nlevels > 1) sf += A.mse_ray[A.B + r];
   }
   sc = wave_sum(sc); sf = wave_sum(sf);
+  float el[5] = {0.f, 0.f, 0.f, 0.f, 0.f};   // elastic_kernel's per-workgroup partials, summed in a fixed order as well
+  if (A.el_part) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      for (int w = threadIdx.x; w < A.el_nwg; w += 64) el[q] += A.el_part[(size_t)q * A.el_nwg + w];
+      el[q] = wave_sum(el[q]);
+    }
+  }
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float* stats = A.stats;
     const float B = (float)A.B;
     const float mc = sc / (3.f * B), mf = sf / (3.f * B);
     const float bgl = A.bg_sum ? A.bg_sum[0] / (float)A.bgN : 0.f;
-    const float ell = A.el_sums ? A.el_sums[0] / B : 0.f;          // sum over samples, mean over rays (training.py:194)
+    const float ell = A.el_part ? el[0] / B : 0.f;          // sum over samples, mean over rays (training.py:194)
     const float wrc = A.wr_sums ? A.wr_sums[0] / B : 0.f, wrf = A.wr_sums ? A.wr_sums[2] / B : 0.f;
     stats[0] = mc; stats[1] = mf;
     stats[2] = -10.f * logf(mc) / logf(10.f);   // utils.compute_psnr (utils.py:94-103)
@@ -566,14 +574,14 @@ __global__ __launch_bounds__(64) void finish_stats_kernel(const StatsArgs A) {
     stats[4] = mc + mf + A.bg_weight * bgl + el_weight * ell + A.wr_weight * (wrc + wrf);   // training.py:261 (+ :197, :212, :257-258)
     stats[5] = bgl;                               // stats['background_loss'] (training.py:259)
     stats[6] = ell;                               // stats['loss/elastic']
-    stats[7] = A.el_sums ? A.el_sums[1] / (float)A.el_rows : 0.f;   // stats['residual/elastic'] (training.py:196)
+    stats[7] = A.el_part ? el[1] / (float)A.el_rows : 0.f;   // stats['residual/elastic'] (training.py:196)
     stats[8] = wrc; stats[9] = wrf;               // stats['loss/warp_reg'] coarse / fine (training.py:210)
     stats[10] = A.wr_sums ? A.wr_sums[1] / B : 0.f;   // stats['residual/warp_reg'] (training.py:211)
     stats[11] = A.wr_sums ? A.wr_sums[3] / B : 0.f;
     const float jr = (float)(A.el_jac_rows > 0 ? A.el_jac_rows : 1);
-    stats[12] = A.el_sums ? A.el_sums[2] / jr : 0.f;  // metric/jacobian_det, _div, _curl (training.py:214-222): mean over all coarse samples
-    stats[13] = A.el_sums ? A.el_sums[3] / jr : 0.f;
-    stats[14] = A.el_sums ? A.el_sums[4] / jr : 0.f;
+    stats[12] = A.el_part ? el[2] / jr : 0.f;  // metric/jacobian_det, _div, _curl (training.py:214-222): mean over all coarse samples
+    stats[13] = A.el_part ? el[3] / jr : 0.f;
+    stats[14] = A.el_part ? el[4] / jr : 0.f;
     stats[15] = 0.f;
   }
 }

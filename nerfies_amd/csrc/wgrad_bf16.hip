@@ -44,6 +44,18 @@ constexpr int WB_LDS = 144 * 1024;           // operand ring: RING chunks (one 3
 template <int N>
 __device__ __forceinline__ void wait_vm() { wait_vmcnt<N>(); }
 
+// 16 bytes per lane from (wave-uniform base) + voff to LDS byte address lds_dst + lane * 16, non-temporal: the scalar-base form of the
+// LDS-DMA (bf16_chain.h lds_dma16s), invisible to hipcc's waitcnt bookkeeping like lds_dma16 (lds_dma.h)
+__device__ __forceinline__ void lds_dma16s_nt(const char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
+#ifndef NRF_WB_EXP
+#define NRF_WB_EXP 0   // experiment builds (scripts/micro/wgrad_bf16_bench.hip): 1 no operand reads / MFMAs, 2 no copies
+#endif
+
 // operand fragment (block image at `img`, k-step ks): two transposing reads = K-slots 0..3, 4..7
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int ks) {
   struct { s16x4 lo, hi; } v;
@@ -84,28 +96,45 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
   const int Kb1 = G.Kb1, Nb1 = G.Nb1;
   // source granule of LDS slot `lane` of a 1 KiB piece (16 samples): n = n0 + 4 (lane >> 4) + (lane & 3), h = (lane >> 3) & 1,
   // jp = (lane >> 2) & 1; stash granule (n, h, jp) of a block sits at jp * 1024 + (n + 32 h) * 16
-  const int src_lane = ((lane >> 2) & 1) * 1024 + (4 * (lane >> 4) + (lane & 3) + 32 * ((lane >> 3) & 1)) * 16;
+  const unsigned src_lane = (unsigned)(((lane >> 2) & 1) * 1024 + (4 * (lane >> 4) + (lane & 3) + 32 * ((lane >> 3) & 1)) * 16);
   const unsigned lds_b = lds_byte_addr(lds);
   // The copies are asm statements (lds_dma.h): counted by hipcc, the RING - 1 chunks "in flight" were drained by a
   // compiler-inserted vmcnt(0) in front of the operand reads of every chunk.
-  auto stage = [&](int ci) {
-    const int t = sg.tile_begin + ci;
-    const unsigned buf = lds_b + (unsigned)((ci % RING) * chunk_bytes);
-    const char* xt = xbase + (size_t)t * G.x_tile_stride * 4;
-    const char* yt = ybase + (size_t)t * G.dy_tile_stride * 4;
-    const char* x2t = x2base + (size_t)t * G.x2_tile_stride * 4;
-    const char* y2t = y2base + (size_t)t * G.dy2_tile_stride * 4;
+  // Round 6: the CPW pieces a wave copies per chunk are the SAME (operand, block, half) for every chunk of a segment, so their
+  // wave-uniform source addresses / strides / LDS offsets are formed once per segment and live in SGPRs; a copy is then two scalar
+  // adds and the scalar-base form of the LDS-DMA (rounds 2-5 re-derived block, source buffer and a 64-bit tile offset per piece and
+  // chunk: ~50 SALU instructions and six branches per piece between the chunk's barrier and its first operand read).
+  const int ts_x = G.x_tile_stride, ts_x2 = G.x2_tile_stride, ts_y = G.dy_tile_stride, ts_y2 = G.dy2_tile_stride;   // values, not &G.field selects
+  const char* psrc[CPW];
+  int pstride[CPW];
+  unsigned pdst[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    int p = wave + 8 * i;
+    p = p < npieces ? p : npieces - 1;      // the tail re-copies the last piece: every wave issues CPW copies
+    const int isy = p >= 2 * Kb;
+    const int pp = isy ? p - 2 * Kb : p;
+    const int b = pp >> 1, half = pp & 1;
+    const bool second = isy ? b >= Nb1 : b >= Kb1;
+    const char* base = isy ? (second ? y2base + (b - Nb1) * 2048 : ybase + b * 2048) : (second ? x2base + (b - Kb1) * 2048 : xbase + b * 2048);
+    const int stride = 4 * (isy ? (second ? ts_y2 : ts_y) : (second ? ts_x2 : ts_x));
+    const char* src = base + (size_t)sg.tile_begin * stride + half * 256;   // half: samples 16..31 = 16 lanes x 16 B further
+    const unsigned long long u = reinterpret_cast<unsigned long long>(src);
+    psrc[i] = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
+    pstride[i] = __builtin_amdgcn_readfirstlane(stride);
+    pdst[i] = (unsigned)__builtin_amdgcn_readfirstlane((isy ? Kb * 2048 : 0) + b * 2048 + half * 1024);
+  }
+  unsigned stage_buf = lds_b;               // LDS byte address of the ring slot the next staged chunk goes to
+  const unsigned ring_end = lds_b + (unsigned)(RING * chunk_bytes);
+  auto stage_next = [&]() __attribute__((always_inline)) {   // chunks are staged in order: the pointers walk the segment
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
-      int p = wave + 8 * i;
-      p = p < npieces ? p : npieces - 1;      // the tail re-copies the last piece: every wave issues CPW copies
-      const int isy = p >= 2 * Kb;
-      const int pp = isy ? p - 2 * Kb : p;
-      const int b = pp >> 1, half = pp & 1;
-      const char* blk = isy ? (b < Nb1 ? yt + b * 2048 : y2t + (b - Nb1) * 2048) : (b < Kb1 ? xt + b * 2048 : x2t + (b - Kb1) * 2048);
-      const char* src = blk + half * 256 + src_lane;   // half: samples 16..31 = 16 lanes x 16 B further
-      lds_dma16<true>(src, buf + (unsigned)((isy ? Kb * 2048 : 0) + b * 2048 + half * 1024));
+      lds_dma16s_nt(psrc[i], src_lane, stage_buf + pdst[i]);
+      psrc[i] += pstride[i];
     }
+    stage_buf += (unsigned)chunk_bytes;
+    if (stage_buf >= ring_end) stage_buf = lds_b;
   };
 
   f32x16 acc[NRB][NCB];
@@ -127,15 +156,17 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
   const int frag_lane = (2 * kg) * 256 + (2 * (q & 1) + mhalf) * 64 + r4 * 16 + (q >> 1) * 8;
 
   const int nchunks = sg.tile_end - sg.tile_begin;
-  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage(c);
+  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage_next();
+  const char* rbuf = lds + frag_lane;        // this lane's read base inside the ring slot of the chunk being multiplied
+  const char* const rbuf_end = lds + frag_lane + RING * chunk_bytes;
   for (int ci = 0; ci < nchunks; ++ci) {
     if (ci + RING - 2 <= nchunks - 1) wait_vm<(RING - 2) * CPW>();   // chunk ci has landed, RING - 2 later ones may fly
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();              // ... for every wave, and nobody still reads the buffer refilled next
     asm volatile("" ::: "memory");
-    if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
-    if (active) {
-      const char* buf = lds + (ci % RING) * chunk_bytes + frag_lane;
+    const bool refill = (ci + RING - 1 < nchunks) && !(NRF_WB_EXP & 2);
+    if (active && !(NRF_WB_EXP & 1)) {
+      const char* buf = rbuf;
       // 10 accumulator blocks per wave (the merged skip-layer shape): the two k-steps stay a loop, so that only one k-step's operand
       // fragments are live next to the 160 accumulator registers (unrolled, hipcc hoists both steps' reads and spills 117 VGPRs)
 #pragma unroll(NRB * NCB >= 10 ? 1 : 2)
@@ -145,6 +176,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
         for (int rb = 0; rb < NRB; ++rb) a[rb] = read_frag(buf + (kb0 + rb) * 2048, ks);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) b[cb] = read_frag(buf + (Kb + nb0 + cb) * 2048, ks);
+        // the refill of the slot read LAST chunk goes out behind the first operand reads: its few scalar instructions and copies issue
+        // while those reads are in flight, not in front of them
+        if (ks == 0 && refill) stage_next();
         if (NCB == 9) {
           // a wave = one row block x ALL column blocks: every wave reads every dY fragment, so the column sums are dealt out -- wave w
           // takes block w, wave 0 block 8 as well -- instead of piling all nine on the wave with kb0 == 0 (a chunk ends at a barrier)
@@ -162,7 +196,11 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[rb], b[cb], acc[rb][cb], 0, 0, 0);
       }
+    } else if (refill) {
+      stage_next();
     }
+    rbuf += chunk_bytes;
+    if (rbuf >= rbuf_end) rbuf = lds + frag_lane;
   }
   if (!active) return;
   const int j = lane & 31, h = lane >> 5;

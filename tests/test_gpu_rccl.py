@@ -128,6 +128,8 @@ def test_bench_line_through_rccl(tmp_path):
   """bench.py BENCH_FORCE_DIST=1: the headline step, the burn-in agreement and the grad_allreduce_us measurement on a one-rank
   RCCL communicator; the line reports the RCCL version."""
   env = dict(os.environ, BENCH_FORCE_DIST='1', MASTER_PORT='29519', HSA_ENABLE_IPC_MODE_LEGACY='0')
+  for k in ('NCCL_DEBUG', 'NCCL_DEBUG_FILE', 'NCCL_DEBUG_SUBSYS'):   # an inherited console log would be left alone by the bench (no capture)
+    env.pop(k, None)
   r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--burn-in-s', '0',
                       '--no-cpu-baseline', '--rays-per-gpu', '128'], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
   assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

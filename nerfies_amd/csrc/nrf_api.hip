@@ -706,8 +706,13 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
   // ---- the same stream-K cut for the bf16 groups: HBM-bound, cost = blocks streamed per 32-sample group ----
   std::vector<int> bnsplit(bspecs.size(), 0);
   if (!bspecs.empty()) {
-    // measured on config A (round-2 experiment, git history): a chunk costs (Kb + Nb) + 12 block units -- the per-chunk barrier and
-    // HBM latency are worth 24 KiB of streaming -- : wgrad 0.87 ms with a pure byte model, 0.61 ms with this one
+    // a chunk costs (Kb + Nb) + a fixed term, in block units (2 KiB streamed).  Round 2 measured + 12 on config A (the per-chunk
+    // barrier and HBM latency worth 24 KiB of streaming: wgrad 0.87 ms with a pure byte model, 0.61 ms with that one).  Round 6,
+    // after the copies moved to per-segment SGPR tables (wgrad_bf16.hip): ALONE every shape streams 5.6-6.4 TB/s, i.e. cost ~ bytes
+    // (scripts/micro/wgrad_bf16_bench.hip), but IN the mixed launch a byte-proportional model is 3-10 % slower than + 12, and the
+    // narrow shapes (Kb + Nb <= 8: the SE3 trunk's 16 / 12 KiB chunks) are best charged + 8: swept on config D / vrig / A (bf16) at
+    // narrow = 12 / 8 / 5 / 2: 1.19 / 1.13 / 1.18 / 1.38 ms, 0.92 / 0.84 / 0.90 / 1.03 ms, 0.456 / 0.460 / 0.495 / 0.618 ms
+    // (profiles/r06_experiments.md section 3)
     const double bc_seg = env_cost("NRF_BCOST_SEG", 16.0);   // opening a segment (pipeline fill + 256 KiB slab flush), in block units
     const double bc_chunk = env_cost("NRF_BCOST_CHUNK", 12.0);   // per-chunk fixed cost (barrier + issue), in block units
     // the two merged shapes (10 x 8, 8 x 9: ten accumulator blocks per wave, five copies per wave and chunk) cost more per chunk
@@ -715,9 +720,11 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN = 0, int elastic = 
     // inside the merged groups ran ~1.35 x their quota); swept on the GPU at +0 / 6 / 10 / 16 / 24 / 32 units: 0.555 / 0.508 /
     // 0.500 / 0.520 / 0.527 / 0.543 ms
     const double bc_merged = env_cost("NRF_BCOST_MERGED", 10.0);
+    const double bc_chunk_narrow = env_cost("NRF_BCOST_CHUNK_NARROW", 8.0);   // ... of the 4 x 4 / 2 x 4 shapes (SE3 trunk: 16 / 12 KiB chunks)
     const double bc_quad = env_cost("NRF_BCOST_QUAD", 0.0);   // per accumulator block (Kb x Nb): the MFMA / operand-read side of a chunk
     auto bcost = [&](const BSpec& sp) {
-      return (double)(sp.Kb + sp.Nb) + bc_chunk + bc_quad * sp.Kb * sp.Nb + ((sp.Kb2 || sp.Nb2) ? bc_merged : 0.0);   // Kb / Nb include the second source's blocks
+      // Kb / Nb include the second source's blocks
+      return (double)(sp.Kb + sp.Nb) + (sp.Kb + sp.Nb <= 8 ? bc_chunk_narrow : bc_chunk) + bc_quad * sp.Kb * sp.Nb + ((sp.Kb2 || sp.Nb2) ? bc_merged : 0.0);
     };
     double total = 0;
     auto bng = [&](const BSpec& sp) { return sp.ngroups ? sp.ngroups : p.L[sp.lv].b_ngroups; };

@@ -581,9 +581,6 @@ __device__ __forceinline__ void warp_jacobian_minus_identity(const Se3CoefD& kc,
 // dL/dJ = coef/B * weight * rho'(sq) * d sq/dJ  (singular-value types: J V diag((d sq/d s_k) / s_k) V^T);  its pull-back
 // through exp_se3 comes from se3_vjp on Duals: value parts -> adjoints of (wd_c, vd_c), tangent parts (Hessian-vector
 // products) -> adjoints of the primal (w, v).  Also the Jacobian statistics of training.py:214-222.
-#ifndef NRF_EL_EXP
-#define NRF_EL_EXP 0   // experiment builds (scripts/micro/elastic_bench.hip): 2 no Jacobi, 4 no pull-back loop
-#endif
 __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
   // Per-thread 3x3 scratch (column = threadIdx.x: no two threads share a word, no barrier): E, later gs * d sq/dJ.  The three
   // Dual evaluations of each phase run as a ROLLED loop over the column c -- a third of the straight-line code (the kernel
@@ -676,12 +673,6 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
             for (int k = 0; k < 3; ++k) { sq += 0.25f * D[i][k] * D[i][k]; M[i][k] = D[i][k]; }
         } else {
           float Vm[3][3], m[3];
-          if (NRF_EL_EXP & 2) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-              for (int k = 0; k < 3; ++k) Vm[i][k] = D[i][k];
-          } else
           jacobi3(D, Vm);
           const float log_eps = logf(A.eps);
 #pragma unroll
@@ -719,7 +710,7 @@ __global__ __launch_bounds__(256) void elastic_kernel(const ElasticArgs A) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) e_s[3 * i + k][tid] = gs * Gd[i][k];
 #pragma unroll 1
-      for (int c = 0; c < ((NRF_EL_EXP & 4) ? 0 : 3); ++c) {
+      for (int c = 0; c < 3; ++c) {
         const size_t tr = (size_t)c * A.rows_pad + row;
         const float4 a = A.tan_wv[2 * tr], b = A.tan_wv[2 * tr + 1];
         const V3T<Dual> W = v3t<Dual>(Dual(w.x, a.x), Dual(w.y, a.y), Dual(w.z, a.z));

@@ -52,9 +52,6 @@ __device__ __forceinline__ void lds_dma16s_nt(const char* sbase, unsigned voff, 
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
 }
 
-#ifndef NRF_WB_EXP
-#define NRF_WB_EXP 0   // experiment builds (scripts/micro/wgrad_bf16_bench.hip): 1 no operand reads / MFMAs, 2 no copies
-#endif
 
 // operand fragment (block image at `img`, k-step ks): two transposing reads = K-slots 0..3, 4..7
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int ks) {
@@ -164,8 +161,8 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();              // ... for every wave, and nobody still reads the buffer refilled next
     asm volatile("" ::: "memory");
-    const bool refill = (ci + RING - 1 < nchunks) && !(NRF_WB_EXP & 2);
-    if (active && !(NRF_WB_EXP & 1)) {
+    const bool refill = ci + RING - 1 < nchunks;
+    if (active) {
       const char* buf = rbuf;
       // 10 accumulator blocks per wave (the merged skip-layer shape): the two k-steps stay a loop, so that only one k-step's operand
       // fragments are live next to the 160 accumulator registers (unrolled, hipcc hoists both steps' reads and spills 117 VGPRs)

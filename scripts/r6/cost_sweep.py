@@ -5,15 +5,19 @@ step times of the three bf16 training lines.  python scripts/r6/cost_sweep.py OU
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 LIB = os.path.join(ROOT, 'nerfies_amd', '_lib', 'variants', 'libnerfies_amd_exp.so')
-SETTINGS = [  # (chunk, merged, quad, seg)
-    (12, 10, 0, 16), (0.5, 0, 0.074, 16), (0, 0, 0, 16), (2, 0, 0.074, 16), (4, 4, 0.05, 16), (6, 5, 0, 16), (0.5, 4, 0.074, 16),
-    (0.5, 0, 0.12, 16), (0.5, 0, 0.074, 4), (3, 2, 0.1, 16)]
+SETTINGS = [  # (chunk, merged, quad, seg[, chunk of the narrow shapes])
+    (12, 10, 0, 16), (12, 10, 0, 16, 8), (12, 10, 0, 16, 5), (12, 10, 0, 16, 2), (12, 6, 0, 16, 5), (12, 14, 0, 16, 5), (4, 4, 0.05, 16),
+    (12, 10, 0, 16), (8, 8, 0.03, 16, 4), (12, 10, 0, 8, 5)]
+if os.environ.get('COST_SWEEP_SETTINGS'):
+  SETTINGS = json.loads(os.environ['COST_SWEEP_SETTINGS'])
 MODES = [['--mode', 'fullhd', '--bf16'], ['--mode', 'vrig', '--bf16'], ['--mode', 'train', '--bf16']]
 out = []
-for (ch, mg, qd, sg) in SETTINGS:
-  row = {'chunk': ch, 'merged': mg, 'quad': qd, 'seg': sg}
+for st in SETTINGS:
+  ch, mg, qd, sg = st[:4]
+  nr = st[4] if len(st) > 4 else ch
+  row = {'chunk': ch, 'merged': mg, 'quad': qd, 'seg': sg, 'narrow': nr}
   for m in MODES:
-    env = dict(os.environ, NRF_LIB_PATH=LIB, NRF_BCOST_CHUNK=str(ch), NRF_BCOST_MERGED=str(mg), NRF_BCOST_QUAD=str(qd), NRF_BCOST_SEG=str(sg))
+    env = dict(os.environ, NRF_LIB_PATH=LIB, NRF_BCOST_CHUNK=str(ch), NRF_BCOST_MERGED=str(mg), NRF_BCOST_QUAD=str(qd), NRF_BCOST_SEG=str(sg), NRF_BCOST_CHUNK_NARROW=str(nr))
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + m + ['--steps', '30', '--warmup', '5', '--no-cpu-baseline', '--burn-in-s', '1'],
                        env=env, capture_output=True, text=True, cwd=ROOT)
     try:

@@ -119,7 +119,9 @@ def test_rccl_preflight_summary_parses_an_init_log(tmp_path, monkeypatch):
   assert s['connections_via'] == {'P2P/IPC': 2, 'SHM/direct/direct': 1} and s['coll_channels'] == [16] and s['nranks_seen'] == [2]
   assert s['init_complete'] and s['xgmi_mentions'] == 1 and s['warnings'] == ['something odd happened']
   assert 'RCCL version' in s['version_line'] and s['env_overrides'] == ['NCCL_SOCKET_IFNAME']
-  assert bench.rccl_preflight_summary(None) is None and bench.rccl_preflight_summary(str(tmp_path / 'none.log')) is None
+  assert bench.rccl_preflight_summary(None) is None
+  miss = bench.rccl_preflight_summary(str(tmp_path / 'none.log'))   # a log that never appeared: says so, with what IS in the directory
+  assert miss['log_lines'] == 0 and miss['missing'].endswith('none.log') and 'rank0.log' in miss['dir']
   # begin(): points RCCL's log of this rank at a file unless the user already asked for a console log
   for k in ('NCCL_DEBUG', 'NCCL_DEBUG_FILE', 'NCCL_DEBUG_SUBSYS'):
     monkeypatch.delenv(k, raising=False)

@@ -72,14 +72,8 @@ __device__ __forceinline__ unsigned bits_mask(unsigned pair, unsigned mb, int j)
   return pair & __builtin_bit_cast(unsigned, m);
 }
 
-// 16 bytes per lane from (wave-uniform base) + voff to LDS byte address lds_dst + lane * 16: the scalar-base form of the LDS-DMA,
-// so a piece costs two SALU adds instead of a 64-bit VALU add per lane (and hipcc has no per-piece address to hoist and spill)
-__device__ __forceinline__ void lds_dma16s(const char* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
+// (the copies use lds_dma16s, lds_dma.h: the scalar-base form of the LDS-DMA, so a piece costs two SALU adds instead of a 64-bit VALU
+// add per lane, and hipcc has no per-piece address to hoist and spill)
 struct BfRing {
   const char* src;   // the weight stream (wave-uniform)
   unsigned voff;     // lane * 16
@@ -106,10 +100,10 @@ __device__ __forceinline__ void bf_ring_copy(BfRing& rg, int slot, int bytes, in
   rg.soff = __builtin_amdgcn_readfirstlane(rg.soff);
 #if NRF_BF_DMA_SPLIT
   if ((wave >> 2) == rg.turn)
-    for (int p = wave & 3; p < npieces; p += 4) lds_dma16s(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
+    for (int p = wave & 3; p < npieces; p += 4) lds_dma16s<false>(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
   rg.turn ^= 1;
 #else
-  for (int p = wave; p < npieces; p += 8) lds_dma16s(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
+  for (int p = wave; p < npieces; p += 8) lds_dma16s<false>(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
 #endif
   rg.soff += bytes;
   if (rg.soff >= rg.total) rg.soff = 0;

@@ -35,6 +35,19 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc, unsigned lds_dst) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
+// The scalar-base form: 16 bytes per lane from (wave-uniform base) + voff (VGPR, bytes) to LDS byte address lds_dst + lane * 16.  A
+// copy costs the issuing wave no per-lane 64-bit address arithmetic: the base walks in SGPRs.
+template <bool NT>
+__device__ __forceinline__ void lds_dma16s(const char* sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  if (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 

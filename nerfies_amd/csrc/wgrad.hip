@@ -56,9 +56,11 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ xt, int Kb
   }
 }
 
-template <int NRB>
+// `refill()` (the copies of the chunk RING - 1 ahead) is called behind the MFMAs of quarter `when` of the chunk: the few scalar
+// instructions and copies of a wave issue while its own last MFMA and its SIMD partner's MFMAs occupy the matrix pipe.
+template <int NRB, class Refill>
 __device__ __forceinline__ void wgrad_compute(f32x16 (&acc)[NRB][2], const float* Xs, const float* Ys,
-                                              int kb0, int nb0, int lane) {
+                                              int kb0, int nb0, int lane, int when, Refill refill) {
   float4 a[2][NRB], b[2][2];
   auto load = [&](int qq, int buf) {
 #pragma unroll
@@ -87,6 +89,7 @@ __device__ __forceinline__ void wgrad_compute(f32x16 (&acc)[NRB][2], const float
         }
       }
     }
+    if (qq < 2 && qq == when) refill();
   }
 }
 
@@ -107,24 +110,64 @@ __device__ __forceinline__ void wgrad_body(const WgradTask& T, float* smem, int 
   const int stage_floats = (T.Kb + T.Nb) * 4 * WG_PIECE;
   const int nchunks = (T.tile_end - T.tile_begin) * 2;
   const unsigned smem_b = lds_byte_addr(smem);
-  auto stage = [&](int ci) {
-    const int tile = T.tile_begin + (ci >> 1);
-    stage_chunk<CPW>(T.X + (size_t)tile * T.x_tile_stride, T.Kb, T.dY + (size_t)tile * T.dy_tile_stride, T.Nb, ci & 1,
-                     smem_b + (unsigned)((ci % RING) * stage_floats * 4), wave, lane);
+  // Round 6 (as wgrad_bf16.hip): the CPW pieces a wave copies per chunk are the same (operand, block, quarter) for every chunk of
+  // the task, so their wave-uniform source pointers live in SGPRs and walk the task -- + 4 KiB from a tile's first 32-row chunk to
+  // its second, then on to the next tile -- instead of a 64-bit per-lane address computation per piece and chunk.
+  const char* psrc[CPW];
+  unsigned ymask = 0;      // bit i: piece i is a dY piece
+  const int next_x = T.x_tile_stride * 4 - 4096, next_y = T.dy_tile_stride * 4 - 4096;   // bytes from a tile's second chunk to the next tile's first
+  const int npx = T.Kb * 4, np = (T.Kb + T.Nb) * 4;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    int p = wave + 8 * i;
+    p = p < np ? p : np - 1;              // the tail re-copies the last piece: every wave issues CPW copies (one vmcnt count fits all)
+    const bool isy = p >= npx;
+    const int pp = isy ? p - npx : p;
+    const int blk = pp >> 2, qq = pp & 3;
+    const int stride = isy ? T.dy_tile_stride : T.x_tile_stride;
+    const char* src = reinterpret_cast<const char*>((isy ? T.dY : T.X) + (size_t)T.tile_begin * stride) + (size_t)(blk * 8 + qq) * 1024;
+    const unsigned long long u = reinterpret_cast<unsigned long long>(src);
+    psrc[i] = reinterpret_cast<const char*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                                            (unsigned)__builtin_amdgcn_readfirstlane((int)(u & 0xffffffffu)));
+    ymask |= isy ? 1u << i : 0u;
+  }
+  ymask = (unsigned)__builtin_amdgcn_readfirstlane((int)ymask);
+  int first = 1;                            // the next staged chunk is a tile's first
+  unsigned stage_buf = smem_b;
+  const unsigned ring_end = smem_b + (unsigned)(RING * stage_floats * 4);
+  const unsigned voff = (unsigned)lane * 16u;
+  auto stage_next = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      int p = wave + 8 * i;
+      p = p < np ? p : np - 1;
+      lds_dma16s<WG_NT>(psrc[i], voff, stage_buf + (unsigned)p * (WG_PIECE * 4));
+      psrc[i] += first ? 4096 : ((ymask >> i) & 1u) ? next_y : next_x;
+    }
+    first ^= 1;
+    stage_buf += (unsigned)(stage_floats * 4);
+    if (stage_buf >= ring_end) stage_buf = smem_b;
   };
   const bool active = kb0 < T.Kb;   // narrow K (Kb < number of k wave groups): surplus waves only stage
 
-  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage(c);
+  for (int c = 0; c < RING - 1 && c < nchunks; ++c) stage_next();
+  const float* Xs = smem;
+  const float* const ring_floats_end = smem + RING * stage_floats;
   for (int ci = 0; ci < nchunks; ++ci) {
     if (ci + RING - 2 <= nchunks - 1) wait_vm<(RING - 2) * CPW>();   // chunk ci has landed, RING - 2 later ones may fly
     else wait_vm<0>();
     __builtin_amdgcn_s_barrier();     // ... for every wave, and nobody still reads the stage refilled next
     asm volatile("" ::: "memory");
-    if (ci + RING - 1 < nchunks) stage(ci + RING - 1);
+    const bool refill = ci + RING - 1 < nchunks;
     if (active) {
-      const float* Xs = smem + (ci % RING) * stage_floats;
-      wgrad_compute<NRB>(acc, Xs, Xs + T.Kb * 4 * WG_PIECE, kb0, nb0, lane);
+      // waves w and w + 4 share a SIMD: one refills behind its first quarter of MFMAs, the other behind its second
+      wgrad_compute<NRB>(acc, Xs, Xs + T.Kb * 4 * WG_PIECE, kb0, nb0, lane, wave >> 2,
+                         [&]() __attribute__((always_inline)) { if (refill) stage_next(); });
+    } else if (refill) {
+      stage_next();
     }
+    Xs += stage_floats;
+    if (Xs >= ring_floats_end) Xs = smem;
   }
   if (!active) return;
 

@@ -44,15 +44,6 @@ constexpr int WB_LDS = 144 * 1024;           // operand ring: RING chunks (one 3
 template <int N>
 __device__ __forceinline__ void wait_vm() { wait_vmcnt<N>(); }
 
-// 16 bytes per lane from (wave-uniform base) + voff to LDS byte address lds_dst + lane * 16, non-temporal: the scalar-base form of the
-// LDS-DMA (bf16_chain.h lds_dma16s), invisible to hipcc's waitcnt bookkeeping like lds_dma16 (lds_dma.h)
-__device__ __forceinline__ void lds_dma16s_nt(const char* sbase, unsigned voff, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
-
 // operand fragment (block image at `img`, k-step ks): two transposing reads = K-slots 0..3, 4..7
 __device__ __forceinline__ bf16x8 read_frag(const char* img, int ks) {
   struct { s16x4 lo, hi; } v;
@@ -127,7 +118,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const WgradGroup& G, const Wgrad
   auto stage_next = [&]() __attribute__((always_inline)) {   // chunks are staged in order: the pointers walk the segment
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
-      lds_dma16s_nt(psrc[i], src_lane, stage_buf + pdst[i]);
+      lds_dma16s<true>(psrc[i], src_lane, stage_buf + pdst[i]);
       psrc[i] += pstride[i];
     }
     stage_buf += (unsigned)chunk_bytes;

@@ -82,6 +82,7 @@ struct BfRing {
   int total;         // stream length (the chunk sequence is cyclic: one pass per 256-sample iteration)
   int slot;          // ring slot of the chunk being multiplied
   int turn;          // which half of the workgroup (waves 0-3 / 4-7) issues the next chunk's copies
+  int nw;            // waves of the workgroup (8; fewer when a launch would leave most CUs without a workgroup: mlp_bf16.hip)
 };
 
 // `bytes` (whole KiB) of the stream at rg.soff -> ring slot `slot`, in 1-KiB pieces.
@@ -99,9 +100,13 @@ __device__ __forceinline__ void bf_ring_copy(BfRing& rg, int slot, int bytes, in
   const int npieces = bytes >> 10;
   rg.soff = __builtin_amdgcn_readfirstlane(rg.soff);
 #if NRF_BF_DMA_SPLIT
-  if ((wave >> 2) == rg.turn)
-    for (int p = wave & 3; p < npieces; p += 4) lds_dma16s<false>(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
-  rg.turn ^= 1;
+  if (rg.nw != 8) {   // a short workgroup: every wave takes pieces of every chunk
+    for (int p = wave; p < npieces; p += rg.nw) lds_dma16s<false>(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
+  } else {
+    if ((wave >> 2) == rg.turn)
+      for (int p = wave & 3; p < npieces; p += 4) lds_dma16s<false>(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
+    rg.turn ^= 1;
+  }
 #else
   for (int p = wave; p < npieces; p += 8) lds_dma16s<false>(rg.src + rg.soff + p * BF_KB, rg.voff, dst + (unsigned)(p * BF_KB));
 #endif
@@ -252,11 +257,11 @@ struct ChainCtx {
 
 // the ring's first two chunks, the first fragments
 template <int SLOT = BF_SLOT>
-__device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* wpk, int total, int bytes0, int bytes1, int lane, int wave) {
+__device__ __forceinline__ void chain_start(ChainCtx& c, char* lds, const void* wpk, int total, int bytes0, int bytes1, int lane, int wave, int nw = 8) {
   c.rg.src = reinterpret_cast<const char*>(wpk);
   c.rg.voff = lane * 16;
   c.rg.lds0 = lds_byte_addr(lds);
-  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0; c.rg.turn = 0;
+  c.rg.soff = 0; c.rg.total = total; c.rg.slot = 0; c.rg.turn = 0; c.rg.nw = nw;
   c.ll = lds + lane * 16; c.wave = wave;
   bf_ring_copy<SLOT>(c.rg, 0, bytes0, wave);
   bf_ring_copy<SLOT>(c.rg, 1, bytes1, wave);

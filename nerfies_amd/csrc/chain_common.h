@@ -219,7 +219,7 @@ __device__ __forceinline__ void mfma_kslice32(f32x16 (&acc)[2], const float* act
 // tiles from a global counter (zeroed by the host before the launch; `slot` is one free LDS word at the tile
 // boundary).  Two workgroups share a CU and the older one wins the MFMA arbitration, so with the static split it
 // finishes early and leaves the younger one alone for the last ~20 % of the kernel; the dynamic hand-out removes
-// that tail but measured 4-6 % slower overall (nrf_api.hip tile_counter_or_null), so it is off by default.
+// that tail but measured 4-6 % slower overall (nrf_plan.hip tile_counter_or_null), so it is off by default.
 __device__ __forceinline__ int next_tile(int* __restrict__ counter, int* slot, int prev = -1) {
   if (!counter) return prev < 0 ? (int)blockIdx.x : prev + (int)gridDim.x;   // static round-robin split
   if (threadIdx.x == 0) *slot = atomicAdd(counter, 1);

@@ -23,7 +23,7 @@ namespace nrf {
 
 namespace {
 
-// ---- forward weight stream: chunk sizes in execution order (nrf_api.hip build_plan emits the same sequence) ----
+// ---- forward weight stream: chunk sizes in execution order (nrf_plan.hip build_plan emits the same sequence) ----
 //   L0      4 panels x (bias + 4 k-steps of the posenc)                        4 x 10 KiB
 //   L1..L7  4 panels x (bias + 16 k-steps); skip layer + 4 posenc k-steps      4 x 34 KiB (4 x 42)
 //   BN      4 panels x (bias + 16), then the alpha head as a one-block panel   4 x 34 + 17
@@ -102,11 +102,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int niter = (A.rows + 255) / 256;
+  const int nw = (int)(blockDim.x >> 6);   // 8; 4 when eight-wave iterations would leave more than half of the CUs idle (launch_chain_fwd_bf16)
+  const int niter = (A.rows + 255) / 256 * (8 / nw);   // the stash holds whole multiples of 8 groups, all of them read by wgrad_bf16: every one is written
   const bf16x8 bias_op = as_bf16x8(0x3F803F80u, 0u, 0u, 0u);   // B = 1 in k-slots 0, 1 (bias hi + lo)
 
   ChainCtx c;
-  chain_start(c, bf_lds, A.wpk, FW_TOTAL, FW_L0, FW_L0, lane0, wave);
+  chain_start(c, bf_lds, A.wpk, FW_TOTAL, FW_L0, FW_L0, lane0, wave, nw);
 
 #pragma unroll 1
   for (int it = blockIdx.x; it < niter; it += gridDim.x) {
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(lo));   // per-iteration opaque lane: nothing derived from it is hoisted out of the loop (and spilled)
     const int lane = lo, n = lane & 31, h = lane >> 5;
     const int lane16 = lane * 16;
-    const int row = it * 256 + wave * 32 + n;
+    const int row = (it * nw + wave) * 32 + n;
     const int rc = row < A.rows ? row : A.rows - 1;
     float x[3];
     if (A.points) {
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int k = 0; k < 3; ++k) x[k] = __fadd_rn(A.origins[3 * ray + k], __fmul_rn(z, A.directions[3 * ray + k]));
     }
-    const size_t gidx = (size_t)it * 8 + wave;   // this wave's group
+    const size_t gidx = (size_t)it * nw + wave;   // this wave's group
     // SinusoidalEncoder (modules.py:213-228) in fp32, packed straight into B-operand registers
     unsigned pe[2][8];
     {
@@ -372,11 +373,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   extern __shared__ __attribute__((aligned(16))) char bf_lds[];
   const int lane0 = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int niter = (A.rows + 255) / 256;
+  const int nw = (int)(blockDim.x >> 6);   // as the forward kernel
+  const int niter = (A.rows + 255) / 256 * (8 / nw);   // the stash holds whole multiples of 8 groups, all of them read by wgrad_bf16: every one is written
   const BfStash& S = A.st;
 
   ChainCtx c;
-  chain_start(c, bf_lds, A.wpk, BW_TOTAL + (DPTS ? 2 * DGP : 0), DG1, DG2, lane0, wave);
+  chain_start(c, bf_lds, A.wpk, BW_TOTAL + (DPTS ? 2 * DGP : 0), DG1, DG2, lane0, wave, nw);
 
 #pragma unroll 1
   for (int it = wg0; it < niter; it += wgn) {
@@ -384,8 +386,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("" : "+v"(lo));   // per-iteration opaque lane (see the forward kernel)
     const int lane = lo, n = lane & 31, h = lane >> 5;
     const int lane16 = lane * 16;
-    const size_t gidx = (size_t)it * 8 + wave;
-    const int row = it * 256 + wave * 32 + n;
+    const size_t gidx = (size_t)it * nw + wave;
+    const int row = (it * nw + wave) * 32 + n;
     float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row < A.rows) d = A.d_raw4[row];
     auto bits_of = [&](int l) __attribute__((always_inline)) {   // nrf_internal.h BfStash::bits
@@ -532,9 +534,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// Waves per workgroup of a chain launch: 8 (two per SIMD, the design point); 4 when the eight-wave iterations would give at most half
+// of the CUs a workgroup -- a 256-row iteration is MFMA-bound at ~30 of its ~50 us, so halving its rows and spreading them over
+// twice the CUs nearly halves such a launch (the 128-ray share of a 1024-ray batch: bench.py --rays-per-gpu 128)
+static int chain_waves(int iters8, int max_grid) { return 2 * iters8 <= max_grid ? 4 : 8; }
+
 void launch_chain_bwd_bf16(const ChainBwdBf16Args& a0, const ChainBwdBf16Args* a1, int max_grid, hipStream_t stream) {
   const size_t lds = BF_LDS_BYTES;
-  const int it0 = (a0.rows + 255) / 256, it1 = a1 ? (a1->rows + 255) / 256 : 0;
+  const int i0 = (a0.rows + 255) / 256, i1 = a1 ? (a1->rows + 255) / 256 : 0;
+  const int nw = chain_waves(i0 + i1, max_grid);
+  const int it0 = i0 * (8 / nw), it1 = i1 * (8 / nw);
   int grid = it0 + it1 < max_grid ? it0 + it1 : max_grid;
   int n0 = grid;
   if (a1) {   // workgroups per level in proportion to the iterations, at least one each
@@ -546,10 +555,10 @@ void launch_chain_bwd_bf16(const ChainBwdBf16Args& a0, const ChainBwdBf16Args* a
   p.a[0] = a0; p.a[1] = a1 ? *a1 : a0; p.n0 = n0;
   if (a0.d_points) {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<true>, dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<true>, dim3(grid), dim3(64 * nw), lds, stream, p);
   } else {
     (void)hipFuncSetAttribute((const void*)nerf_mlp_bwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<false>, dim3(grid), dim3(512), lds, stream, p);
+    hipLaunchKernelGGL(nerf_mlp_bwd_bf16_kernel<false>, dim3(grid), dim3(64 * nw), lds, stream, p);
   }
 }
 
@@ -639,17 +648,20 @@ void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, f
 
 namespace {
 template <bool STASH, bool ABN>
-void launch_fwd_variant(const ChainFwdArgs& a, int grid, hipStream_t stream) {
+void launch_fwd_variant(const ChainFwdArgs& a, int max_grid, hipStream_t stream) {
   (void)hipFuncSetAttribute((const void*)nerf_mlp_fwd_bf16_kernel<STASH, ABN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF_LDS_BYTES);
-  hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<STASH, ABN>), dim3(grid), dim3(512), BF_LDS_BYTES, stream, a);
+  const int i8 = (a.rows + 255) / 256;
+  const int nw = chain_waves(i8, max_grid);
+  const int nit = i8 * (8 / nw);
+  hipLaunchKernelGGL((nerf_mlp_fwd_bf16_kernel<STASH, ABN>), dim3(nit < max_grid ? nit : max_grid), dim3(64 * nw), BF_LDS_BYTES, stream, a);
 }
 }  // namespace
 
-void launch_chain_fwd_bf16(const ChainFwdArgs& a, int grid, hipStream_t stream) {
+void launch_chain_fwd_bf16(const ChainFwdArgs& a, int max_grid, hipStream_t stream) {
   const bool stash = a.bst.h != nullptr;      // training: stash every layer's packed output + sign bits
   const bool abn = a.alpha_ct != nullptr;     // use_alpha_condition: the alpha head reads the bottleneck
-  if (stash) { if (abn) launch_fwd_variant<true, true>(a, grid, stream); else launch_fwd_variant<true, false>(a, grid, stream); }
-  else { if (abn) launch_fwd_variant<false, true>(a, grid, stream); else launch_fwd_variant<false, false>(a, grid, stream); }
+  if (stash) { if (abn) launch_fwd_variant<true, true>(a, max_grid, stream); else launch_fwd_variant<true, false>(a, max_grid, stream); }
+  else { if (abn) launch_fwd_variant<false, true>(a, max_grid, stream); else launch_fwd_variant<false, false>(a, max_grid, stream); }
 }
 
 }  // namespace nrf

@@ -95,7 +95,7 @@ void launch_time_encoder_bwd(const TimeEncArgs& a, hipStream_t stream);
 void launch_time_encoder_wgrad(const TimeEncArgs& a, float* grad, hipStream_t stream);
 
 // bf16 chains (mlp_bf16.hip): one descriptor fills rows of a weight stream
-// stream lengths in KiB (mlp_bf16.hip: chunk tables FW_* / DG*; nrf_api.hip build_plan emits the chunks)
+// stream lengths in KiB (mlp_bf16.hip: chunk tables FW_* / DG*; nrf_plan.hip build_plan emits the chunks)
 constexpr int BF_FWD_STREAM_KB = 4 * 10 + 28 * 34 + 4 * 42 + 17 + 2 * 32 + 9;
 constexpr int BF_BWD_STREAM_KB = 8 + 4 * 18 + 4 * 34 + 28 * 32;
 constexpr int BF_BWD_STREAM_DPTS_KB = BF_BWD_STREAM_KB + 2 * 32;
@@ -511,7 +511,7 @@ struct EmbedDesc {
   long long ext_off, int_off;
   int rows, ext_cols, int_cols, split, shift, pad_;
 };
-void launch_chain_fwd_bf16(const struct ChainFwdArgs& a, int grid, hipStream_t stream);
+void launch_chain_fwd_bf16(const struct ChainFwdArgs& a, int max_grid, hipStream_t stream);
 // bf16 SE3 trunk: forward of one or two levels (a1: e.g. the background batch) or the tangent pass (a.prim_... set);
 // reverse of up to three levels, or of the tangent pass
 void launch_warp_fwd_bf16(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int max_grid, hipStream_t stream);

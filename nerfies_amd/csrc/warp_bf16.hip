@@ -398,6 +398,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int id0 = __builtin_amdgcn_readfirstlane(id);
       const bool one_id = __all(id == id0);   // a ray has >= 32 samples: the groups of the sample levels (padding rows break it)
       const int cbase = 3 + 6 * A.F;
+      // one id per group: the (<= 8) column sums are collected in lanes 0 .. G-1 and leave as ONE atomic instruction = one request on the
+      // id's 32-byte row (rounds 4-5: one instruction per column, 98 k requests per config-D launch onto the 64 lines of a 256-frame
+      // table -- ~25 us of the kernel, profiles/r06_experiments.md section 4)
+      float mine = 0.f;
 #pragma unroll
       for (int o = 0; o < 2; ++o)
 #pragma unroll
@@ -410,11 +414,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           if (one_id) {
 #pragma unroll
             for (int sft = 16; sft > 0; sft >>= 1) v += __shfl_xor(v, sft);   // over the 32 rows of the lane half
-            if (n == 0 && valid && v != 0.f) atomicAdd(A.grad_embed + (size_t)id * A.G + g, v);
+            const float vo = __shfl_xor(v, 32);                                // the other half's column
+            const int g0 = e0 - cbase, g1 = g0 + 4;                            // columns of the h = 0 / h = 1 lanes (wave-uniform)
+            if (g0 >= 0 && g0 < A.G && lane == g0) mine = v;
+            if (g1 >= 0 && g1 < A.G && lane == g1) mine = vo;
           } else if (valid && v != 0.f) {
             atomicAdd(A.grad_embed + (size_t)id * A.G + g, v);
           }
         }
+      if (one_id && id0 >= 0 && lane < A.G && mine != 0.f) atomicAdd(A.grad_embed + (size_t)id0 * A.G + lane, mine);
     }
   }
 }

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Stream-K cost model of wgrad_bf16 (csrc/nrf_api.hip bcost): sweep the per-chunk / per-accumulator-block / merged-shape terms on an
+"""Stream-K cost model of wgrad_bf16 (csrc/nrf_plan.hip bcost): sweep the per-chunk / per-accumulator-block / merged-shape terms on an
 experiment build (scripts/build_variant.py exp -DNRF_EXPERIMENT reads NRF_BCOST_* from the environment) and report the kernel and
 step times of the three bf16 training lines.  python scripts/r6/cost_sweep.py OUT.json"""
 import json, os, subprocess, sys

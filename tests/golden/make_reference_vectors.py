@@ -580,6 +580,42 @@ def nerf_model_baseline_shapes():
     save('nerf_' + name, **out)
 
 
+# ---- round 6: the same three configurations at the FULL batch sizes of BASELINE.json (1024 / 768 / 512 rays): the rendered outputs
+#      only (rgb, depth, med_depth, acc: 48 KB for 1024 rays); the uniforms are re-drawn from the seed by the consumer ----
+FULL_BATCH = {'cfgA': 1024, 'cfgC': 768, 'cfgD': 512}
+
+
+def full_batch_uniforms(seed, B, spec):
+  rng = np.random.default_rng(seed + 2)
+  t_rand = rng.uniform(0, 1, (B, spec.num_coarse_samples)).astype(np.float32).astype(np.float64)
+  u = rng.uniform(0, 1, (B, spec.num_fine_samples)).astype(np.float32).astype(np.float64)
+  return t_rand, u
+
+
+def nerf_model_full_batches():
+  import time
+  for name, (kw, alpha, _) in BASELINE_CASES.items():
+    B = FULL_BATCH[name]
+    spec = O.ModelSpec(**kw)
+    seed = 900 + sum(ord(c) for c in name)
+    params = O.init_params(spec, seed=seed, trained_like=True)
+    batch = O.synthetic_batch(B, seed=seed + 1)
+    t_rand, u = full_batch_uniforms(seed, B, spec)
+    model = build_ref_model(spec)
+    rays = {'origins': batch['origins'].numpy(), 'directions': batch['directions'].numpy(),
+            'metadata': {k: v.numpy() for k, v in batch['metadata'].items()}}
+    t0 = time.time()
+    ret = model.apply({'params': tree_np(params)}, rays, {'alpha': alpha, 'time_alpha': 0.0}, return_points=False, return_weights=False,
+                      rngs={'coarse': jrandom.Key(uniform=t_rand), 'fine': jrandom.Key(uniform=u)})
+    print(f'{name}: {B} rays through the reference in {time.time() - t0:.1f} s')
+    out = dict(alpha=alpha, seed=seed, num_rays=B)
+    for lv, d in ret.items():
+      for k, v in d.items():
+        if k in ('rgb', 'depth', 'med_depth', 'acc'):
+          out[f'{lv}/{k}'] = np.asarray(v, dtype=np.float32)
+    save('nerf_' + name + '_full', **out)
+
+
 # ---- round 5: a REFERENCE-side gradient.  jax.value_and_grad cannot run under the NumPy shim; what can is the
 #      reference's own _loss_fn (training.py:229-262, the closure train_step differentiates), evaluated in float64 at
 #      params +- eps * v: a central-difference directional derivative.  lax.stop_gradient (model_utils.py:187 on the fine
@@ -728,3 +764,4 @@ if __name__ == '__main__':
   nerf_model_baseline_shapes()
   loss_directional()
   nerf_model_r6()
+  nerf_model_full_batches()

@@ -242,6 +242,42 @@ def test_nerf_model_apply_at_the_baseline_shapes_against_the_reference_run(name)
         ', '.join(f'{k} {v:.2e}' for k, v in worst.items()))
 
 
+FULL_BATCH = {'cfgA': 1024, 'cfgC': 768, 'cfgD': 512}   # tests/golden/make_reference_vectors.py::nerf_model_full_batches
+
+
+@pytest.mark.parametrize('name', sorted(FULL_BATCH))
+def test_nerf_model_apply_at_the_full_baseline_batches_against_the_reference_run(name):
+  """Round 6: the same three configurations at BASELINE.json's FULL batch sizes -- 1024 rays x (64 + 128), 768 x (128 + 128) with the
+  warp, 512 x (256 + 256) at F_p = 10 with the warp -- rendered by the unmodified reference (rgb / depth / med_depth / acc kept; the
+  uniforms are re-drawn from the fixture's seed): one hop at the batch size too, not only at the sample counts."""
+  kw, alpha = BASELINE_CASES[name]
+  r = _ref('nerf_' + name + '_full')
+  spec = O.ModelSpec(**kw)
+  seed, B = int(r['seed']), int(r['num_rays'])
+  assert B == FULL_BATCH[name]
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(B, seed=seed + 1)
+  rng = np.random.default_rng(seed + 2)
+  t_rand = rng.uniform(0, 1, (B, spec.num_coarse_samples)).astype(np.float32)
+  u = rng.uniform(0, 1, (B, spec.num_fine_samples)).astype(np.float32)
+  model, fp = H.gpu_model(spec, params, B)
+  rngs = {'coarse': torch.tensor(t_rand).to(DEV), 'fine': torch.tensor(u).to(DEV)}
+  out = model.apply({'params': fp}, H.gpu_batch(batch), {'alpha': alpha}, rngs=rngs)
+  tol = 1e-3 if spec.use_warp else 1e-4
+  worst = {}
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc'):
+      d = np.abs(_np(out[lv][k]) - r[f'{lv}/{k}'].astype(np.float64))
+      worst[k] = max(worst.get(k, 0.0), float(d.max()))
+      # a stratified inverse-CDF draw within float32 rounding of a bin edge lands in the neighbouring bin: a handful of rays may carry
+      # one displaced fine sample; every other ray holds the tolerance
+      assert (d > tol).sum() <= max(1, d.size // 500), (name, lv, k, float(d.max()), int((d > tol).sum()))
+      assert d.max() <= 20 * tol, (name, lv, k, float(d.max()))
+    md = np.abs(_np(out[lv]['med_depth']) - r[f'{lv}/med_depth'])
+    assert (md <= 1e-4).sum() >= md.size - max(1, md.size // 16), (name, lv)
+  print(f'one-hop {name} at the full batch ({B} rays): max |hip - reference| ' + ', '.join(f'{k} {v:.2e}' for k, v in worst.items()))
+
+
 @pytest.mark.parametrize('name', sorted(H.LOSS_DIR_CASES))
 def test_gradient_against_the_reference_side_directional_derivative(name):
   """<grad_hip, v> against central differences of the REFERENCE's own `_loss_fn` (training.py:229-262) along 8 seeded parameter

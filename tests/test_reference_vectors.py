@@ -209,6 +209,26 @@ def test_nerf_model_with_moved_skips_and_warp_kwargs(name):
       close(ret[lv]['warp_jacobian'], r[f'{lv}/warp_jacobian'], 2e-6)
 
 
+def test_oracle_at_the_full_config_a_batch_against_the_reference_run():
+  """tests/golden/make_reference_vectors.py::nerf_model_full_batches: NerfModel.apply by the unmodified reference on the FULL 1024-ray batch
+  of BASELINE.json configs[1] (64 + 128 samples, F_p = 8, stratified); the oracle on the same rays, parameters and re-drawn uniforms.
+  (The 768- and 512-ray warp configurations are compared on the GPU only: tests/test_gpu_reference_onehop.py.)"""
+  r = ref('nerf_cfgA_full')
+  spec = O.ModelSpec(num_coarse_samples=64, num_fine_samples=128, num_nerf_point_freqs=8, use_stratified_sampling=True)
+  seed, B = int(r['seed']), int(r['num_rays'])
+  assert B == 1024
+  params = O.init_params(spec, seed=seed, trained_like=True)
+  batch = O.synthetic_batch(B, seed=seed + 1)
+  rng = np.random.default_rng(seed + 2)
+  t_rand = T(rng.uniform(0, 1, (B, spec.num_coarse_samples)).astype(np.float32).astype(np.float64))
+  u = T(rng.uniform(0, 1, (B, spec.num_fine_samples)).astype(np.float32).astype(np.float64))
+  with torch.no_grad():
+    ret = O.nerf_model_apply(params, spec, batch, 0.0, t_rand=t_rand, u=u)
+  for lv in ('coarse', 'fine'):
+    for k in ('rgb', 'depth', 'acc'):
+      close(ret[lv][k], r[f'{lv}/{k}'].astype(np.float64), 1e-6, msg=f'cfgA full {lv}/{k}')   # float32 storage of the fixture
+
+
 def test_losses_psnr_elastic():
   r = ref('losses_schedules')
   sq = T(r['sq'])

@@ -366,6 +366,9 @@ struct ReduceDesc {
   int64_t part_stride;
   int dst_ld, rows, cols, src_ld, nparts;
   int accumulate;     // > 0: dst += (pass index: a later level adding into leaves shared with earlier passes)
+  int next;           // the descriptor of the NEXT pass into the same destination, run by the same threads right behind this one
+                      // (-1: none): every pass of a leaf in ONE launch, in pass order (round 6; rounds 1-5: one launch per pass)
+  int path;           // element -> thread mapping, the same along a chain: 0 scalar, 1 four columns per thread, 2 one wave per column
 };
 
 struct PackDesc {
@@ -413,7 +416,7 @@ void launch_jacobian(const JacobianArgs& a, hipStream_t stream);
 void launch_median_coef(const float* weights, int B, int S, float* coef, hipStream_t stream);
 void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const int* d_seg_begin, int nwg, float* ws,
                   unsigned long long* seg_clock, hipStream_t stream);
-void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream);
+void launch_reduce(const ReduceDesc* d_table, int first, int ndesc, const float* ws, float* grad, hipStream_t stream);   // chain heads table[first .. first + ndesc)
 // bf16 wgrad (wgrad_bf16.hip): the same group / segment tables, "tile" = one 32-sample group of the bf16 stash, Kb / Nb
 // blocks per group for X / dY (x_tile_stride = Kb * 512, dy_tile_stride = Nb * 512 dwords); vslab_off >= 0: the
 // group also sums dY over the rows (bias gradient) into vslab[slab_idx][Nb * 32]

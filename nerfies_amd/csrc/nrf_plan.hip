@@ -924,13 +924,50 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
       }
     }
   }
-  p.nreduce_pass[0] = (int)p.reduce.size();
-  p.nreduce_pass[1] = (int)reduce2.size();
-  p.nreduce_pass[2] = (int)reduce3.size();
-  p.nreduce_pass[3] = (int)reduce4.size();
-  p.reduce.insert(p.reduce.end(), reduce2.begin(), reduce2.end());
-  p.reduce.insert(p.reduce.end(), reduce3.begin(), reduce3.end());
-  p.reduce.insert(p.reduce.end(), reduce4.begin(), reduce4.end());
+  {
+    // Every pass of a destination in ONE launch: the descriptors that add into a leaf (the SE3 field's: fine level, tangent pass,
+    // background batch) are chained behind the pass-0 descriptor of the same destination window; a workgroup column of reduce_kernel
+    // walks the chain with one element -> thread mapping.  Heads first (the launch's grid), chained descriptors behind them.
+    std::vector<ReduceDesc> all = p.reduce;
+    all.insert(all.end(), reduce2.begin(), reduce2.end());
+    all.insert(all.end(), reduce3.begin(), reduce3.end());
+    all.insert(all.end(), reduce4.begin(), reduce4.end());
+    auto wide_ok = [](const ReduceDesc& d) {
+      return ((d.cols | d.src_ld | d.dst_ld) & 3) == 0 && (d.part_stride & 3) == 0 && (d.src_off & 3) == 0 && (d.dst_off & 3) == 0;
+    };
+    const int n = (int)all.size();
+    std::vector<int> prev(n, -1), nxt(n, -1);
+    for (int i = 0; i < n; ++i) {
+      if (all[i].accumulate == 0) continue;
+      for (int j = i - 1; j >= 0; --j)   // the latest earlier descriptor of the same destination window that is still a chain's tail
+        if (nxt[j] < 0 && all[j].dst_off == all[i].dst_off && all[j].rows == all[i].rows && all[j].cols == all[i].cols &&
+            all[j].dst_ld == all[i].dst_ld && all[j].accumulate < all[i].accumulate) { prev[i] = j; nxt[j] = i; break; }
+    }
+    std::vector<int> order, pos(n, -1);
+    for (int i = 0; i < n; ++i) if (prev[i] < 0 && all[i].accumulate == 0) order.push_back(i);          // heads of pass 0
+    const int nheads0 = (int)order.size();
+    for (int i = 0; i < n; ++i) if (prev[i] >= 0) order.push_back(i);                                    // chained
+    const int nchained_end = (int)order.size();
+    for (int i = 0; i < n; ++i) if (prev[i] < 0 && all[i].accumulate != 0) order.push_back(i);          // no pass-0 partner: a second launch
+    for (int k = 0; k < (int)order.size(); ++k) pos[order[k]] = k;
+    p.reduce.clear();
+    for (int k = 0; k < (int)order.size(); ++k) {
+      ReduceDesc d = all[order[k]];
+      d.next = nxt[order[k]] >= 0 ? pos[nxt[order[k]]] : -1;
+      p.reduce.push_back(d);
+    }
+    for (int k = 0; k < (int)p.reduce.size(); ++k) {   // one mapping per chain, chosen at its head
+      if (k >= nheads0 && k < nchained_end) continue;
+      bool tall = p.reduce[k].rows == 1, wide = true, big = false;
+      for (int q = k; q >= 0; q = p.reduce[q].next) { wide = wide && wide_ok(p.reduce[q]); big = big || p.reduce[q].nparts >= 64; }
+      const int path = (tall && big) ? 2 : wide ? 1 : 0;
+      for (int q = k; q >= 0; q = p.reduce[q].next) p.reduce[q].path = path;
+    }
+    p.nreduce_pass[0] = nheads0;
+    p.nreduce_pass[1] = nchained_end - nheads0;            // reached through `next`, not launched
+    p.nreduce_pass[2] = (int)order.size() - nchained_end;  // launched second (empty in every configuration built so far)
+    p.nreduce_pass[3] = 0;
+  }
   // ---- descriptor tables (bytes), sized from what was actually built (round 2 reserved 64 pack / 192 reduce
   //      descriptors without a check) ----
   p.pack_off_b = 0;

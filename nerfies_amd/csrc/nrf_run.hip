@@ -604,8 +604,9 @@ int backward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, con
   }
   h->prof.begin("grad_reduce", 0, stream);
   const ReduceDesc* rd = reinterpret_cast<const ReduceDesc*>(tables + p.reduce_off_b);
-  for (int pass = 0, at = 0; pass < 4; at += p.nreduce_pass[pass], ++pass)   // later passes add into shared leaves (SE3 field)
-    if (p.nreduce_pass[pass] > 0) launch_reduce(rd + at, p.nreduce_pass[pass], ws, grad, stream);
+  // one launch: the grid's columns are the chain heads, the later passes into shared leaves (SE3 field) hang behind them (nrf_plan.hip)
+  if (p.nreduce_pass[0] > 0) launch_reduce(rd, 0, p.nreduce_pass[0], ws, grad, stream);
+  if (p.nreduce_pass[2] > 0) launch_reduce(rd, p.nreduce_pass[0] + p.nreduce_pass[1], p.nreduce_pass[2], ws, grad, stream);
   if (h->embed) {
     hipError_t e = hipMemsetAsync(grad_x, 0, (size_t)h->xnparams * sizeof(float), stream);
     if (e != hipSuccess) return fail_hip(e, "zero grad");

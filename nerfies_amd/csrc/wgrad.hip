@@ -303,65 +303,66 @@ void launch_wgrad(const WgradGroup* d_groups, const WgradSegment* d_segs, const 
 
 // dst[r][c] = sum_parts src[part][r][c].  Wide leaves (cols, ld multiples of 4) go 4 columns per
 // thread with 4 independent partial sums so that the part loop keeps 4 x 16 B loads in flight.
-__global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs, const float* __restrict__ ws,
+// A workgroup column (blockIdx.y) runs a CHAIN of descriptors -- the passes that add into one destination, in pass order --: the
+// element -> thread mapping (`path`) is the same along the chain, so a thread re-reads only what it wrote itself.
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceDesc* __restrict__ descs, int first, const float* __restrict__ ws,
                                                      float* __restrict__ grad) {
-  const ReduceDesc d = descs[blockIdx.y];
-  if (d.rows == 1 && d.nparts >= 64) {
-    // tall and thin (bias partials, one per chain-kernel workgroup): one wave per column, lanes stride over
-    // the parts, shuffle tree at the end (deterministic order)
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int c = blockIdx.x * 4 + wv; c < d.cols; c += gridDim.x * 4) {
-      const float* s = ws + d.src_off + c;
-      float a0 = 0.f, a1 = 0.f;
-      int q = lane;
-      for (; q + 64 < d.nparts; q += 128) { a0 += s[(size_t)q * d.part_stride]; a1 += s[(size_t)(q + 64) * d.part_stride]; }
-      if (q < d.nparts) a0 += s[(size_t)q * d.part_stride];
-      float t = a0 + a1;
+  for (int di = first + (int)blockIdx.y; di >= 0;) {
+    const ReduceDesc d = descs[di];
+    di = d.next;
+    if (d.path == 2) {
+      // tall and thin (bias partials, one per chain-kernel workgroup): one wave per column, lanes stride over
+      // the parts, shuffle tree at the end (deterministic order)
+      const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+      for (int c = blockIdx.x * 4 + wv; c < d.cols; c += gridDim.x * 4) {
+        const float* s = ws + d.src_off + c;
+        float a0 = 0.f, a1 = 0.f;
+        int q = lane;
+        for (; q + 64 < d.nparts; q += 128) { a0 += s[(size_t)q * d.part_stride]; a1 += s[(size_t)(q + 64) * d.part_stride]; }
+        if (q < d.nparts) a0 += s[(size_t)q * d.part_stride];
+        float t = a0 + a1;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
-      if (lane == 0) { float* o = grad + d.dst_off + c; *o = d.accumulate ? *o + t : t; }
-    }
-    return;
-  }
-  const bool wide = ((d.cols | d.src_ld | d.dst_ld) & 3) == 0 && (d.part_stride & 3) == 0 && (d.src_off & 3) == 0 &&
-                    (d.dst_off & 3) == 0;
-  if (wide) {
-    const int c4 = d.cols >> 2, total = d.rows * c4;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-      const int r = idx / c4, c = (idx - r * c4) << 2;
-      const float4* s = reinterpret_cast<const float4*>(ws + d.src_off + (size_t)r * d.src_ld + c);
-      const size_t ps = (size_t)(d.part_stride >> 2);
-      float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
-      int q = 0;
-      for (; q + 4 <= d.nparts; q += 4) {
-        const float4 v0 = s[(q + 0) * ps], v1 = s[(q + 1) * ps], v2 = s[(q + 2) * ps], v3 = s[(q + 3) * ps];
-        a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
-        a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
-        a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
-        a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o);
+        if (lane == 0) { float* o = grad + d.dst_off + c; *o = d.accumulate ? *o + t : t; }
       }
-      for (; q < d.nparts; ++q) { const float4 v = s[q * ps]; a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w; }
-      float4 t = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
-                             (a0.w + a1.w) + (a2.w + a3.w));
-      float4* o = reinterpret_cast<float4*>(grad + d.dst_off + (size_t)r * d.dst_ld + c);
-      if (d.accumulate) { const float4 p = *o; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
-      *o = t;
+    } else if (d.path == 1) {
+      const int c4 = d.cols >> 2, total = d.rows * c4;
+      for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int r = idx / c4, c = (idx - r * c4) << 2;
+        const float4* s = reinterpret_cast<const float4*>(ws + d.src_off + (size_t)r * d.src_ld + c);
+        const size_t ps = (size_t)(d.part_stride >> 2);
+        float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+        int q = 0;
+        for (; q + 4 <= d.nparts; q += 4) {
+          const float4 v0 = s[(q + 0) * ps], v1 = s[(q + 1) * ps], v2 = s[(q + 2) * ps], v3 = s[(q + 3) * ps];
+          a0.x += v0.x; a0.y += v0.y; a0.z += v0.z; a0.w += v0.w;
+          a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+          a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+          a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; q < d.nparts; ++q) { const float4 v = s[q * ps]; a0.x += v.x; a0.y += v.y; a0.z += v.z; a0.w += v.w; }
+        float4 t = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y), (a0.z + a1.z) + (a2.z + a3.z),
+                               (a0.w + a1.w) + (a2.w + a3.w));
+        float4* o = reinterpret_cast<float4*>(grad + d.dst_off + (size_t)r * d.dst_ld + c);
+        if (d.accumulate) { const float4 p = *o; t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w; }
+        *o = t;
+      }
+    } else {
+      const int total = d.rows * d.cols;
+      for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int r = idx / d.cols, c = idx - r * d.cols;
+        const float* s = ws + d.src_off + (size_t)r * d.src_ld + c;
+        float acc = 0.f;
+        for (int q = 0; q < d.nparts; ++q) acc += s[(size_t)q * d.part_stride];
+        float* o = grad + d.dst_off + (size_t)r * d.dst_ld + c;
+        *o = d.accumulate ? *o + acc : acc;
+      }
     }
-    return;
-  }
-  const int total = d.rows * d.cols;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int r = idx / d.cols, c = idx - r * d.cols;
-    const float* s = ws + d.src_off + (size_t)r * d.src_ld + c;
-    float acc = 0.f;
-    for (int q = 0; q < d.nparts; ++q) acc += s[(size_t)q * d.part_stride];
-    float* o = grad + d.dst_off + (size_t)r * d.dst_ld + c;
-    *o = d.accumulate ? *o + acc : acc;
   }
 }
 
-void launch_reduce(const ReduceDesc* d_descs, int ndesc, const float* ws, float* grad, hipStream_t stream) {
-  hipLaunchKernelGGL(reduce_kernel, dim3(64, ndesc), dim3(256), 0, stream, d_descs, ws, grad);
+void launch_reduce(const ReduceDesc* d_table, int first, int ndesc, const float* ws, float* grad, hipStream_t stream) {
+  hipLaunchKernelGGL(reduce_kernel, dim3(64, ndesc), dim3(256), 0, stream, d_table, first, ws, grad);
 }
 
 }  // namespace nrf

@@ -519,8 +519,11 @@ def roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg):
   traffic, traffic_src = hbm_traffic(dom['name'], mode_key)
   # the NeRF-MLP kernels run on bf16 MFMA in the bf16 modes, and so does the SE3 trunk unless --warp-f32 keeps it in float32
   # (bf16 == 'mlp'); the fp32 wgrad kernel never does
-  on_bf16 = bool(bf16) and (dom['name'].startswith('mlp_') or (bf16 != 'mlp' and dom['name'].startswith('warp_')))
+  on_bf16 = bool(bf16) and (dom['name'].startswith('mlp_') or (bf16 not in ('mlp', 'x3') and dom['name'].startswith('warp_')))
   peak_tf = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
+  if on_bf16 and bf16 == 'x3':
+    # split-bf16: the ALGORITHMIC flops of the layer (what `achieved` counts) cost three bf16 MFMAs each (hi.hi + lo.hi + hi.lo)
+    peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0
   r = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': achieved / peak_tf,
        'traffic': traffic, 'traffic_source': traffic_src, 'kernel_ms': dom_ms, 'flops_per_launch': dom['flops_per_launch']}
   if dom['name'] == 'wgrad_bf16':
@@ -627,17 +630,21 @@ def eval_mode(args, world, rank, dev, bf16, emit=True):
   prof = model.profile_read()
   model.profile_enable(False)
   if rank == 0:
-    roofline, peak = roofline_of(prof, bf16, ('eval_warp' if args.warp else 'eval') + ('_bf16' if bf16 else ''), n, cfg)
+    roofline, peak = roofline_of(prof, bf16, ('eval_warp' if args.warp else 'eval') + ('_x3' if bf16 == 'x3' else '_bf16' if bf16 else ''), n, cfg)
+    if bf16 == 'x3':
+      roofline['peak_note'] = ('dense bf16 MFMA peak / 3: every algorithmic multiply-add is three bf16 MFMAs (hi.hi + lo.hi + hi.lo, fp32 accumulate); '
+                               'the float32 chains it emulates are priced against 157.3 TFLOP/s')
     at_clock(roofline, clocks)
     step_flops = sum(e['flops_per_launch'] * e['launches'] for e in prof) / 5
     ms = 1e3 * elapsed / args.steps
     warp_txt = 'SE3 warp F_w=8 G=8 (one warp id per chunk)' if args.warp else 'warp off'
     line = {
         'metric': 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [SE3 warp on]' if args.warp else '') +
-                  (' [bf16 MLP operands]' if bf16 else ''),
+                  (' [split-bf16 (bf16x3) MLP arithmetic]' if bf16 == 'x3' else ' [bf16 MLP operands]' if bf16 else ''),
         'value': world * n * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': ('bf16 NeRF MLPs + f32 warp field' if (args.warp and bf16 == 'mlp') else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
+        'dtype': 'bf16x3 (fp32-emulating)' if bf16 == 'x3' else
+                 ('bf16 NeRF MLPs + f32 warp field' if (args.warp and bf16 == 'mlp') else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': f'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, {warp_txt}, deterministic, forward only',
                    'rays_per_gpu': n, 'parallelism': f'ray-shard dp{world}'},
         'roofline': roofline, 'step_tflops': step_flops / (ms * 1e-3) / 1e12, 'kernels': kernel_table(prof, 5),
@@ -842,6 +849,10 @@ def main(argv=None):
   ap.add_argument('--graph', action='store_true', help='replay the whole train step (loss+grad, all-reduce, Adam) from one hipGraph')
   ap.add_argument('--no-strong', action='store_true', help='N>1: skip the nested strong-scaling record (1024-ray global batch)')
   ap.add_argument('--warp', action='store_true', help='eval mode: render with the SE3 warp field (the path eval.py takes)')
+  ap.add_argument('--split-bf16', action='store_true',
+                  help='--mode eval: the NeRF MLPs in split-bf16 arithmetic (NRF_FLAG_BF16X3: every float32 operand as a bf16 pair, three bf16 '
+                       'MFMAs per product, float32 accumulate -- float32-emulating, ~1e-6 of the float32 chains on rendered colour); the '
+                       "line says dtype 'bf16x3 (fp32-emulating)', never 'f32'")
   ap.add_argument('--warp-f32', action='store_true', help='bf16 modes: keep the SE3 trunk in float32 (NRF_FLAG_WARP_F32; the round-3 behaviour)')
   ap.add_argument('--chain-rows', type=int, default=0, choices=[0, 32, 64],
                   help='rows per workgroup tile of the fp32 NeRF chain kernels (NRF_OPT_CHAIN_TILE_ROWS): 0 = the library\'s automatic choice')
@@ -898,6 +909,10 @@ def main(argv=None):
   bf16 = args.bf16 or bool(os.environ.get('BENCH_BF16'))
   if bf16 and args.warp_f32:
     bf16 = 'mlp'
+  if args.split_bf16:
+    if args.mode != 'eval' or bf16:
+      raise SystemExit('--split-bf16 is an inference mode (--mode eval) of its own, not combined with --bf16')
+    bf16 = 'x3'
   if args.mode == 'eval':
     eval_mode(args, world, rank, dev, bf16)
     if dist_on:

@@ -39,7 +39,8 @@ extern "C" {
 
 #define NRF_VERSION 600 /* 0.6.0: nrf_model_desc grows warp_trunk_depth / warp_trunk_width (SE3Field / TranslationField trunk_depth <= 6,
                            trunk_width <= 128 of ModelConfig.warp_kwargs); nerf_skip_layer accepts any single index 1..7 (float32
-                           mode; the bfloat16 mode where the trunk can be laid out around the chains' layer 4).  Behaviour change
+                           mode; the bfloat16 mode where the trunk can be laid out around the chains' layer 4); NRF_FLAG_BF16X3 (split-bf16,
+                           float32-emulating inference chains).  Behaviour change
                            since 0.5.0: the flag word is validated on every entry point -- NRF_FLAG_TRAIN | NRF_FLAG_NO_WARP is refused
                            also for models without a warp field (it used to be a no-op there), NRF_FLAG_WARP_F32 without NRF_FLAG_BF16
                            is refused by nrf_train_step_loss_grad_ex as well.
@@ -223,6 +224,12 @@ typedef struct nrf_outputs {
 #define NRF_FLAG_WARP_F32 16u     /* with NRF_FLAG_BF16: keep SE3Field's 6 x 128 trunk on float32 operands (since 0.4.0 NRF_FLAG_BF16
                                      runs it on bfloat16 operands as well: annealed posenc, exp_se3, (w, v), the Jacobian algebra and
                                      the GLO table stay float32); a call that returns the warp Jacobian uses the float32 trunk anyway */
+#define NRF_FLAG_BF16X3 32u       /* since 0.6.0, nrf_forward / nrf_workspace_bytes[_ex] only (inference): the NeRF MLPs
+                                     (modules.py:26-62, 95-169) in split-bfloat16 arithmetic -- every float32 operand as a bf16 pair
+                                     hi + lo, a product as hi.hi + lo.hi + hi.lo on the bf16 matrix pipe, float32 accumulate: float32-
+                                     EMULATING (product error ~2^-16; rendered colour within ~1e-5 of the float32 chains, far inside the
+                                     1e-3 parity gate), not bit-comparable with them.  The warp field, sampling and compositing stay
+                                     float32.  Not with NRF_FLAG_TRAIN or NRF_FLAG_BF16; same model limits as NRF_FLAG_BF16 */
 
 int nrf_version(void);
 const char* nrf_last_error(void);

@@ -607,7 +607,8 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
   uint4* dst = reinterpret_cast<uint4*>(ws + d.dst_off);
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int lane = idx & 63, o = (idx >> 6) % d.nout, rowi = (idx >> 6) / d.nout;
-    const int m = lane & 31, h = lane >> 5, b = rowi >> 1, s = rowi & 1;
+    const int rowk = d.x3 ? rowi >> 1 : rowi, var = d.x3 ? rowi & 1 : 0;   // x3: rows (W_hi, W_lo) per k-step
+    const int m = lane & 31, h = lane >> 5, b = rowk >> 1, s = rowk & 1;
     const int col = 32 * (d.oblk0 + o) + m;
     // two leaves side by side (SE3 heads): output columns (forward, bias) / K indices (transposed) >= split come from src_off2
     const bool col2 = !d.transposed && d.split > 0 && col >= d.split;
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
         const float bias = params[leaf + lcol];
         const float hi = __uint_as_float(pack_bf16(bias, 0.f) << 16);
         v[0] = hi; v[1] = bias - hi;
+        if (d.x3) v[2] = v[1] - __uint_as_float(pack_bf16(v[1], 0.f) << 16);   // the third term: bias to 24 bits
       }
     } else {
 #pragma unroll
@@ -634,6 +636,10 @@ __global__ __launch_bounds__(256) void bf16_pack_kernel(const RcPackDesc* __rest
           }
         }
       }
+    }
+    if (var == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] -= __uint_as_float(pack_bf16(v[e], 0.f) << 16);   // the lo part
     }
     uint4 out;
     out.x = pack_bf16(v[0], v[1]); out.y = pack_bf16(v[2], v[3]); out.z = pack_bf16(v[4], v[5]); out.w = pack_bf16(v[6], v[7]);

@@ -136,15 +136,18 @@ int nrf_param_layout(nrf_handle h, nrf_tensor_info* out, int32_t* n) {
 // (they used to pass through: NRF_FLAG_WARP_F32 without NRF_FLAG_BF16 was silently ignored, and TRAIN | WARP_JACOBIAN sized a
 // workspace for a plan no call can run).
 static int check_flags(const nrf_handle_s* h, uint32_t flags) {
-  const uint32_t known = NRF_FLAG_TRAIN | NRF_FLAG_NO_WARP | NRF_FLAG_BF16 | NRF_FLAG_WARP_JACOBIAN | NRF_FLAG_WARP_F32;
+  const uint32_t known = NRF_FLAG_TRAIN | NRF_FLAG_NO_WARP | NRF_FLAG_BF16 | NRF_FLAG_WARP_JACOBIAN | NRF_FLAG_WARP_F32 | NRF_FLAG_BF16X3;
   if (flags & ~known) return fail(NRF_E_UNSUPPORTED, "unknown bits in flags");
+  if ((flags & NRF_FLAG_BF16X3) && (flags & (NRF_FLAG_TRAIN | NRF_FLAG_BF16)))
+    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16X3 is an inference mode of its own: not with NRF_FLAG_TRAIN (the training chains stash float32 or "
+                                   "bfloat16 activations) and not with NRF_FLAG_BF16");
   if ((flags & NRF_FLAG_WARP_F32) && !(flags & NRF_FLAG_BF16))
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_F32 only qualifies NRF_FLAG_BF16 (the float32 mode runs the warp trunk in float32 anyway)");
   if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_WARP_JACOBIAN))
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_JACOBIAN is an inference output (training consumes the Jacobian through nrf_elastic)");
   if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_NO_WARP))
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_NO_WARP cannot be combined with NRF_FLAG_TRAIN");
-  if ((flags & NRF_FLAG_BF16) && h->d.nerf_skip_layer != SKIP_LAYER)
+  if ((flags & (NRF_FLAG_BF16 | NRF_FLAG_BF16X3)) && h->d.nerf_skip_layer != SKIP_LAYER)
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16: the bfloat16 chains run the skip at trunk layer 4; this model's nerf_skips cannot be laid out "
                                    "around it (needs skip <= 4 and depth - skip <= 4): use the float32 mode");
   return NRF_OK;

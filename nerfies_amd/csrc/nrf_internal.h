@@ -99,9 +99,11 @@ void launch_time_encoder_wgrad(const TimeEncArgs& a, float* grad, hipStream_t st
 constexpr int BF_FWD_STREAM_KB = 4 * 10 + 28 * 34 + 4 * 42 + 17 + 2 * 32 + 9;
 constexpr int BF_BWD_STREAM_KB = 8 + 4 * 18 + 4 * 34 + 28 * 32;
 constexpr int BF_BWD_STREAM_DPTS_KB = BF_BWD_STREAM_KB + 2 * 32;
+// split-bf16 inference chain (mlp_bf16x3.hip): every k-step row twice (W_hi, W_lo)
+constexpr int BF_X3_STREAM_KB = 4 * 18 + 28 * 66 + 4 * 82 + 33 + 4 * 32 + 17;
 struct RcPackDesc {
   long long src_off, dst_off;   // params leaf / first row written, in floats from the workspace base
-  int kind;                     // 0: k-step rows of weights, 1: the bias row
+  int kind;                     // 0: k-step rows of weights, 1: the bias row, 2: a zero row
   int src_ld, row0, krows, ncols;   // leaf column count, first row, valid K and valid M (output index of the GEMM)
   int ngroups, nout, nout_panel, o0;   // rows written, output blocks written, blocks per row of the chunk, first block position in the row
   int transposed;               // 0: A[m][k] = leaf[row0 + k][m] (forward); 1: A[m][k] = leaf[row0 + m][k] (dgrad: W as is)
@@ -109,7 +111,10 @@ struct RcPackDesc {
   // two leaves side by side (the SE3 heads w | v, [128, 3] each): split > 0 -> indices >= split of the OUTPUT columns (forward,
   // bias) or of K (transposed) read leaf src_off2 at index - split
   long long src_off2;
-  int split, pad_;
+  int split;
+  // split-bf16 stream (mlp_bf16x3.hip): kind 0 writes TWO rows per k-step -- bf16(W), bf16(W - bf16(W)) -- and
+  // `ngroups` counts those rows; kind 1 writes the bias as the triple (hi, lo, lo2) in k-slots 0..2
+  int x3;
 };
 void launch_bf16_pack(const RcPackDesc* descs, int ndesc, const float* params, float* ws, hipStream_t stream);
 
@@ -515,6 +520,8 @@ struct EmbedDesc {
   int rows, ext_cols, int_cols, split, shift, pad_;
 };
 void launch_chain_fwd_bf16(const struct ChainFwdArgs& a, int max_grid, hipStream_t stream);
+// split-bf16 ("bf16x3", float32-emulating) inference chain: a.wpk = the x3 weight stream
+void launch_chain_fwd_x3(const struct ChainFwdArgs& a, int max_grid, hipStream_t stream);
 // bf16 SE3 trunk: forward of one or two levels (a1: e.g. the background batch) or the tangent pass (a.prim_... set);
 // reverse of up to three levels, or of the tangent pass
 void launch_warp_fwd_bf16(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int max_grid, hipStream_t stream);

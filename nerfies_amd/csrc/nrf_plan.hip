@@ -206,6 +206,7 @@ constexpr int AUTO32_FWD_BELOW_TILES_PER_CU = 2;
 uint32_t plan_flags(uint32_t flags) {
   uint32_t f = flags & (NRF_FLAG_TRAIN | NRF_FLAG_WARP_JACOBIAN);
   if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_BF16)) f |= NRF_FLAG_BF16 | (flags & NRF_FLAG_WARP_F32);
+  if (!(flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_BF16X3)) f |= NRF_FLAG_BF16X3;   // its own (tripled) weight streams
   return f;
 }
 
@@ -230,6 +231,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
   const nrf_model_desc& d = h->d;
   const bool train = flags & NRF_FLAG_TRAIN;
   const bool bft = train && (flags & NRF_FLAG_BF16);   // bf16 training: the NeRF MLPs stash / differentiate in bfloat16
+  const bool x3 = !train && (flags & NRF_FLAG_BF16X3);  // split-bf16 inference chains (mlp_bf16x3.hip)
   const bool jac = (flags & NRF_FLAG_WARP_JACOBIAN) && h->warp;   // tangent pass in an inference plan
   const bool bfw = bft && h->warp && !(flags & NRF_FLAG_WARP_F32);   // ... and so does the SE3 trunk (warp_bf16.hip)
   const bool wstash = (train && !bfw) || jac;                      // the fp32 warp kernels keep their input / sign-bit stash
@@ -547,7 +549,9 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
   if (!train || bft) {   // weight streams of the bf16 chains (mlp_bf16.hip): chunks (panels) in execution order
     for (int lv = 0; lv < h->nlevels; ++lv) {
       const MlpParamOffsets& po = h->po[lv];
-      p.L[lv].bf_wpk = take((size_t)BF_FWD_STREAM_KB * 256);   // KiB -> floats
+      // x3: the same GEMM sequence with every k-step row doubled (W_hi, W_lo); the kernel cuts a panel's rows into chunks itself
+      const size_t fwd_kb = x3 ? BF_X3_STREAM_KB : BF_FWD_STREAM_KB;
+      p.L[lv].bf_wpk = take(fwd_kb * 256);   // KiB -> floats
       size_t at = 0;   // floats from the level's stream base
       size_t base = p.L[lv].bf_wpk;
       int tr = 0;
@@ -562,13 +566,13 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
             memset(&e, 0, sizeof(e));
             e.src_off = src; e.dst_off = (long long)(base + at + (size_t)row * pb * 256); e.kind = kind; e.src_ld = ld; e.row0 = row0;
             e.krows = krows; e.ncols = ncols; e.ngroups = nrows; e.nout = pb; e.nout_panel = pb; e.o0 = 0; e.transposed = tr;
-            e.oblk0 = pn * pb;
+            e.oblk0 = pn * pb; e.x3 = x3 && !tr;
             p.bfpack.push_back(e);
             row += nrows;
           };
           if (bias >= 0) emit(1, bias, 0, 0, 0, 1);
           else if (bias == -2) emit(2, 0, 0, 0, 0, 1);   // a zero row where the kernel runs a bias-style k-step this model does not use
-          for (const Part& q : parts) emit(0, q.leaf, q.ld, q.row0, q.krows, 2 * q.nin);
+          for (const Part& q : parts) emit(0, q.leaf, q.ld, q.row0, q.krows, (x3 && !tr ? 2 : 1) * 2 * q.nin);
           at += (size_t)row * pb * 256;
         }
       };
@@ -581,7 +585,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
       gemm(1, 1, 1, po.alpha_b, {{po.alpha_k, 1, 0, TRUNK_W, 8}});               // alpha head: one block, column 0
       gemm(2, 4, RGB_W, -1, {{po.rgbh_k, RGB_W, 0, TRUNK_W, 8}});                // rgb hidden (bias: the fp32 per-ray term)
       gemm(1, 1, 3, po.logit_b, {{po.logit_k, 3, 0, RGB_W, 4}});                 // rgb logits: one block, columns 0..2
-      p.bf_stream_ok = at == (size_t)BF_FWD_STREAM_KB * 256;
+      p.bf_stream_ok = at == fwd_kb * 256;
       if (bft) {
         // dgrad stream (nerf_mlp_bwd_bf16_kernel): A = W as stored, [m = the layer's input feature][k = its output feature];
         // ncols = valid M, Part.krows = valid K
@@ -601,7 +605,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
         p.bf_stream_ok = p.bf_stream_ok && at == (size_t)(h->warp ? BF_BWD_STREAM_DPTS_KB : BF_BWD_STREAM_KB) * 256;
       }
     }
-    if (h->warp) {   // bf16 SE3 trunk (warp_bf16.hip): forward stream (also for bf16 inference), reverse stream (training)
+    if (h->warp && !x3) {   // bf16 SE3 trunk (warp_bf16.hip): forward stream (also for bf16 inference), reverse stream (training)
       const WarpParamOffsets& w = h->wpo;
       size_t at = 0, base = 0;
       int tr = 0;

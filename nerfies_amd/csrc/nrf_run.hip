@@ -191,10 +191,11 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   pf.begin("pack_prep_sample", 0, stream);
   if (!p.pack.empty()) launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
   const bool bf16 = flags & NRF_FLAG_BF16;
+  const bool x3 = (flags & NRF_FLAG_BF16X3) != 0;   // split-bf16 NeRF chains (inference; check_flags); the warp field stays float32
   // the SE3 trunk follows the MLPs into bf16 unless the caller opts out (NRF_FLAG_WARP_F32) or asks for the Jacobian output
   // (inference tangent pass: fp32 kernels); a training plan has decided already (its stash layout depends on it)
   const bool bfw_on = warp_on && bf16 && (train ? p.bfw : !(flags & NRF_FLAG_WARP_F32) && !jac);
-  if (bf16) launch_bf16_pack(reinterpret_cast<const RcPackDesc*>(ws + p.bf_desc), (int)p.bfpack.size(), params, ws, stream);
+  if (bf16 || x3) launch_bf16_pack(reinterpret_cast<const RcPackDesc*>(ws + p.bf_desc), (int)p.bfpack.size(), params, ws, stream);
   const float* viewdirs = rays->viewdirs ? rays->viewdirs : rays->directions;   // models.py:326-329
   {
     RayPrepArgs ra;
@@ -237,7 +238,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
     }
     ChainFwdArgs a = fwd_args(h, lv, params, rays, ws, train, rnd, dyn);
     const int gmul = knobs().grid_mul;
-    const bool c32 = !bf16 && chain32_for(h, p.ntiles[lv]);   // 32-row half tiles, four workgroups per CU
+    const bool c32 = !bf16 && !x3 && chain32_for(h, p.ntiles[lv]);   // 32-row half tiles, four workgroups per CU
     const int grid = c32 ? (2 * p.ntiles[lv] < 4 * h->num_cus ? 2 * p.ntiles[lv] : 4 * h->num_cus)
                          : (p.ntiles[lv] < gmul * h->num_cus ? p.ntiles[lv] : gmul * h->num_cus);   // two workgroups per CU
     if (warp_on) {
@@ -278,6 +279,9 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
     if (bf16) {   // one workgroup per CU (90 KiB of weight staging), 256 samples per workgroup iteration
       a.wpk = ws + L.bf_wpk;
       launch_chain_fwd_bf16(a, h->num_cus, stream);
+    } else if (x3) {   // one four-wave workgroup per CU (150 KiB ring), 128 samples per workgroup iteration
+      a.wpk = ws + L.bf_wpk;
+      launch_chain_fwd_x3(a, h->num_cus, stream);
     } else {
       if (c32) launch_chain_fwd32(a, train, grid, stream);
       else launch_chain_fwd(a, train, grid, stream);

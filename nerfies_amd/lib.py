@@ -11,6 +11,7 @@ NRF_FLAG_NO_WARP = 2
 NRF_FLAG_BF16 = 4
 NRF_FLAG_WARP_JACOBIAN = 8
 NRF_FLAG_WARP_F32 = 16
+NRF_FLAG_BF16X3 = 32
 NRF_NUM_STATS = 16
 ACT = {'relu': 0, 'softplus': 1}
 WARP_FIELD = {'se3': 0, 'translation': 1}

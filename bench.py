@@ -404,6 +404,7 @@ def eval_parity(dev, num_rays=256, threads=32):
           'metadata': {'warp': b64['metadata']['warp'].to(dev)}}
   alpha = 8.0
   out = model.apply({'params': fp}, rays, {'alpha': alpha})
+  out_x3 = model.apply({'params': fp}, rays, {'alpha': alpha}, bf16='x3')   # the split-bf16 (float32-emulating) chains on the same rays
   torch.cuda.synchronize()
   prev = torch.get_num_threads()
   torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1)))
@@ -418,7 +419,13 @@ def eval_parity(dev, num_rays=256, threads=32):
   mse = float(((out['fine']['rgb'].cpu().double() - ref['fine']['rgb']) ** 2).mean())
   import math
   worst = max(max(v.values()) for v in err.values())
-  return {'rays': num_rays, 'workload': 'config E (eval.py render): 128+128 samples, SE3 warp F_w=8 G=8 alpha=8, deterministic, fp32',
+  err3 = {lv: {k: float((out_x3[lv][k].cpu().double() - ref[lv][k]).abs().max()) for k in ('rgb', 'depth', 'acc')} for lv in ('coarse', 'fine')}
+  mse3 = float(((out_x3['fine']['rgb'].cpu().double() - ref['fine']['rgb']) ** 2).mean())
+  x3 = {'mode': 'NRF_FLAG_BF16X3: split-bf16 NeRF chains, float32 warp field', 'max_abs_rgb': err3['fine']['rgb'], 'max_abs_depth': err3['fine']['depth'],
+        'max_abs_acc': err3['fine']['acc'], 'max_abs_coarse': err3['coarse'], 'psnr_vs_oracle_db': (-10.0 * math.log10(mse3)) if mse3 > 0 else float('inf'),
+        'max_abs_rgb_vs_f32_path': float((out_x3['fine']['rgb'] - out['fine']['rgb']).abs().max()),
+        'pass': bool(max(max(v.values()) for v in err3.values()) <= 1e-3)}
+  return {'rays': num_rays, 'bf16x3': x3, 'workload': 'config E (eval.py render): 128+128 samples, SE3 warp F_w=8 G=8 alpha=8, deterministic, fp32',
           'against': 'float64 oracle (oracle/nerfies_oracle.py, pinned to the reference-run vectors tests/golden/ref_*.npz)',
           'max_abs_rgb': err['fine']['rgb'], 'max_abs_depth': err['fine']['depth'], 'max_abs_acc': err['fine']['acc'],
           'max_abs_coarse': err['coarse'], 'psnr_vs_oracle_db': (-10.0 * math.log10(mse)) if mse > 0 else float('inf'),
@@ -447,16 +454,21 @@ def secondary_lines(args, ctx):
     except Exception as e:   # noqa: BLE001  (a secondary line must never take the headline down)
       out.append({'mode': mode, 'dtype': 'bf16' if bf16 else 'f32', 'error': f'{type(e).__name__}: {e}'[:300]})
     torch.cuda.empty_cache()
-  t0 = time.perf_counter()
-  try:
-    ea = argparse.Namespace(**dict(vars(args), burn_in_s=0.5, steps=10, warmup=2, warp=True, frame=False))
-    line = eval_mode(ea, ctx['world'], ctx['rank'], ctx['dev'], False, emit=False)
-    out.append({'mode': 'eval_warp', 'dtype': 'f32', 'value': line['value'], 'unit': 'rays/s', 'ms_per_step': line['ms_per_step'],
-                'steps': ea.steps, 'rays_per_gpu': 8192, 'step_tflops': line['step_tflops'],
-                'roofline': {k: line['roofline'].get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'kernel_ms', 'frac_at_clock')},
-                'seconds': time.perf_counter() - t0})
-  except Exception as e:   # noqa: BLE001
-    out.append({'mode': 'eval_warp', 'dtype': 'f32', 'error': f'{type(e).__name__}: {e}'[:300]})
+  # eval (configs[4]): with the SE3 warp in float32 (what eval.py renders), and the split-bf16 (float32-emulating) NeRF chains with
+  # and without the warp in front (NRF_FLAG_BF16X3; the warp field stays float32)
+  for mode, warp, prec, dtype in (('eval_warp', True, False, 'f32'), ('eval_x3', False, 'x3', 'bf16x3 (fp32-emulating)'),
+                                  ('eval_warp_x3', True, 'x3', 'bf16x3 (fp32-emulating) NeRF MLPs + f32 warp field')):
+    t0 = time.perf_counter()
+    try:
+      ea = argparse.Namespace(**dict(vars(args), burn_in_s=0.5, steps=10, warmup=2, warp=warp, frame=False))
+      line = eval_mode(ea, ctx['world'], ctx['rank'], ctx['dev'], prec, emit=False)
+      out.append({'mode': mode, 'dtype': dtype, 'value': line['value'], 'unit': 'rays/s', 'ms_per_step': line['ms_per_step'],
+                  'steps': ea.steps, 'rays_per_gpu': 8192, 'step_tflops': line['step_tflops'],
+                  'roofline': {k: line['roofline'].get(k) for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac', 'kernel_ms', 'frac_at_clock')},
+                  'seconds': time.perf_counter() - t0})
+    except Exception as e:   # noqa: BLE001
+      out.append({'mode': mode, 'dtype': dtype, 'error': f'{type(e).__name__}: {e}'[:300]})
+    torch.cuda.empty_cache()
   torch.cuda.empty_cache()
   return out
 
@@ -643,7 +655,7 @@ def eval_mode(args, world, rank, dev, bf16, emit=True):
                   (' [split-bf16 (bf16x3) MLP arithmetic]' if bf16 == 'x3' else ' [bf16 MLP operands]' if bf16 else ''),
         'value': world * n * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'bf16x3 (fp32-emulating)' if bf16 == 'x3' else
+        'dtype': ('bf16x3 (fp32-emulating) NeRF MLPs + f32 warp field' if args.warp else 'bf16x3 (fp32-emulating)') if bf16 == 'x3' else
                  ('bf16 NeRF MLPs + f32 warp field' if (args.warp and bf16 == 'mlp') else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': f'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, {warp_txt}, deterministic, forward only',
                    'rays_per_gpu': n, 'parallelism': f'ray-shard dp{world}'},

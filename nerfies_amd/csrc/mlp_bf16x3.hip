@@ -11,14 +11,19 @@
 // Design = bf16_chain.h (transposed panel-outer chain, weights through a three-slot LDS ring, activations in registers), with
 //   * every k-step row of the weight stream doubled -- (W_hi, W_lo) -- by the pack kernel (RcPackDesc.x3); the inner loop (x3_panel
 //     below) reads a W_hi fragment ONCE for its two MFMAs (against x_hi and x_lo) and a W_lo fragment for one: 2/3 ds_read_b128 per
-//     MFMA and 2/3 of the LDS-DMA refill of a tripled stream (the first version of this kernel: 7.8 ms for the fine level of an
-//     8192-ray chunk; a four-wave workgroup refills 1 KiB per 4 MFMAs, twice the eight-wave bf16 chains' rate, and the LDS array was
-//     the busiest unit);
-//   * a panel's rows cut into chunks of <= 17 rows (34 KiB ring slots);
-//   * activations kept as TWO packed register sets (hi, lo): 2 x 64 registers per 256-wide layer and side, i.e. a wave needs the
-//     whole 512-register file: four waves per workgroup, one per SIMD, 128 samples per workgroup iteration;
-//   * the epilogue unit (ReLU, hi = pack, lo = pack(x - hi): 8 VALU per register pair) rides between the MFMAs of the next panel;
+//     MFMA and 2/3 of the ring refill of a tripled stream.  A four-wave workgroup refills 1 KiB per 4 MFMAs -- twice the eight-wave
+//     bf16 chains' rate -- and the LDS array was the busiest unit of the first version (tripled rows through bf_panel unchanged:
+//     7.6 ms for the fine level of an 8192-ray chunk; W_hi once: 6.6 ms; same-box A/B, profiles/r06_experiments.md section 5);
+//   * the refill of chunk g+2 spread one piece per MFMA behind the chunk's barrier instead of one burst (a wave is alone on its
+//     SIMD: nobody else feeds the matrix pipe while it issues ~60 scalar / VMEM instructions): 6.6 -> 6.1 ms;
+//   * a panel's rows cut into chunks of <= 17 rows (34 KiB ring slots, 102 of the CU's 160 KiB);
+//   * activations kept as TWO packed register sets (hi, lo): 2 x 64 registers per 256-wide layer and side, i.e. a wave needs most of
+//     the 512-register file (460-486 allocated, nothing in scratch): four waves per workgroup, one per SIMD, 128 samples per iteration;
+//   * the epilogue unit (ReLU, hi = pack, lo = pack(x - hi): 7 VALU per register pair + the moves between the VGPR and AGPR halves)
+//     rides between the MFMAs of the next panel;
 //   * posenc by sinf (the float32 chains' function), bias as a (hi, lo, lo2) triple against B = 1.
+// Not a lever here (same-box A/B): the fragment prefetch depth (8 vs 12), the VALU group sizes of the riding epilogue, laundering the
+// slot bases so the ds_read offsets fit their immediates (that one LOSES 20 %).
 // Inference only: the training path keeps its float32 / bf16 stashes.
 #include <stdlib.h>
 
@@ -87,6 +92,11 @@ __device__ __forceinline__ void x3_panel(f32x16 (&acc)[PB], ChainCtx& c, int byt
 #pragma unroll
     for (int p = 0; p < PB; ++p) acc[p] = zero;
   }
+  // The refill of chunk g+2 (<= 34 pieces of 1 KiB, every wave a quarter) is NOT issued in one burst behind the barrier: a wave is alone
+  // on its SIMD here, and ~9 pieces x 7 scalar / VMEM instructions in a row let the matrix pipe run dry (~250 clocks per chunk).  One
+  // piece rides behind each of the MFMAs that follow the barrier; the data is needed a whole chunk later.
+  const int npieces = bytes2 >> 10, full = npieces >> 2, rem = npieces & 3;
+  const unsigned dst = rg.lds0 + (unsigned)(s2 * X3_SLOT);
 #pragma unroll
   for (int m = 0; m < NM; ++m) {
     if (m == MSYNC) {
@@ -94,7 +104,7 @@ __device__ __forceinline__ void x3_panel(f32x16 (&acc)[PB], ChainCtx& c, int byt
       bf_wait_vm<0>();                   // my pieces of chunk g+1 (copied one chunk ago) have landed
       __builtin_amdgcn_s_barrier();      // ... and everyone's; all waves are done with chunk g-1's slot
       asm volatile("" ::: "memory");
-      bf_ring_copy<X3_SLOT>(rg, s2, bytes2, c.wave);
+      rg.soff = __builtin_amdgcn_readfirstlane(rg.soff);
       __builtin_amdgcn_sched_barrier(0);
     }
     const int f = M::frag(m), v = M::variant(m), p = M::blk(m);
@@ -106,7 +116,17 @@ __device__ __forceinline__ void x3_panel(f32x16 (&acc)[PB], ChainCtx& c, int byt
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     if (M::last_use(m)) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     if constexpr (ESPAN > 0) sgb_valu_n(epi_units_at(m, ESPAN) * EOPS + 2);
+    if (m >= MSYNC) {   // piece (m - MSYNC) of this wave's share: pieces wave, wave + 4, ...
+      const int j = m - MSYNC;
+      static_assert(NM - MSYNC >= 10, "the slots behind the barrier must take a wave's share of the largest chunk (9 pieces)");
+      if (j < full || (j == full && c.wave < rem)) {
+        const int pc = c.wave + 4 * j;
+        lds_dma16s<false>(rg.src + rg.soff + pc * BF_KB, rg.voff, dst + (unsigned)(pc * BF_KB));
+      }
+    }
   }
+  rg.soff += bytes2;
+  if (rg.soff >= rg.total) rg.soff = 0;
   if constexpr (NF % BF_DF != 0) {   // slot i <- fragment i of the next chunk
     bf16x8 t[BF_DF];
 #pragma unroll

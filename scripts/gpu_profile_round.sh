@@ -8,7 +8,7 @@
 # Passes are separate processes: bench line, rocprofv3 kernel trace, three PMC passes (SQ / FETCH_SIZE / WRITE_SIZE never
 # share a pass, never combined with a trace domain).
 TAG=${1:-r04}
-MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_warp eval_warp_bf16 train128 train128_graph sustained sustained_bf16"}
+MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_x3 eval_warp eval_warp_bf16 eval_warp_x3 train128 train128_graph sustained sustained_bf16"}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -30,6 +30,8 @@ for mode in $MODES; do
     fullhd_bf16)    ARGS="--mode fullhd --bf16";               SUF="_fullhd_bf16" ;;
     eval)           ARGS="--mode eval";                        SUF="_eval"; PMC=0 ;;
     eval_bf16)      ARGS="--mode eval --bf16";                 SUF="_eval_bf16"; PMC=0 ;;
+    eval_x3)        ARGS="--mode eval --split-bf16";           SUF="_eval_x3"; PMC=0 ;;
+    eval_warp_x3)   ARGS="--mode eval --warp --frame --split-bf16"; SUF="_eval_warp_x3"; PMC=0 ;;
     eval_warp)      ARGS="--mode eval --warp --frame";         SUF="_eval_warp"; PMC=0 ;;
     eval_warp_bf16) ARGS="--mode eval --warp --frame --bf16";  SUF="_eval_warp_bf16"; PMC=0 ;;
     train128)       ARGS="--rays-per-gpu 128";                 SUF="_train128"; PMC=0; TRACE=0 ;;
@@ -54,7 +56,7 @@ for mode in $MODES; do
     timeout 300 rocprofv3 --pmc $ICC -d $O/pmc5_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc5_${TAG}${SUF}.log 2>&1
     summ $O/pmc5_${TAG}${SUF} $O/${TAG}${SUF}_pmc_icache.md; clean $O/pmc5_${TAG}${SUF} ;;
   esac
-  case $mode in *bf16*)
+  case $mode in *bf16*|*x3*)
     timeout 300 rocprofv3 --pmc $LDSC -d $O/pmc4_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc4_${TAG}${SUF}.log 2>&1
     summ $O/pmc4_${TAG}${SUF} $O/${TAG}${SUF}_pmc_lds.md; clean $O/pmc4_${TAG}${SUF} ;;
   esac

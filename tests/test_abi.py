@@ -62,6 +62,8 @@ def test_struct_sizes_match_header():
     assert [f[0] for f in ct._fields_] == names, (cname, names)
   assert '#define NRF_NUM_STATS %d' % L.NRF_NUM_STATS in src
   assert '#define NRF_FLAG_WARP_JACOBIAN %du' % L.NRF_FLAG_WARP_JACOBIAN in src
+  for name in ('NRF_FLAG_TRAIN', 'NRF_FLAG_NO_WARP', 'NRF_FLAG_BF16', 'NRF_FLAG_WARP_F32', 'NRF_FLAG_BF16X3'):   # every flag bit, header == ctypes side
+    assert re.search(r'#define %s %du\b' % (name, getattr(L, name)), src), name
 
 
 def test_ctypes_mirrors_match_the_compiled_header(tmp_path):

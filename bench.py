@@ -1024,7 +1024,9 @@ def main(argv=None):
       # of the three certificates rides in `config` (it still names the workload; the full objects are top-level keys)
       ep, sec, sus = out['eval_parity'], out['secondary'], out['sustained']
       out['config']['certified_in_this_run'] = {
-          'eval_parity': {k: ep.get(k) for k in ('rays', 'max_abs_rgb', 'max_abs_depth', 'psnr_vs_oracle_db', 'pass', 'error') if k in ep},
+          'eval_parity': dict({k: ep.get(k) for k in ('rays', 'max_abs_rgb', 'max_abs_depth', 'psnr_vs_oracle_db', 'pass', 'error') if k in ep},
+                              **({'bf16x3': {k: ep['bf16x3'].get(k) for k in ('max_abs_rgb', 'max_abs_depth', 'psnr_vs_oracle_db', 'max_abs_rgb_vs_f32_path', 'pass')}}
+                                 if isinstance(ep.get('bf16x3'), dict) else {})),
           'secondary': [{k: (x.get('roofline') or {}).get('frac') if k == 'roofline_frac' else x.get(k)
                          for k in ('mode', 'dtype', 'value', 'ms_per_step', 'roofline_frac', 'error') if k == 'roofline_frac' or k in x}
                         for x in sec],

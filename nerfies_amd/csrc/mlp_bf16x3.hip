@@ -19,7 +19,7 @@
 //   * a panel's rows cut into chunks of <= 17 rows (34 KiB ring slots, 102 of the CU's 160 KiB);
 //   * activations kept as TWO packed register sets (hi, lo): 2 x 64 registers per 256-wide layer and side, i.e. a wave needs most of
 //     the 512-register file (460-486 allocated, nothing in scratch): four waves per workgroup, one per SIMD, 128 samples per iteration;
-//   * the epilogue unit (ReLU, hi = pack, lo = pack(x - hi): 7 VALU per register pair + the moves between the VGPR and AGPR halves)
+//   * the epilogue unit (ReLU, hi = pack, lo = pack(x - hi): 9 VALU per register pair + the moves between the VGPR and AGPR halves)
 //     rides between the MFMAs of the next panel;
 //   * posenc by sinf (the float32 chains' function), bias as a (hi, lo, lo2) triple against B = 1.
 // Not a lever here (same-box A/B): the fragment prefetch depth (8 vs 12), the VALU group sizes of the riding epilogue, laundering the
@@ -142,19 +142,19 @@ __device__ __forceinline__ void x3_panel(f32x16 (&acc)[PB], ChainCtx& c, int byt
 #ifndef NRF_X3_EOPS
 #define NRF_X3_EOPS 9
 #endif
-#ifndef NRF_X3_RELU_ASM
-#define NRF_X3_RELU_ASM 1
-#endif
 __device__ __forceinline__ constexpr int x3_ops(bool relu) { return NRF_X3_EOPS + (relu ? 2 : 0); }
-// max(x, 0) as ONE instruction: fmaxf() canonicalises its operand first (v_max_f32 x, x, x: IEEE sNaN quieting), 4 VALU per pair
+// max(x, 0) of an accumulator element.  fmaxf() canonicalises its operand first (v_max_f32 x, x: IEEE sNaN quieting; 4 VALU per pair)
+// and every pure-compiler form tried (fmaxf, integer max, ReLU on the packed pair + a mask for the lo pair) ends with 45-82 spilled
+// VGPRs and a 10 % slower kernel; `v_max_f32 r, 0, x` as an asm statement does not (0 spills).  But hipcc's hazard recognizer does not
+// see what an asm statement reads, and nothing interlocks a VALU read behind the MFMA that writes the register: the value therefore
+// passes through an identity DPP move first -- a VALU instruction the compiler knows, so the wait states behind the MFMA are its
+// business -- and the asm reads the copy (+3 % against the raw asm, same-box A/B; profiles/r06_experiments.md section 5).  A whole
+// unit as one volatile asm statement was tried on all three inference chains and dropped: the SE3 chain's output then depended on timing.
 __device__ __forceinline__ float relu1(float x) {
-#if NRF_X3_RELU_ASM
   float r;
-  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  const float y = __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), 0xE4, 0xF, 0xF, true));
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(y));
   return r;
-#else
-  return fmaxf(x, 0.f);
-#endif
 }
 
 // Units of a pending panel (2 blocks = 16 register pairs) that fall on slot k: accumulators -> (ReLU) -> hi / lo bf16 pairs

@@ -421,7 +421,7 @@ def eval_parity(dev, num_rays=256, threads=32):
   worst = max(max(v.values()) for v in err.values())
   err3 = {lv: {k: float((out_x3[lv][k].cpu().double() - ref[lv][k]).abs().max()) for k in ('rgb', 'depth', 'acc')} for lv in ('coarse', 'fine')}
   mse3 = float(((out_x3['fine']['rgb'].cpu().double() - ref['fine']['rgb']) ** 2).mean())
-  x3 = {'mode': 'NRF_FLAG_BF16X3: split-bf16 NeRF chains, float32 warp field', 'max_abs_rgb': err3['fine']['rgb'], 'max_abs_depth': err3['fine']['depth'],
+  x3 = {'mode': 'NRF_FLAG_BF16X3: split-bf16 NeRF chains and SE3 trunk', 'max_abs_rgb': err3['fine']['rgb'], 'max_abs_depth': err3['fine']['depth'],
         'max_abs_acc': err3['fine']['acc'], 'max_abs_coarse': err3['coarse'], 'psnr_vs_oracle_db': (-10.0 * math.log10(mse3)) if mse3 > 0 else float('inf'),
         'max_abs_rgb_vs_f32_path': float((out_x3['fine']['rgb'] - out['fine']['rgb']).abs().max()),
         'pass': bool(max(max(v.values()) for v in err3.values()) <= 1e-3)}
@@ -454,10 +454,10 @@ def secondary_lines(args, ctx):
     except Exception as e:   # noqa: BLE001  (a secondary line must never take the headline down)
       out.append({'mode': mode, 'dtype': 'bf16' if bf16 else 'f32', 'error': f'{type(e).__name__}: {e}'[:300]})
     torch.cuda.empty_cache()
-  # eval (configs[4]): with the SE3 warp in float32 (what eval.py renders), and the split-bf16 (float32-emulating) NeRF chains with
-  # and without the warp in front (NRF_FLAG_BF16X3; the warp field stays float32)
+  # eval (configs[4]): with the SE3 warp in float32 (what eval.py renders), and the split-bf16 (float32-emulating) mode without and
+  # with the warp (NRF_FLAG_BF16X3: NeRF chains and SE3 trunk)
   for mode, warp, prec, dtype in (('eval_warp', True, False, 'f32'), ('eval_x3', False, 'x3', 'bf16x3 (fp32-emulating)'),
-                                  ('eval_warp_x3', True, 'x3', 'bf16x3 (fp32-emulating) NeRF MLPs + f32 warp field')):
+                                  ('eval_warp_x3', True, 'x3', 'bf16x3 (fp32-emulating)')):
     t0 = time.perf_counter()
     try:
       ea = argparse.Namespace(**dict(vars(args), burn_in_s=0.5, steps=10, warmup=2, warp=warp, frame=False))
@@ -531,9 +531,9 @@ def roofline_of(prof, bf16, mode_key, rays_per_gpu, cfg):
   traffic, traffic_src = hbm_traffic(dom['name'], mode_key)
   # the NeRF-MLP kernels run on bf16 MFMA in the bf16 modes, and so does the SE3 trunk unless --warp-f32 keeps it in float32
   # (bf16 == 'mlp'); the fp32 wgrad kernel never does
-  on_bf16 = bool(bf16) and (dom['name'].startswith('mlp_') or (bf16 not in ('mlp', 'x3') and dom['name'].startswith('warp_')))
+  on_bf16 = bool(bf16) and (dom['name'].startswith('mlp_') or (bf16 not in ('mlp', 'x3mlp') and dom['name'].startswith('warp_')))
   peak_tf = PEAK_BF16_MFMA_TFLOPS if on_bf16 else PEAK_FP32_MFMA_TFLOPS
-  if on_bf16 and bf16 == 'x3':
+  if on_bf16 and bf16 in ('x3', 'x3mlp'):
     # split-bf16: the ALGORITHMIC flops of the layer (what `achieved` counts) cost three bf16 MFMAs each (hi.hi + lo.hi + hi.lo)
     peak_tf = PEAK_BF16_MFMA_TFLOPS / 3.0
   r = {'bound': 'mfma', 'kernel': dom['name'], 'achieved': achieved, 'peak': peak_tf, 'unit': 'TFLOP/s', 'frac': achieved / peak_tf,
@@ -642,8 +642,8 @@ def eval_mode(args, world, rank, dev, bf16, emit=True):
   prof = model.profile_read()
   model.profile_enable(False)
   if rank == 0:
-    roofline, peak = roofline_of(prof, bf16, ('eval_warp' if args.warp else 'eval') + ('_x3' if bf16 == 'x3' else '_bf16' if bf16 else ''), n, cfg)
-    if bf16 == 'x3':
+    roofline, peak = roofline_of(prof, bf16, ('eval_warp' if args.warp else 'eval') + ('_x3' if bf16 in ('x3', 'x3mlp') else '_bf16' if bf16 else ''), n, cfg)
+    if bf16 in ('x3', 'x3mlp'):
       roofline['peak_note'] = ('dense bf16 MFMA peak / 3: every algorithmic multiply-add is three bf16 MFMAs (hi.hi + lo.hi + hi.lo, fp32 accumulate); '
                                'the float32 chains it emulates are priced against 157.3 TFLOP/s')
     at_clock(roofline, clocks)
@@ -652,10 +652,10 @@ def eval_mode(args, world, rank, dev, bf16, emit=True):
     warp_txt = 'SE3 warp F_w=8 G=8 (one warp id per chunk)' if args.warp else 'warp off'
     line = {
         'metric': 'eval rays/sec (128+128 samples/ray, forward only, hipGraph replay)' + (' [SE3 warp on]' if args.warp else '') +
-                  (' [split-bf16 (bf16x3) MLP arithmetic]' if bf16 == 'x3' else ' [bf16 MLP operands]' if bf16 else ''),
+                  (' [split-bf16 (bf16x3) arithmetic: NeRF MLPs' + (' + SE3 trunk]' if (args.warp and bf16 == 'x3') else ']') if bf16 in ('x3', 'x3mlp') else ' [bf16 MLP operands]' if bf16 else ''),
         'value': world * n * args.steps / elapsed, 'unit': 'rays/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': ('bf16x3 (fp32-emulating) NeRF MLPs + f32 warp field' if args.warp else 'bf16x3 (fp32-emulating)') if bf16 == 'x3' else
+        'dtype': ('bf16x3 (fp32-emulating) NeRF MLPs + f32 warp field' if (args.warp and bf16 == 'x3mlp') else 'bf16x3 (fp32-emulating)') if bf16 in ('x3', 'x3mlp') else
                  ('bf16 NeRF MLPs + f32 warp field' if (args.warp and bf16 == 'mlp') else 'bf16') if bf16 else 'f32', 'data': 'synthetic',
         'config': {'workload': f'gpu eval/video shape: 8192-ray chunk x (128+128) samples, F_p=8, {warp_txt}, deterministic, forward only',
                    'rays_per_gpu': n, 'parallelism': f'ray-shard dp{world}'},
@@ -862,7 +862,7 @@ def main(argv=None):
   ap.add_argument('--no-strong', action='store_true', help='N>1: skip the nested strong-scaling record (1024-ray global batch)')
   ap.add_argument('--warp', action='store_true', help='eval mode: render with the SE3 warp field (the path eval.py takes)')
   ap.add_argument('--split-bf16', action='store_true',
-                  help='--mode eval: the NeRF MLPs in split-bf16 arithmetic (NRF_FLAG_BF16X3: every float32 operand as a bf16 pair, three bf16 '
+                  help='--mode eval: the NeRF MLPs and the SE3 trunk (--warp-f32: the MLPs only) in split-bf16 arithmetic (NRF_FLAG_BF16X3: every float32 operand as a bf16 pair, three bf16 '
                        'MFMAs per product, float32 accumulate -- float32-emulating, ~1e-6 of the float32 chains on rendered colour); the '
                        "line says dtype 'bf16x3 (fp32-emulating)', never 'f32'")
   ap.add_argument('--warp-f32', action='store_true', help='bf16 modes: keep the SE3 trunk in float32 (NRF_FLAG_WARP_F32; the round-3 behaviour)')
@@ -922,9 +922,9 @@ def main(argv=None):
   if bf16 and args.warp_f32:
     bf16 = 'mlp'
   if args.split_bf16:
-    if args.mode != 'eval' or bf16:
+    if args.mode != 'eval' or args.bf16 or os.environ.get('BENCH_BF16'):
       raise SystemExit('--split-bf16 is an inference mode (--mode eval) of its own, not combined with --bf16')
-    bf16 = 'x3'
+    bf16 = 'x3mlp' if args.warp_f32 else 'x3'   # --warp-f32: the SE3 trunk stays on the float32 kernels
   if args.mode == 'eval':
     eval_mode(args, world, rank, dev, bf16)
     if dist_on:

@@ -221,15 +221,18 @@ typedef struct nrf_outputs {
                                loss / Adam); an opt-in mode with no reference counterpart (BASELINE config D) -- ~1e-2 on
                                rendered colour */
 #define NRF_FLAG_WARP_JACOBIAN 8u /* return_warp_jacobian (models.py:297): forward-mode tangent pass of the warp per level */
-#define NRF_FLAG_WARP_F32 16u     /* with NRF_FLAG_BF16: keep SE3Field's 6 x 128 trunk on float32 operands (since 0.4.0 NRF_FLAG_BF16
+#define NRF_FLAG_WARP_F32 16u     /* with NRF_FLAG_BF16 (or NRF_FLAG_BF16X3): keep SE3Field's 6 x 128 trunk on float32 operands (since 0.4.0 NRF_FLAG_BF16
                                      runs it on bfloat16 operands as well: annealed posenc, exp_se3, (w, v), the Jacobian algebra and
                                      the GLO table stay float32); a call that returns the warp Jacobian uses the float32 trunk anyway */
 #define NRF_FLAG_BF16X3 32u       /* since 0.6.0, nrf_forward / nrf_workspace_bytes[_ex] only (inference): the NeRF MLPs
-                                     (modules.py:26-62, 95-169) in split-bfloat16 arithmetic -- every float32 operand as a bf16 pair
-                                     hi + lo, a product as hi.hi + lo.hi + hi.lo on the bf16 matrix pipe, float32 accumulate: float32-
-                                     EMULATING (product error ~2^-16; rendered colour within ~1e-5 of the float32 chains, far inside the
-                                     1e-3 parity gate), not bit-comparable with them.  The warp field, sampling and compositing stay
-                                     float32.  Not with NRF_FLAG_TRAIN or NRF_FLAG_BF16; same model limits as NRF_FLAG_BF16 */
+                                     (modules.py:26-62, 95-169) and SE3Field's trunk (warping.py:264-288) in split-bfloat16 arithmetic --
+                                     every float32 operand as a bf16 pair hi + lo, a product as hi.hi + hi.lo + lo.hi on the bf16 matrix
+                                     pipe, float32 accumulate: float32-EMULATING (an operand carries 16 mantissa bits; rendered colour
+                                     within ~1e-6 of the float32 chains without the warp, ~1e-5 with it -- a warped point moves by ~1e-5
+                                     and meets the 2^(F-1) posenc band --, far inside the 1e-3 parity gate), not bit-comparable with them.
+                                     Posenc, exp_se3, sampling and compositing stay float32.  NRF_FLAG_WARP_F32 keeps the SE3 trunk on
+                                     the float32 kernels (bit-identical warped points; a call that returns the warp Jacobian uses them
+                                     anyway).  Not with NRF_FLAG_TRAIN or NRF_FLAG_BF16; same model limits as NRF_FLAG_BF16 */
 
 int nrf_version(void);
 const char* nrf_last_error(void);

@@ -12,12 +12,12 @@ CSRC = os.path.join(HERE, 'csrc')
 LIB_DIR = os.path.join(HERE, '_lib')
 OBJ_DIR = os.path.join(LIB_DIR, 'obj')
 LIB_PATH = os.path.join(LIB_DIR, 'libnerfies_amd.so')
-SOURCES = ['mlp_chain.hip', 'mlp_chain32.hip', 'mlp_bf16.hip', 'mlp_bf16x3.hip', 'warp_bf16.hip', 'warp_chain.hip', 'wgrad.hip', 'wgrad_bf16.hip', 'ray_kernels.hip', 'camera.hip', 'time_encoder.hip', 'nrf_plan.hip', 'nrf_run.hip', 'nrf_api.hip']
+SOURCES = ['mlp_chain.hip', 'mlp_chain32.hip', 'mlp_bf16.hip', 'mlp_bf16x3.hip', 'warp_bf16.hip', 'warp_bf16x3.hip', 'warp_chain.hip', 'wgrad.hip', 'wgrad_bf16.hip', 'ray_kernels.hip', 'camera.hip', 'time_encoder.hip', 'nrf_plan.hip', 'nrf_run.hip', 'nrf_api.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC']
 # per-source extras.  mlp_bf16.hip: every chunk of the bf16 chains is a fully unrolled `#pragma unroll` loop (34-42 MFMA slots with
 # the previous panel's epilogue threaded through); above LLVM's default pragma-unroll threshold (16 k instructions) the loops
 # stay rolled until after SROA and the register arrays end up in scratch.
-EXTRA_FLAGS = {'mlp_bf16.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'], 'mlp_bf16x3.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'], 'warp_bf16.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
+EXTRA_FLAGS = {'mlp_bf16.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'], 'mlp_bf16x3.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'], 'warp_bf16x3.hip': ['-mllvm', '-pragma-unroll-threshold=1000000'], 'warp_bf16.hip': ['-mllvm', '-pragma-unroll-threshold=1000000']}
 
 
 def find_hipcc():

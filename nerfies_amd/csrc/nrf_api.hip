@@ -141,8 +141,8 @@ static int check_flags(const nrf_handle_s* h, uint32_t flags) {
   if ((flags & NRF_FLAG_BF16X3) && (flags & (NRF_FLAG_TRAIN | NRF_FLAG_BF16)))
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_BF16X3 is an inference mode of its own: not with NRF_FLAG_TRAIN (the training chains stash float32 or "
                                    "bfloat16 activations) and not with NRF_FLAG_BF16");
-  if ((flags & NRF_FLAG_WARP_F32) && !(flags & NRF_FLAG_BF16))
-    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_F32 only qualifies NRF_FLAG_BF16 (the float32 mode runs the warp trunk in float32 anyway)");
+  if ((flags & NRF_FLAG_WARP_F32) && !(flags & (NRF_FLAG_BF16 | NRF_FLAG_BF16X3)))
+    return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_F32 only qualifies NRF_FLAG_BF16 / NRF_FLAG_BF16X3 (the float32 mode runs the warp trunk in float32 anyway)");
   if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_WARP_JACOBIAN))
     return fail(NRF_E_UNSUPPORTED, "NRF_FLAG_WARP_JACOBIAN is an inference output (training consumes the Jacobian through nrf_elastic)");
   if ((flags & NRF_FLAG_TRAIN) && (flags & NRF_FLAG_NO_WARP))

@@ -145,6 +145,7 @@ struct BfStash {
 //   forward:  L0 2 x 10, L1..L3 + L5 2 x 18 each, L4 (skip) 2 x 26, heads 9
 //   reverse:  heads^T 8, L5..L1 2 x 16 each, code-gradient GEMMs C0 / C4 16 each (the tangent reverse stops before them)
 constexpr int BFW_FWD_STREAM_KB = 2 * 10 + 8 * 18 + 2 * 26 + 9;
+constexpr int BFW_X3_STREAM_KB = 2 * 18 + 8 * 34 + 2 * 50 + 17;   // split-bf16 inference trunk (warp_bf16x3.hip): rows (W_hi, W_lo)
 constexpr int BFW_BWD_TAN_STREAM_KB = 8 + 10 * 16;
 constexpr int BFW_BWD_STREAM_KB = BFW_BWD_TAN_STREAM_KB + 2 * 16;
 // Stash of one pass over one level, units as BfStash (32-row group x 32-feature block = 2 KiB)
@@ -526,6 +527,8 @@ void launch_chain_fwd_x3(const struct ChainFwdArgs& a, int max_grid, hipStream_t
 // reverse of up to three levels, or of the tangent pass
 void launch_warp_fwd_bf16(const WarpFwdArgs& a, const WarpFwdArgs* a1, bool stash, int max_grid, hipStream_t stream);
 void launch_warp_bwd_bf16(const WarpBwdArgs& a, const WarpBwdArgs* a1, const WarpBwdArgs* a2, int max_grid, hipStream_t stream);
+// split-bf16 (float32-emulating) SE3 trunk, inference forward of one level: a.bwpk = the x3 stream
+void launch_warp_fwd_x3(const WarpFwdArgs& a, int max_grid, hipStream_t stream);
 void launch_embed(const EmbedDesc* descs, int ndesc, const float* src, float* dst, bool to_internal, hipStream_t stream);
 
 // camera.hip -- Camera.pixels_to_rays / pixels_to_points / project (nerfies/camera.py)

@@ -605,7 +605,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
         p.bf_stream_ok = p.bf_stream_ok && at == (size_t)(h->warp ? BF_BWD_STREAM_DPTS_KB : BF_BWD_STREAM_KB) * 256;
       }
     }
-    if (h->warp && !x3) {   // bf16 SE3 trunk (warp_bf16.hip): forward stream (also for bf16 inference), reverse stream (training)
+    if (h->warp) {   // bf16 SE3 trunk (warp_bf16.hip): forward stream (also for bf16 inference), reverse stream (training); x3: its doubled rows (warp_bf16x3.hip)
       const WarpParamOffsets& w = h->wpo;
       size_t at = 0, base = 0;
       int tr = 0;
@@ -619,16 +619,17 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
             memset(&e, 0, sizeof(e));
             e.src_off = src; e.dst_off = (long long)(base + at + (size_t)row * pb * 256); e.kind = kind; e.src_ld = ld; e.row0 = row0;
             e.krows = krows; e.ncols = ncols; e.ngroups = nrows; e.nout = pb; e.nout_panel = pb; e.o0 = 0; e.transposed = tr;
-            e.oblk0 = pn * pb; e.src_off2 = src2 >= 0 ? src2 : 0; e.split = src2 >= 0 ? split : 0;
+            e.oblk0 = pn * pb; e.src_off2 = src2 >= 0 ? src2 : 0; e.split = src2 >= 0 ? split : 0; e.x3 = x3 && !tr;
             p.bfpack.push_back(e);
             row += nrows;
           };
           if (bias >= 0) emit(1, bias, bias2, bsplit, 0, 0, 0, 1);
-          for (const Part& q : parts) emit(0, q.leaf, q.leaf2, q.split, q.ld, q.row0, q.krows, 2 * q.nin);
+          for (const Part& q : parts) emit(0, q.leaf, q.leaf2, q.split, q.ld, q.row0, q.krows, (x3 && !tr ? 2 : 1) * 2 * q.nin);
           at += (size_t)row * pb * 256;
         }
       };
-      p.bfw_wpk = take((size_t)BFW_FWD_STREAM_KB * 256);
+      const size_t wfwd_kb = x3 ? BFW_X3_STREAM_KB : BFW_FWD_STREAM_KB;
+      p.bfw_wpk = take(wfwd_kb * 256);
       base = p.bfw_wpk;
       gemm(2, 4, WARP_W, w.trunk_b[0], -1, 0, {{w.trunk_k[0], WARP_W, 0, h->Win, 2}});
       for (int l = 1; l < WARP_DEPTH; ++l) {
@@ -636,7 +637,7 @@ void build_plan(nrf_handle h, int B, uint32_t flags, int bgN, int elastic) {
         else gemm(2, 4, WARP_W, w.trunk_b[l], -1, 0, {{w.trunk_k[l], WARP_W, 0, WARP_W, 4}});
       }
       gemm(1, 1, 6, w.w_b, w.v_b, 3, {{w.w_k, 3, 0, WARP_W, 4, w.v_k, 3}});     // heads: columns 0..2 = w, 3..5 = v
-      p.bf_stream_ok = p.bf_stream_ok && at == (size_t)BFW_FWD_STREAM_KB * 256;
+      p.bf_stream_ok = p.bf_stream_ok && at == wfwd_kb * 256;
       if (bfw) {
         // reverse stream: A = W as stored, [m = the layer's input feature][k = its output feature]
         p.bfw_wpkT = take((size_t)BFW_BWD_STREAM_KB * 256);

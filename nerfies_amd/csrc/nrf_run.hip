@@ -191,7 +191,7 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
   pf.begin("pack_prep_sample", 0, stream);
   if (!p.pack.empty()) launch_pack(reinterpret_cast<const PackDesc*>(tables + p.pack_off_b), (int)p.pack.size(), params, ws, stream);
   const bool bf16 = flags & NRF_FLAG_BF16;
-  const bool x3 = (flags & NRF_FLAG_BF16X3) != 0;   // split-bf16 NeRF chains (inference; check_flags); the warp field stays float32
+  const bool x3 = (flags & NRF_FLAG_BF16X3) != 0;   // split-bf16 NeRF chains and SE3 trunk (inference; check_flags)
   // the SE3 trunk follows the MLPs into bf16 unless the caller opts out (NRF_FLAG_WARP_F32) or asks for the Jacobian output
   // (inference tangent pass: fp32 kernels); a training plan has decided already (its stash layout depends on it)
   const bool bfw_on = warp_on && bf16 && (train ? p.bfw : !(flags & NRF_FLAG_WARP_F32) && !jac);
@@ -249,7 +249,11 @@ int forward_impl(nrf_handle h, const float* params_x, const nrf_rays* rays, cons
       const int wnt = p.ntiles[lv] + (with_bg ? p.ntiles[BG] : 0);
       const int wgrid = wnt < warp_grid_mul() * h->num_cus ? wnt : warp_grid_mul() * h->num_cus;
       pf.begin(lv == 0 ? "warp_fwd_coarse" : "warp_fwd_fine", warp_fwd_flops_row(h) * (p.rows[lv] + (with_bg ? p.bgN : 0)), stream);
-      if (bfw_on) {   // SE3 trunk on bf16 operands (warp_bf16.hip); one workgroup per CU, 256 rows per iteration
+      if (x3 && !jac && !(flags & NRF_FLAG_WARP_F32)) {   // SE3 trunk in split-bf16 arithmetic (warp_bf16x3.hip); the Jacobian output keeps the float32 kernels (their input stash)
+        WarpFwdArgs wa = warp_fwd_args(h, lv, params, rays, scalars, ws, false);
+        wa.bwpk = ws + p.bfw_wpk; wa.rows_pad = p.ntiles[lv] * TILE_ROWS;
+        launch_warp_fwd_x3(wa, h->num_cus, stream);
+      } else if (bfw_on) {   // SE3 trunk on bf16 operands (warp_bf16.hip); one workgroup per CU, 256 rows per iteration
         WarpFwdArgs wa = warp_fwd_args(h, lv, params, rays, scalars, ws, train);
         wa.bwpk = ws + p.bfw_wpk; wa.rows_pad = p.ntiles[lv] * TILE_ROWS;
         if (train) wa.bst = bfw_stash(p, lv, ws);

@@ -266,12 +266,14 @@ class NerfModel:
   @staticmethod
   def bf16_flags(bf16) -> int:
     """bf16=True: NRF_FLAG_BF16 (NeRF MLPs AND the SE3 trunk on bfloat16 operands); bf16='mlp': the NeRF MLPs only
-    (NRF_FLAG_WARP_F32: the round-3 behaviour); bf16='x3' (inference only): NRF_FLAG_BF16X3, the NeRF MLPs in split-bf16
-    (float32-emulating) arithmetic, everything else float32; False: float32."""
+    (NRF_FLAG_WARP_F32: the round-3 behaviour); bf16='x3' (inference only): NRF_FLAG_BF16X3, the NeRF MLPs and the SE3 trunk in split-bf16
+    (float32-emulating) arithmetic ('x3mlp': the trunk stays float32); False: float32."""
     if not bf16:
       return 0
     if bf16 == 'x3':
       return L.NRF_FLAG_BF16X3
+    if bf16 == 'x3mlp':   # split-bf16 NeRF MLPs, float32 SE3 trunk (bit-identical warped points)
+      return L.NRF_FLAG_BF16X3 | L.NRF_FLAG_WARP_F32
     if bf16 == 'mlp':
       return L.NRF_FLAG_BF16 | L.NRF_FLAG_WARP_F32
     return L.NRF_FLAG_BF16
@@ -279,7 +281,7 @@ class NerfModel:
   def workspace(self, num_rays: int, train: bool, device, num_background_points: int = 0, elastic: bool = False,
                 jacobian: bool = False, bf16=False) -> torch.Tensor:
     # the TRAINING layout depends on it (bf16 stashes instead of the fp32 ones); so does an 'x3' inference plan (its weight streams)
-    bf16 = bf16 if (train or bf16 == 'x3') else False
+    bf16 = 'x3' if bf16 in ('x3', 'x3mlp') else (bf16 if train else False)
     key = (int(num_rays), bool(train), str(device), int(num_background_points), bool(elastic), bool(jacobian), bf16)
     ws = self._ws.get(key)
     if ws is None:

@@ -8,7 +8,7 @@
 # Passes are separate processes: bench line, rocprofv3 kernel trace, three PMC passes (SQ / FETCH_SIZE / WRITE_SIZE never
 # share a pass, never combined with a trace domain).
 TAG=${1:-r04}
-MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_x3 eval_warp eval_warp_bf16 eval_warp_x3 train128 train128_graph sustained sustained_bf16"}
+MODES=${2:-"train train_bf16 vrig vrig_bf16 fullhd fullhd_bf16 eval eval_bf16 eval_x3 eval_warp eval_warp_bf16 eval_warp_x3 eval_warp_x3mlp train128 train128_graph sustained sustained_bf16"}
 O=gpurun_out
 mkdir -p $O
 export TMPDIR=/tmp
@@ -32,6 +32,7 @@ for mode in $MODES; do
     eval_bf16)      ARGS="--mode eval --bf16";                 SUF="_eval_bf16"; PMC=0 ;;
     eval_x3)        ARGS="--mode eval --split-bf16";           SUF="_eval_x3"; PMC=0 ;;
     eval_warp_x3)   ARGS="--mode eval --warp --frame --split-bf16"; SUF="_eval_warp_x3"; PMC=0 ;;
+    eval_warp_x3mlp) ARGS="--mode eval --warp --split-bf16 --warp-f32"; SUF="_eval_warp_x3mlp"; PMC=0; TRACE=0 ;;
     eval_warp)      ARGS="--mode eval --warp --frame";         SUF="_eval_warp"; PMC=0 ;;
     eval_warp_bf16) ARGS="--mode eval --warp --frame --bf16";  SUF="_eval_warp_bf16"; PMC=0 ;;
     train128)       ARGS="--rays-per-gpu 128";                 SUF="_train128"; PMC=0; TRACE=0 ;;

@@ -34,7 +34,8 @@ rows = [('', 'train, config A, fp32 (the headline)'), ('_train_bf16', 'train, co
         ('_eval_bf16', 'eval forward, bf16 operands, warp off'),
         ('_eval_x3', 'eval forward, split-bf16 (bf16x3, float32-emulating) NeRF chains, warp off'), ('_eval_warp', 'eval forward with the SE3 warp (as eval.py renders), fp32'),
         ('_eval_warp_bf16', 'eval forward with the SE3 warp, bf16 mode'),
-        ('_eval_warp_x3', 'eval forward with the SE3 warp (float32), split-bf16 NeRF chains'), ('_train128', 'config A, 128 rays per GPU (strong-scaling point)'),
+        ('_eval_warp_x3', 'eval forward with the SE3 warp, split-bf16 NeRF chains and SE3 trunk'),
+        ('_eval_warp_x3mlp', 'same with the SE3 trunk on the float32 kernels (`--warp-f32`)'), ('_train128', 'config A, 128 rays per GPU (strong-scaling point)'),
         ('_train128_graph', 'same, whole step from one hipGraph')]
 print('| line | rays/s | ms/step | step TF | roofline (dominant kernel) | traffic |')
 print('|---|---|---|---|---|---|')
@@ -47,7 +48,7 @@ for suf, label in rows:
   trs = f"{tr / 1e9:.2f} GB" if isinstance(tr, (int, float)) else (json.dumps(tr) if tr else 'null')
   print(f"| {label} (`{os.path.basename(pre)}_bench{suf}.json`) | {b['value'] / 1e3:.1f} k | {b['ms_per_step']:.3f} | {b['step_tflops']:.1f} | "
         f"{r.get('kernel', '')} {r['achieved']:.1f} / {r['peak']:.0f} {r['unit']} = {r['frac']:.3f} | {trs} |")
-for suf in ('', '_vrig', '_vrig_bf16', '_fullhd', '_fullhd_bf16', '_train_bf16', '_eval', '_eval_bf16', '_eval_x3', '_eval_warp', '_eval_warp_bf16', '_eval_warp_x3'):
+for suf in ('', '_vrig', '_vrig_bf16', '_fullhd', '_fullhd_bf16', '_train_bf16', '_eval', '_eval_bf16', '_eval_x3', '_eval_warp', '_eval_warp_bf16', '_eval_warp_x3', '_eval_warp_x3mlp'):
   b = load(suf)
   if not b:
     continue

@@ -26,19 +26,19 @@ def parse_flags(argv=None):
   p.add_argument('--gin_bindings', action='append', default=None, help='Gin parameter bindings.')
   p.add_argument('--gin_configs', action='append', default=[], help='Gin config files.')
   p.add_argument('--max_steps', type=int, default=None, help='stop early (smoke runs); default TrainConfig.max_steps')
-  p.add_argument('--bf16', nargs='?', const='all', default=None, choices=['all', 'mlp', 'x3'],
+  p.add_argument('--bf16', nargs='?', const='all', default=None, choices=['all', 'mlp', 'x3', 'x3mlp'],
                  help="bfloat16 MFMA operands (NRF_FLAG_BF16; no reference counterpart; fp32 master weights, posenc, exp_se3, compositing, "
                       "loss, Adam).  --bf16 / --bf16 all: the NeRF MLPs AND the SE3 warp trunk (BASELINE configs[3]; a warped point moves by "
                       "~5e-4 of its displacement; no systematic held-out-PSNR cost at the vrig preset's posenc widths over a 6000-step schedule, profiles/r05_bf16_warp_gap.json); --bf16 mlp: the NeRF MLPs only, the warp trunk stays float32 (NRF_FLAG_WARP_F32; about half the speed with the warp on; for captures whose deformation is large against the scene).  train.py "
                       "trains with a bfloat16 activation / gradient stash (~6x the fp32 step without the warp), eval.py renders with "
                       "bfloat16 operands (~1e-2 on colour, < 0.01 dB held-out PSNR).  --bf16 x3 (eval.py only): the NeRF MLPs in split-bf16 "
                       "arithmetic (NRF_FLAG_BF16X3: every float32 operand as a bf16 pair, three bf16 MFMAs per product, float32 accumulate) -- "
-                      "float32-emulating, ~1e-6 of the float32 render on colour at ~2-3x its speed; the warp field stays float32")
+                      "float32-emulating, ~1e-6 of the float32 render on colour without the warp, ~1e-5 with it, at ~3x its speed (--bf16 x3mlp: the SE3 trunk stays on the float32 kernels)")
   p.add_argument('--graph', action='store_true', help='replay the whole train step (loss + gradient, all-reduce, Adam) from ONE hipGraph '
                  '(training.GraphedTrainStep): the reference jits the step into one XLA executable (train.py:254-262); worth it for small '
                  'per-GPU batches, where the ~25 launches of a step take about as long as the kernels')
   flags = p.parse_args(argv)
-  flags.bf16 = {'all': True, 'mlp': 'mlp', 'x3': 'x3', None: False}[flags.bf16]   # the value models / training take (False, True, 'mlp', 'x3')
+  flags.bf16 = {'all': True, 'mlp': 'mlp', 'x3': 'x3', 'x3mlp': 'x3mlp', None: False}[flags.bf16]   # the value models / training take (False, True, 'mlp', 'x3')
   return flags
 
 
@@ -63,7 +63,7 @@ def make_datasource(flags, exp_config, model_config):
 
 def main(argv=None):
   flags = parse_flags(argv)
-  if flags.bf16 == 'x3':
+  if flags.bf16 in ('x3', 'x3mlp'):
     raise SystemExit('--bf16 x3 is an inference mode (eval.py): the training chains stash float32 or bfloat16 activations')
   gin.parse_config_files_and_bindings(config_files=flags.gin_configs, bindings=flags.gin_bindings, skip_unknown=True)
   exp_config, model_config, train_config = configs.ExperimentConfig(), configs.ModelConfig(), configs.TrainConfig()

@@ -130,6 +130,16 @@ def test_train_and_eval_drivers_end_to_end(tmp_path, capsys, extra):
   assert Image.open(os.path.join(rdir, 'rgb_000003.png')).size == (24, 16)
   assert Image.open(os.path.join(rdir, 'depth_median_000003.png')).mode in ('I;16', 'I')
   gin.clear_config()
+  if not extra:
+    # round 6: the same checkpoint rendered by the split-bf16 (float32-emulating) chains and trunk -- `eval.py --bf16 x3` -- and with the
+    # float32 trunk under them (`x3mlp`): the held-out metrics of the float32 render to 1e-3 dB; train.py refuses the inference mode
+    for mode in ('x3', 'x3mlp'):
+      r3 = eval_driver.main(args + ['--bf16', mode])
+      gin.clear_config()
+      assert abs(r3['val']['psnr'] - res['val']['psnr']) < 1e-3 and abs(r3['train']['mse'] - res['train']['mse']) < 1e-6 * max(1.0, res['train']['mse'] * 1e6), (mode, r3, res)
+    with pytest.raises(SystemExit):
+      train_driver.main(args + ['--bf16', 'x3'])
+    gin.clear_config()
 
 
 def test_configs0_test_local_preset_end_to_end(tmp_path, capsys):

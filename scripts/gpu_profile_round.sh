@@ -49,6 +49,9 @@ for mode in $MODES; do
   [ $TRACE = 0 ] && continue
   rm -rf $O/prof_${TAG}${SUF} $O/pmc1_${TAG}${SUF} $O/pmc2_${TAG}${SUF} $O/pmc3_${TAG}${SUF}
   PARGS=${ARGS/ --frame/}   # the trace / counter passes time chunks only: a whole frame under PMC serialisation took > 30 min once (round 4)
+  # ... and the headline workload ALONE: since round 6 the default line also runs the secondary workloads, whose launches of the same
+  # kernel symbols (other shapes) would be averaged into the per-launch times and bytes of the config-A kernels
+  [ "$mode" = train ] && PARGS="$PARGS --no-extras"
   timeout 300 rocprofv3 --kernel-trace --stats -d $O/prof_${TAG}${SUF} -o kt -- python bench.py $PARGS --steps 10 --warmup 2 --burn-in-s 0 --no-cpu-baseline > $O/prof_${TAG}${SUF}.log 2>&1
   summ $O/prof_${TAG}${SUF} $O/${TAG}${SUF}_kernel_stats.md
   timeout 300 rocprofv3 --pmc $SQ -d $O/pmc1_${TAG}${SUF} -o pmc -- python bench.py $PARGS --steps 3 --warmup 1 --burn-in-s 0 --no-cpu-baseline > $O/pmc1_${TAG}${SUF}.log 2>&1

@@ -26,7 +26,8 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda'
 
 # the cases the bf16 chains can lay out (skip at layer 4); the moved-skip cases are float32-only (NRF_E_UNSUPPORTED, below)
-SMALL = ['nowarp', 'camera', 'warp', 'nocond', 'nocond_warp', 'depth6', 'depth3', 'skip2_depth6', 'warp_trunk5x96']
+SMALL = ['nowarp', 'camera', 'warp', 'nocond', 'nocond_warp', 'depth6', 'depth3', 'skip2_depth6', 'warp_trunk5x96', 'warp_trunk3x64',
+         'translation_trunk4x80']
 
 
 @pytest.mark.parametrize('name', SMALL)
@@ -145,6 +146,32 @@ def test_x3_with_the_float32_warp_trunk_keeps_the_warped_points():
   for lv in ('coarse', 'fine'):
     np.testing.assert_allclose(_np(a[lv]['rgb']), _np(b[lv]['rgb']), atol=1e-5)
     np.testing.assert_allclose(_np(c[lv]['rgb']), _np(b[lv]['rgb']), atol=1e-4)
+
+
+@pytest.mark.parametrize('kw,B,alpha,time_alpha', [
+    (dict(num_nerf_point_freqs=8, num_warp_freqs=6, num_warp_features=5, use_camera_metadata=True, num_coarse_samples=32, num_fine_samples=32), 33, 4.5, 0.4),
+    (dict(num_nerf_point_freqs=6, warp_field_type='translation', num_coarse_samples=24, num_fine_samples=24), 12, 2.0, 0.0)])
+def test_x3_with_the_time_encoder_and_encoded_codes(kw, B, alpha, time_alpha):
+  """The warp metadata as per-ray codes (modules.TimeEncoder's output, modules.py:297-322; or metadata_encoded=True, warping.py:378-381):
+  the split-bf16 trunk gathers row `ray` of the code table; against the float32 path on the same rays."""
+  spec = O.ModelSpec(use_warp=True, use_stratified_sampling=False, warp_metadata_encoder_type='time', **kw)
+  p = O.init_params(spec, seed=17, trained_like=True)
+  b = O.synthetic_batch(B, seed=18)
+  model, fp = H.gpu_model(spec, p, B)
+  gb = H.gpu_batch(b)
+  extra = {'alpha': alpha, 'time_alpha': time_alpha}
+  a = model.apply({'params': fp}, gb, extra, bf16='x3', return_points=True)
+  f = model.apply({'params': fp}, gb, extra, return_points=True)
+  np.testing.assert_allclose(_np(a['coarse']['warped_points']), _np(f['coarse']['warped_points']), atol=5e-5)
+  for lv in ('coarse', 'fine'):
+    np.testing.assert_allclose(_np(a[lv]['rgb']), _np(f[lv]['rgb']), atol=1e-4)
+    np.testing.assert_allclose(_np(a[lv]['depth']), _np(f[lv]['depth']), atol=1e-4)
+  if not spec.use_camera_metadata:   # metadata_encoded wants every metadata entry as codes: the case whose only entry is the time stamp
+    codes = O.time_encode(p['warp_field']['metadata_encoder'], b['metadata']['time'].double(), spec.num_time_encoder_freqs, time_alpha)
+    enc = dict(gb)
+    enc['metadata'] = {'time': codes.float().to(DEV)}
+    c = model.apply({'params': fp}, enc, extra, metadata_encoded=True, bf16='x3')
+    np.testing.assert_allclose(_np(c['fine']['rgb']), _np(a['fine']['rgb']), atol=5e-5)
 
 
 def test_x3_is_an_inference_mode_of_its_own():
